@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+STANDARD_CASES = [
+    "c1_304x240_n10000_pm1", "c1_304x240_n10000_01", "dense_64x48_n61440_pm1",
+    "s_80x60_n4095_pm1", "s_80x60_n4097_01", "s_80x60_n5000_pm1", "s_80x60_n5001_pm1",
+    "s_80x60_n5002_01", "duplast_80x60_n3000_pm1", "shortspan_40x30_n2000_pm1",
+    "single_pos_80x60_n2000", "single_neg_80x60_n2000", "single_zero_80x60_n2000",
+    "tiny_16x12_n13_pm1", "tiny_16x12_n2_01",
+]
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as o
+    o.build()
+    return o
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    if not np.array_equal(a.view(np.uint8), b.view(np.uint8)):
+        # -0.0 vs 0.0 and NaN payloads count as different on purpose; report the first mismatch
+        bad = np.flatnonzero(~((a == b) | ((a != a) & (b != b))).reshape(-1))
+        if bad.size == 0:
+            bad = np.flatnonzero(a.reshape(-1).view(np.uint8 if a.itemsize == 1 else "u%d" % a.itemsize)
+                                 != b.reshape(-1).view("u%d" % a.itemsize))
+        i = int(bad[0])
+        raise AssertionError("%s: %d mismatches, first at flat %d: %r vs %r"
+                             % (what, bad.size, i, a.reshape(-1)[i], b.reshape(-1)[i]))
