@@ -1,0 +1,98 @@
+"""ctypes binding of libevrep.so (the C ABI declared in include/evrep.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load, importing
+a builder raises.  (The library is built in-tree by ``event_representation_study_amd.build``.)
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libevrep.so")
+
+EVREP_OK, EVREP_EINVAL, EVREP_EWORKSPACE, EVREP_EHIP, EVREP_ENOTBINNED = 0, 1, 2, 3, 4
+ST_EMPTY, ST_OOB, ST_UNSORTED, ST_FLAT_TIME = 1, 2, 4, 8
+F64, F32 = 0, 1
+MAX_CHANNELS = 16
+MAX_DIM = 4096
+ABI_VERSION = 1
+
+FUNCS = ["timestamp", "polarity", "count", "timestamp_pos", "timestamp_neg", "count_pos", "count_neg"]
+AGGS = ["sum", "mean", "max", "variance"]
+
+
+class Plan(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("total_events", ctypes.c_int64),
+        ("max_events_per_window", ctypes.c_int64),
+        ("chunk", ctypes.c_int32), ("nblk", ctypes.c_int32),
+        ("off_meta", ctypes.c_size_t), ("off_table", ctypes.c_size_t), ("off_rowoff", ctypes.c_size_t),
+        ("off_sorted1", ctypes.c_size_t), ("off_sorted2", ctypes.c_size_t), ("off_cuts", ctypes.c_size_t),
+        ("off_scratch", ctypes.c_size_t),
+        ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+# every symbol include/evrep.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_float
+_PP = ctypes.POINTER(Plan)
+_I32P = ctypes.POINTER(ctypes.c_int32)
+SYMBOLS = {
+    "evrep_abi_version": (ctypes.c_int, []),
+    "evrep_last_hip_error": (ctypes.c_char_p, []),
+    "evrep_plan_init": (ctypes.c_int, [_PP, _i32, _i32, _i32, _i64, _i64]),
+    "evrep_workspace_bytes": (ctypes.c_size_t, [_PP]),
+    "evrep_bin_events": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp]),
+    "evrep_mdes": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _I32P, _I32P, _I32P, _f64, _i32, _vp, _vp]),
+    "evrep_optimized": (ctypes.c_int, [_PP, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
+    "evrep_event_stack": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
+    "evrep_time_surface": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _f64, _i32, _f64, _i32, _vp, _vp]),
+    "evrep_tore": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
+    "evrep_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f64, _vp, _vp]),
+    "evrep_read_status": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
+    "evrep_read_bbox": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
+    "evrep_gwd_scratch_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "evrep_gwd_padded_l1": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class EvrepError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libevrep.so; raises (loudly) if the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvrepError(
+            "libevrep.so is missing (%s). Build it with `python -m event_representation_study_amd.build`; "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.evrep_abi_version() != ABI_VERSION:
+        raise EvrepError("libevrep.so ABI %d != binding ABI %d" % (lib.evrep_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc == EVREP_OK:
+        return
+    names = {EVREP_EINVAL: "EVREP_EINVAL (bad argument)", EVREP_EWORKSPACE: "EVREP_EWORKSPACE",
+             EVREP_EHIP: "EVREP_EHIP", EVREP_ENOTBINNED: "EVREP_ENOTBINNED"}
+    msg = names.get(rc, "rc=%d" % rc)
+    if rc == EVREP_EHIP:
+        msg += ": " + (load().evrep_last_hip_error() or b"").decode()
+    raise EvrepError("%s failed: %s" % (what or "libevrep call", msg))
+
+
+def int32_array(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])

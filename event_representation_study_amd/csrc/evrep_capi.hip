@@ -1,0 +1,278 @@
+// evrep_capi.hip -- the extern "C" surface declared in include/evrep.h: argument checks, workspace
+// carving and kernel launches.  No allocation, no global state besides the last HIP error string.
+#include <string.h>
+
+#include "evrep_common.h"
+
+// kernels (defined in the sibling translation units; everything is compiled into one .so)
+#include "evrep_bin.hip"
+#include "evrep_builders.hip"
+#include "evrep_gwd.hip"
+
+using namespace evrep;
+
+static thread_local char g_last_error[256] = "";
+
+static int hip_check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return EVREP_OK;
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return EVREP_EHIP;
+}
+#define LAUNCH_CHECK(what)                                  \
+    do {                                                    \
+        int rc_ = hip_check(hipGetLastError(), what);       \
+        if (rc_ != EVREP_OK) return rc_;                    \
+    } while (0)
+
+static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" {
+
+int evrep_abi_version(void) { return EVREP_ABI_VERSION; }
+const char *evrep_last_hip_error(void) { return g_last_error; }
+
+int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
+                    int64_t max_events_per_window) {
+    if (!plan || B <= 0 || H <= 0 || W <= 0 || H > EVREP_MAX_DIM || W > EVREP_MAX_DIM) return EVREP_EINVAL;
+    if (total_events < 0 || max_events_per_window < 0 || max_events_per_window > total_events) return EVREP_EINVAL;
+    if (total_events >= (int64_t)1 << 31 || (int64_t)H * W >= (int64_t)1 << 30) return EVREP_EINVAL;
+    memset(plan, 0, sizeof(*plan));
+    plan->abi_version = EVREP_ABI_VERSION;
+    plan->B = B; plan->H = H; plan->W = W;
+    plan->total_events = total_events;
+    plan->max_events_per_window = max_events_per_window;
+    int64_t chunk = 2048;
+    int64_t nblk = (max_events_per_window + chunk - 1) / chunk;
+    if (nblk > 128) {
+        chunk = ((max_events_per_window + 127) / 128 + 255) / 256 * 256;
+        nblk = (max_events_per_window + chunk - 1) / chunk;
+    }
+    if (nblk < 1) nblk = 1;
+    plan->chunk = (int32_t)chunk;
+    plan->nblk = (int32_t)nblk;
+    size_t o = 0;
+    plan->off_meta = o;    o += up256((size_t)B * sizeof(WindowMeta));
+    plan->off_table = o;   o += up256((size_t)B * nblk * H * sizeof(uint32_t));
+    plan->off_rowoff = o;  o += up256((size_t)B * (H + 1) * sizeof(uint32_t));
+    plan->off_sorted1 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
+    plan->off_sorted2 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
+    plan->off_cuts = o;    o += up256((size_t)B * sizeof(TsCuts));
+    plan->off_scratch = o; o += 256;
+    plan->workspace_bytes = o;
+    return EVREP_OK;
+}
+
+size_t evrep_workspace_bytes(const evrep_plan *plan) { return plan ? plan->workspace_bytes : 0; }
+
+static int check_common(const evrep_plan *plan, const void *events, const void *offsets, const void *ws) {
+    if (!plan || plan->abi_version != EVREP_ABI_VERSION || !offsets || !ws) return EVREP_EINVAL;
+    if (plan->total_events > 0 && !events) return EVREP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(events) & 15u) || (reinterpret_cast<uintptr_t>(ws) & 255u)) return EVREP_EINVAL;
+    return EVREP_OK;
+}
+
+#define WS(type, field) reinterpret_cast<type *>(static_cast<char *>(workspace) + plan->field)
+#define CWS(type, field) reinterpret_cast<const type *>(static_cast<const char *>(workspace) + plan->field)
+
+int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                     void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int B = plan->B, H = plan->H, W = plan->W, chunk = plan->chunk, nblk = plan->nblk;
+    const int4 *ev = reinterpret_cast<const int4 *>(events);
+    WindowMeta *meta = WS(WindowMeta, off_meta);
+    uint32_t *table = WS(uint32_t, off_table);
+    uint32_t *row_off = WS(uint32_t, off_rowoff);
+    Rec *s1 = WS(Rec, off_sorted1);
+    Rec *s2 = WS(Rec, off_sorted2);
+    k_init_meta<<<(B + 63) / 64, 64, 0, stream>>>(meta, B);
+    LAUNCH_CHECK("k_init_meta");
+    k_row_hist<<<dim3(nblk, B), kThreads, (size_t)H * 4, stream>>>(ev, offsets, H, W, chunk, nblk, table, meta);
+    LAUNCH_CHECK("k_row_hist");
+    k_row_scan<<<B, kThreads, (size_t)(H + 8) * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, meta);
+    LAUNCH_CHECK("k_row_scan");
+    k_row_scatter<<<dim3(nblk, B), kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, H, W, chunk, nblk, table, row_off, s1);
+    LAUNCH_CHECK("k_row_scatter");
+    k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, s2);
+    LAUNCH_CHECK("k_col_sort");
+    return EVREP_OK;
+}
+
+static size_t builder_lds(int W, int C, size_t elem) { return align16((size_t)2 * W * 4) + align16((size_t)kThreads * C * elem) + 256; }
+
+int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
+               const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
+               void *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (C <= 0 || C > EVREP_MAX_CHANNELS || !window || !func || !agg || !out) return EVREP_EINVAL;
+    if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MdesParams P;
+    memset(&P, 0, sizeof(P));
+    P.C = C;
+    for (int c = 0; c < C; ++c) { P.win[c] = window[c]; P.func[c] = func[c]; P.agg[c] = agg[c]; }
+    const dim3 grid(plan->H, plan->B);
+    if (out_dtype == EVREP_F64) {
+        k_mdes<double><<<grid, kThreads, builder_lds(plan->W, C, 8), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
+            scale, static_cast<double *>(out));
+    } else {
+        k_mdes<float><<<grid, kThreads, builder_lds(plan->W, C, 4), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
+            scale, static_cast<float *>(out));
+    }
+    LAUNCH_CHECK("k_mdes");
+    return EVREP_OK;
+}
+
+int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                    double scale, int32_t out_dtype, void *out, void *stream) {
+    // the ERGO-12 triples, optimized_representation.py:87-115
+    static const int32_t win[12] = {0, 3, 2, 6, 5, 6, 2, 5, 1, 0, 4, 1};
+    static const int32_t func[12] = {EVREP_F_POLARITY, EVREP_F_TIMESTAMP_NEG, EVREP_F_COUNT_NEG, EVREP_F_POLARITY,
+                                     EVREP_F_COUNT_POS, EVREP_F_COUNT, EVREP_F_TIMESTAMP_POS, EVREP_F_COUNT_NEG,
+                                     EVREP_F_TIMESTAMP_NEG, EVREP_F_TIMESTAMP_POS, EVREP_F_TIMESTAMP, EVREP_F_COUNT};
+    static const int32_t agg[12] = {EVREP_A_VARIANCE, EVREP_A_VARIANCE, EVREP_A_MEAN, EVREP_A_SUM, EVREP_A_MEAN, EVREP_A_SUM,
+                                    EVREP_A_MEAN, EVREP_A_MEAN, EVREP_A_MAX, EVREP_A_MAX, EVREP_A_MAX, EVREP_A_MEAN};
+    return evrep_mdes(plan, events, offsets, workspace, 12, win, func, agg, scale, out_dtype, out, stream);
+}
+
+int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      int32_t stack_size, int32_t premap, float scale, float *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    k_event_stack<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, stack_size, 4), stream>>>(
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, plan->H, plan->W, stack_size, premap, scale, out);
+    LAUNCH_CHECK("k_event_stack");
+    return EVREP_OK;
+}
+
+int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                       int32_t slices, double tau, int32_t premap, double scale, int32_t out_dtype, void *out,
+                       void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (slices <= 0 || slices > kMaxSlices || !out || !(tau > 0.0)) return EVREP_EINVAL;
+    if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    TsCuts *cuts = WS(TsCuts, off_cuts);
+    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, cuts);
+    LAUNCH_CHECK("k_ts_cuts");
+    const dim3 grid(plan->H, plan->B);
+    if (out_dtype == EVREP_F64) {
+        k_time_surface<double><<<grid, kThreads, builder_lds(plan->W, 2 * slices, 8), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), cuts, plan->H, plan->W, slices, tau, premap, scale,
+            static_cast<double *>(out));
+    } else {
+        k_time_surface<float><<<grid, kThreads, builder_lds(plan->W, 2 * slices, 4), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), cuts, plan->H, plan->W, slices, tau, premap, scale,
+            static_cast<float *>(out));
+    }
+    LAUNCH_CHECK("k_time_surface");
+    return EVREP_OK;
+}
+
+int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t k,
+               int32_t frame_mode, float scale, float *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    k_tore<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, 2 * k, 4), stream>>>(
+        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets,
+        CWS(WindowMeta, off_meta), plan->H, plan->W, k, frame_mode, scale, out);
+    LAUNCH_CHECK("k_tore");
+    return EVREP_OK;
+}
+
+int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t bins,
+                int32_t mode, double scale, double *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 1 || !out) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    k_voxel<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, bins, 8), stream>>>(
+        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, plan->H,
+        plan->W, bins, mode, scale, out);
+    LAUNCH_CHECK("k_voxel");
+    return EVREP_OK;
+}
+
+int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream_) {
+    if (!plan || !workspace || !status) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (rc) return rc;
+    const WindowMeta *meta = CWS(WindowMeta, off_meta);
+    for (int b = 0; b < plan->B; ++b) {
+        WindowMeta m;
+        rc = hip_check(hipMemcpy(&m, meta + b, sizeof(m), hipMemcpyDeviceToHost), "hipMemcpy(meta)");
+        if (rc) return rc;
+        status[b] = m.status;
+    }
+    return EVREP_OK;
+}
+
+int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox, void *stream_) {
+    if (!plan || !workspace || !bbox) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (rc) return rc;
+    const WindowMeta *meta = CWS(WindowMeta, off_meta);
+    for (int b = 0; b < plan->B; ++b) {
+        WindowMeta m;
+        rc = hip_check(hipMemcpy(&m, meta + b, sizeof(m), hipMemcpyDeviceToHost), "hipMemcpy(meta)");
+        if (rc) return rc;
+        bbox[4 * b + 0] = m.xmin; bbox[4 * b + 1] = m.ymin; bbox[4 * b + 2] = m.xmax; bbox[4 * b + 3] = m.ymax;
+    }
+    return EVREP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- GWD
+static int64_t pad_tile(int64_t n) { return (n + kTile - 1) / kTile * kTile; }
+
+size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m) {
+    if (n <= 0 || m <= 0) return 0;
+    const int64_t L = n > m ? n : m;
+    const int64_t T = pad_tile(L) / kTile;
+    size_t o = up256(sizeof(GwdStats));
+    o += up256((size_t)kGwdMaxD * pad_tile(n) * sizeof(float));
+    o += up256((size_t)kGwdMaxD * pad_tile(m) * sizeof(float));
+    o += up256((size_t)(T * (T + 1) / 2) * sizeof(double));
+    return o;
+}
+
+int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt, double h,
+                        void *scratch, double *cost, void *stream_) {
+    if (!Xs || !Xt || !scratch || !cost || n <= 0 || m <= 0 || ds <= 0 || dt <= 0 || ds > kGwdMaxD || dt > kGwdMaxD)
+        return EVREP_EINVAL;
+    if (!(h > 0.0) || (reinterpret_cast<uintptr_t>(scratch) & 255u)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t npad = pad_tile(n), mpad = pad_tile(m);
+    const int64_t L = n > m ? n : m;
+    const int T = (int)(pad_tile(L) / kTile);
+    if ((int64_t)T * (T + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
+    char *p = static_cast<char *>(scratch);
+    GwdStats *st = reinterpret_cast<GwdStats *>(p); p += up256(sizeof(GwdStats));
+    float *Ys = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * npad * sizeof(float));
+    float *Yt = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * mpad * sizeof(float));
+    double *partial = reinterpret_cast<double *>(p);
+    k_gwd_stats<<<2, kThreads, 0, stream>>>(Xs, n, ds, Xt, m, dt, st);
+    LAUNCH_CHECK("k_gwd_stats");
+    k_gwd_prep<<<(unsigned)((npad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xs, n, ds, npad, st, 0, h, Ys);
+    LAUNCH_CHECK("k_gwd_prep(s)");
+    k_gwd_prep<<<(unsigned)((mpad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xt, m, dt, mpad, st, 1, h, Yt);
+    LAUNCH_CHECK("k_gwd_prep(t)");
+    const int ntiles = T * (T + 1) / 2;
+    k_gwd_tiles<<<ntiles, kThreads, (size_t)2 * (ds + dt) * kTile * sizeof(float), stream>>>(Ys, ds, n, npad, Yt, dt, m, mpad, T, partial);
+    LAUNCH_CHECK("k_gwd_tiles");
+    k_gwd_finish<<<1, kThreads, 0, stream>>>(partial, ntiles, (double)L, cost);
+    LAUNCH_CHECK("k_gwd_finish");
+    return EVREP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// evrep_common.h -- shared device-side definitions of libevrep (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "evrep.h"
+
+namespace evrep {
+
+constexpr int kThreads = 256;  // 4 wave64 per workgroup
+constexpr int kWaves = 4;
+constexpr int kWave = 64;
+
+// Per-window statistics produced by the binning pass (workspace, one per window).
+struct WindowMeta {
+    int32_t tmin, tmax;              // over all events of the window
+    int32_t xmin, xmax, ymin, ymax;  // over all events of the window (raw coordinates)
+    uint32_t neg_flags;              // bit w: an event with p == -1 exists in MDES window w
+    uint32_t oob_flags;              // bit 7*c + w: out-of-frame key in MDES window w, class c (0 any, 1 p==1, 2 p==-1, 3 p==0)
+    uint32_t status;                 // EVREP_ST_*
+    int32_t n_valid;                 // in-frame events
+    int32_t pad[6];
+};
+static_assert(sizeof(WindowMeta) == 64, "WindowMeta is one 64-byte line");
+
+// One binned event: 16 bytes, what both partition levels move and every builder reads.
+//   x = pixel id (x + y*W) inside the window, y = rank (index inside the window, i.e. time order),
+//   z = t (raw int32 timestamp), w = p (raw polarity)
+using Rec = int4;
+
+// The 7 "SBN" windows of MixedDensityEventStack.create_windows
+// (representation_search/mixed_density_event_stack.py:48-74) as [lo, hi) rank ranges.
+struct MdesWindows {
+    int32_t lo[7], hi[7];
+};
+
+__host__ __device__ inline MdesWindows mdes_windows(int64_t n64) {
+    MdesWindows w;
+    int32_t n = (int32_t)n64;
+    int32_t third = n / 3;
+    w.lo[0] = 0; w.hi[0] = n;
+    for (int i = 0; i < 3; ++i) { w.lo[1 + i] = i * third; w.hi[1 + i] = (i + 1) * third; }
+    int32_t cur = n, start = 0;
+    for (int i = 0; i < 3; ++i) { cur /= 2; start += cur; w.lo[4 + i] = start; w.hi[4 + i] = n; }
+    return w;
+}
+
+// bit w set iff rank r lies in MDES window w
+__device__ inline uint32_t mdes_membership(const MdesWindows &w, int32_t r) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m |= (r >= w.lo[i] && r < w.hi[i]) ? (1u << i) : 0u;
+    return m;
+}
+
+__device__ inline int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Stable in-wave multisplit: for every valid lane, `rank` = number of lower valid lanes holding
+// the same key, `last` = no higher valid lane holds it.  nbits = significant key bits (uniform).
+__device__ inline void wave_match(uint32_t key, int nbits, bool valid, int lane, uint32_t &rank, bool &last) {
+    uint64_t mask = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+        bool bit = (key >> b) & 1u;
+        uint64_t bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+    }
+    uint64_t below = (1ull << lane) - 1ull;
+    rank = (uint32_t)__popcll(mask & below);
+    last = (mask & ~below & ~(1ull << lane)) == 0ull;
+}
+
+__device__ inline int bits_for(int n) {  // bits needed to represent values in [0, n)
+    int b = 0;
+    while ((1 << b) < n) ++b;
+    return b;
+}
+
+// Exclusive scan of one uint32 per thread across a 256-thread workgroup. tmp: >= 8 uint32 of LDS.
+// Returns the exclusive prefix; *total receives the workgroup sum.  Contains __syncthreads().
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) tmp[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        uint32_t t = tmp[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+}  // namespace evrep

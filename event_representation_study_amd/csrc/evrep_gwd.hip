@@ -1,0 +1,198 @@
+// evrep_gwd.hip -- the GWD score of representation_search/compute_otmi.py:61-93 in closed form
+// for POT's max_iter=0 path:
+//     C = (1/L^2) * sum_{i,j<L} | Ks_pad[i,j] - Kt_pad[i,j] |,   L = max(n, m),
+//     K = exp(-(D / (h*sigma))^2 / 2),  D = pairwise L2,  sigma^2 = mean(D^2) / 2.
+// Nothing n^2 touches HBM: the two Gaussian kernels are generated tile by tile from the point
+// coordinates (LDS-resident) and folded into the |.| sum on the fly.  sigma needs no n^2 pass:
+// mean_ij ||a_i - a_j||^2 = 2 * mean_i ||a_i - abar||^2.  The kernel is VALU / transcendental
+// bound (d <= 32 is far too thin for MFMA to matter); both K matrices are symmetric, so only
+// upper-triangular tiles are evaluated.
+#include "evrep_common.h"
+
+namespace evrep {
+
+constexpr int kGwdMaxD = 32;
+constexpr int kTile = 128;  // tile edge; 256 threads, each an 8x8 register block
+
+// scratch layout (floats unless noted):
+//   [0, 64) doubles : stats: mean_s[32], then (as doubles) ...   (see offsets below)
+struct GwdStats {
+    double mean_s[kGwdMaxD], mean_t[kGwdMaxD];
+    double var_s, var_t;  // mean ||a - abar||^2  (= sigma^2)
+};
+
+// grid (2): block 0 -> Xs, block 1 -> Xt.  Two-pass mean / centred second moment in float64.
+__global__ __launch_bounds__(kThreads) void k_gwd_stats(const double *__restrict__ Xs, int64_t n, int ds,
+                                                       const double *__restrict__ Xt, int64_t m, int dt,
+                                                       GwdStats *__restrict__ st) {
+    __shared__ double red[kThreads];
+    __shared__ double mean[kGwdMaxD];
+    const bool second = blockIdx.x == 1;
+    const double *X = second ? Xt : Xs;
+    const int64_t N = second ? m : n;
+    const int d = second ? dt : ds;
+    for (int k = 0; k < d; ++k) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < N; i += kThreads) s += X[i * d + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = kThreads / 2; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) mean[k] = red[0] / (double)N;
+        __syncthreads();
+    }
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += kThreads)
+        for (int k = 0; k < d; ++k) { const double u = X[i * d + k] - mean[k]; s += u * u; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < d) (second ? st->mean_t : st->mean_s)[threadIdx.x] = mean[threadIdx.x];
+    if (threadIdx.x == 0) (second ? st->var_t : st->var_s) = red[0] / (double)N;
+}
+
+// Centre, scale by sqrt(log2(e) / (2 h^2 sigma^2)) so that K = exp2(-||a'_i - a'_j||^2), and lay
+// the cloud out dimension-major (SoA) in float32, padded with zeros to a multiple of kTile points.
+__global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict__ X, int64_t N, int d, int64_t Npad,
+                                                      const GwdStats *__restrict__ st, int which, double h,
+                                                      float *__restrict__ Y /* [d][Npad] */) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= Npad) return;
+    const double var = which ? st->var_t : st->var_s;
+    const double *mean = which ? st->mean_t : st->mean_s;
+    const double sc = sqrt(1.4426950408889634 / (2.0 * h * h * var));
+    for (int k = 0; k < d; ++k) {
+        float v;
+        if (i < N) v = (float)((X[i * d + k] - mean[k]) * sc);
+        else v = 0.0f;  // padding rows are masked in k_gwd_tiles
+        Y[(int64_t)k * Npad + i] = v;
+    }
+}
+
+template <int D>
+__device__ inline void tile_accumulate(const float *__restrict__ A, const float *__restrict__ Bm, int lds_stride,
+                                       int ti, int tj, float (&acc)[8][8]) {
+    // A: LDS [D][kTile] row points, Bm: LDS [D][kTile] column points; thread owns rows ti*8.., cols tj*8..
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        float a[8], b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = A[k * lds_stride + ti * 8 + r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = Bm[k * lds_stride + tj * 8 + c];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float u = a[r] - b[c]; acc[r][c] = fmaf(u, u, acc[r][c]); }
+    }
+}
+
+__device__ inline void tile_accumulate_rt(const float *__restrict__ A, const float *__restrict__ Bm, int lds_stride,
+                                          int D, int ti, int tj, float (&acc)[8][8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        float a[8], b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = A[k * lds_stride + ti * 8 + r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = Bm[k * lds_stride + tj * 8 + c];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float u = a[r] - b[c]; acc[r][c] = fmaf(u, u, acc[r][c]); }
+    }
+}
+
+// grid: one workgroup per upper-triangular tile pair (bi <= bj) of the L x L grid, T = Lpad/kTile.
+// partial[blockIdx.x] = sum over the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
+__global__ __launch_bounds__(kThreads) void k_gwd_tiles(const float *__restrict__ Ys, int ds, int64_t n, int64_t npad,
+                                                       const float *__restrict__ Yt, int dt, int64_t m, int64_t mpad,
+                                                       int T, double *__restrict__ partial) {
+    extern __shared__ float lds[];  // As[ds][kTile] Bs[ds][kTile] At[dt][kTile] Bt[dt][kTile]
+    // decode (bi, bj), bi <= bj, from the linear upper-triangular index
+    int t = blockIdx.x, bi = 0;
+    while (t >= T - bi) { t -= T - bi; ++bi; }
+    const int bj = bi + t;
+    const int64_t i0 = (int64_t)bi * kTile, j0 = (int64_t)bj * kTile;
+    const bool has_s = j0 < n, has_t = j0 < m;  // bi <= bj: the row range starts no later
+    float *As = lds, *Bs = lds + ds * kTile, *At = lds + 2 * ds * kTile, *Bt = At + dt * kTile;
+    if (has_s)
+        for (int e = threadIdx.x; e < ds * kTile; e += kThreads) {
+            const int k = e / kTile, i = e % kTile;
+            As[e] = Ys[(int64_t)k * npad + i0 + i];
+            Bs[e] = Ys[(int64_t)k * npad + j0 + i];
+        }
+    if (has_t)
+        for (int e = threadIdx.x; e < dt * kTile; e += kThreads) {
+            const int k = e / kTile, i = e % kTile;
+            At[e] = Yt[(int64_t)k * mpad + i0 + i];
+            Bt[e] = Yt[(int64_t)k * mpad + j0 + i];
+        }
+    __syncthreads();
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    float ks[8][8], kt[8][8];
+    if (has_s) {
+        if (ds == 4) tile_accumulate<4>(As, Bs, kTile, ti, tj, ks);
+        else tile_accumulate_rt(As, Bs, kTile, ds, ti, tj, ks);
+    }
+    if (has_t) {
+        if (dt == 14) tile_accumulate<14>(At, Bt, kTile, ti, tj, kt);
+        else tile_accumulate_rt(At, Bt, kTile, dt, ti, tj, kt);
+    }
+    float sum = 0.0f;
+    const int64_t lim = n < m ? n : m;
+    if (j0 + kTile <= lim) {  // interior tile: every entry exists in both kernels
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                sum += fabsf(__builtin_amdgcn_exp2f(-ks[r][c]) - __builtin_amdgcn_exp2f(-kt[r][c]));
+    } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
+        const int64_t gi0 = i0 + ti * 8, gj0 = j0 + tj * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int64_t gi = gi0 + r, gj = gj0 + c;
+                const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(-ks[r][c]) : 0.0f;
+                const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(-kt[r][c]) : 0.0f;
+                sum += fabsf(a - bb);
+            }
+    }
+    __shared__ double red[kThreads];
+    red[threadIdx.x] = (double)sum;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = (bi == bj ? 1.0 : 2.0) * red[0];
+}
+
+// grid (1): deterministic final reduction; cost = sum / L^2.
+__global__ __launch_bounds__(kThreads) void k_gwd_finish(const double *__restrict__ partial, int count, double L,
+                                                        double *__restrict__ cost) {
+    __shared__ double red[kThreads];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += kThreads) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *cost = red[0] / (L * L);
+}
+
+}  // namespace evrep

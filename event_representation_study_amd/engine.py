@@ -1,0 +1,218 @@
+"""Device-resident batch engine: the fast path of the package.
+
+A :class:`EventBatch` holds B windows of events as one concatenated ``(total, 4)`` int32 tensor
+plus ``B+1`` offsets in HBM, runs the (y,x) binning pass once, and then builds any number of
+representations from the binned stream -- all on the caller's HIP stream, no host sync.
+
+The per-sample functions that mirror the reference's Python names
+(``representations/*.py``) are thin wrappers over this class with B = 1.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Plan, check
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.EvrepError("no HIP device visible: the builders run on an MI355X only (no CPU fallback)")
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class EventBatch:
+    """B event windows resident on one GPU.
+
+    events  : (total, 4) int32 cuda tensor, rows [x, y, t, p], each window time-sorted
+    offsets : (B+1,) int64 tensor (host or device); window b = rows [offsets[b], offsets[b+1])
+    """
+
+    def __init__(self, events, offsets, height, width, max_events_per_window=None):
+        _require_gpu()
+        self.lib = _lib.load()
+        if events.dtype != torch.int32 or events.dim() != 2 or events.shape[1] != 4 or not events.is_cuda:
+            raise ValueError("events must be a (total, 4) int32 CUDA tensor")
+        self.events = events.contiguous()
+        self.device = events.device
+        off_host = offsets.detach().cpu().to(torch.int64) if isinstance(offsets, torch.Tensor) else \
+            torch.as_tensor(np.asarray(offsets, dtype=np.int64))
+        if max_events_per_window is None:
+            max_events_per_window = int((off_host[1:] - off_host[:-1]).max().item()) if off_host.numel() > 1 else 0
+        self.offsets_host = off_host
+        self.offsets = off_host.to(self.device)
+        self.B = int(off_host.numel() - 1)
+        self.H, self.W = int(height), int(width)
+        self.total = int(self.events.shape[0])
+        self.plan = Plan()
+        check(self.lib.evrep_plan_init(ctypes.byref(self.plan), self.B, self.H, self.W, self.total,
+                                       int(max_events_per_window)), "evrep_plan_init")
+        nbytes = int(self.lib.evrep_workspace_bytes(ctypes.byref(self.plan)))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._binned = False
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_numpy(cls, windows, height, width, device="cuda:0"):
+        """windows: list of (n_b, 4) int32 arrays (or one array) -> device batch."""
+        _require_gpu()
+        if isinstance(windows, np.ndarray):
+            windows = [windows]
+        ws = [np.ascontiguousarray(w, dtype=np.int32).reshape(-1, 4) for w in windows]
+        offs = np.zeros(len(ws) + 1, dtype=np.int64)
+        np.cumsum([w.shape[0] for w in ws], out=offs[1:])
+        cat = np.concatenate(ws, axis=0) if ws else np.zeros((0, 4), np.int32)
+        ev = torch.from_numpy(cat).to(device)
+        if ev.shape[0] == 0:
+            ev = torch.zeros((0, 4), dtype=torch.int32, device=device)
+        return cls(ev, torch.from_numpy(offs), height, width)
+
+    def _args(self):
+        return ctypes.byref(self.plan), _ptr(self.events), _ptr(self.offsets), _ptr(self.workspace)
+
+    def bin(self):
+        """Run the (y,x) binning pass (idempotent)."""
+        if not self._binned:
+            with torch.cuda.device(self.device):
+                check(self.lib.evrep_bin_events(*self._args(), _stream_ptr()), "evrep_bin_events")
+            self._binned = True
+        return self
+
+    def rebin(self):
+        self._binned = False
+        return self.bin()
+
+    # ------------------------------------------------------------------ read-backs (sync)
+    def status(self):
+        self.bin()
+        st = np.zeros(self.B, dtype=np.uint32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_read_status(ctypes.byref(self.plan), _ptr(self.workspace),
+                                             st.ctypes.data_as(ctypes.c_void_p), _stream_ptr()), "evrep_read_status")
+        return st
+
+    def bbox(self):
+        self.bin()
+        bb = np.zeros((self.B, 4), dtype=np.int32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_read_bbox(ctypes.byref(self.plan), _ptr(self.workspace),
+                                           bb.ctypes.data_as(ctypes.c_void_p), _stream_ptr()), "evrep_read_bbox")
+        return bb
+
+    # ------------------------------------------------------------------ builders
+    def _out(self, out, C, dtype):
+        shape = (self.B, self.H, self.W, C)
+        if out is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        if tuple(out.shape) != shape or out.dtype != dtype or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous %s tensor of shape %r on %s" % (dtype, shape, self.device))
+        return out
+
+    @staticmethod
+    def _dt(dtype):
+        if dtype == torch.float64:
+            return _lib.F64
+        if dtype == torch.float32:
+            return _lib.F32
+        raise ValueError("dtype must be torch.float64 or torch.float32")
+
+    def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64, out=None):
+        """MixedDensityEventStack.stack for every window -> (B, H, W, C).  ``None`` entries give the
+        reference's failed-channel zeros.  More than 16 channels are built 16 at a time."""
+        self.bin()
+        C = len(windows)
+        w = [-1 if v is None else int(v) for v in windows]
+        f = [-1 if v is None else (_lib.FUNCS.index(v) if isinstance(v, str) else int(v)) for v in funcs]
+        a = [-1 if v is None else (_lib.AGGS.index(v) if isinstance(v, str) else int(v)) for v in aggs]
+        if C <= _lib.MAX_CHANNELS:
+            out = self._out(out, C, dtype)
+            with torch.cuda.device(self.device):
+                check(self.lib.evrep_mdes(*self._args(), C, _lib.int32_array(w), _lib.int32_array(f),
+                                          _lib.int32_array(a), float(scale), self._dt(dtype), _ptr(out),
+                                          _stream_ptr()), "evrep_mdes")
+            return out
+        parts = [self.mdes(w[i:i + 16], f[i:i + 16], a[i:i + 16], scale, dtype) for i in range(0, C, 16)]
+        res = torch.cat(parts, dim=3)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def optimized(self, scale=1.0, dtype=torch.float64, out=None):
+        """get_optimized_representation (ERGO-12) for every window -> (B, H, W, 12)."""
+        self.bin()
+        out = self._out(out, 12, dtype)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_optimized(*self._args(), float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
+                  "evrep_optimized")
+        return out
+
+    def event_stack(self, stack_size=12, premap=True, scale=1.0, out=None):
+        self.bin()
+        out = self._out(out, stack_size, torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_event_stack(*self._args(), int(stack_size), int(bool(premap)), float(scale),
+                                             _ptr(out), _stream_ptr()), "evrep_event_stack")
+        return out
+
+    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None):
+        self.bin()
+        out = self._out(out, 2 * slices, dtype)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_time_surface(*self._args(), int(slices), float(tau), int(bool(premap)),
+                                              float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
+                  "evrep_time_surface")
+        return out
+
+    def tore(self, k=6, frame_mode=0, scale=1.0, out=None):
+        """TORE.  frame_mode 0 (bounding box, the gen1/gen4 dispatcher's behaviour) returns a list of
+        per-window (Hbb, Wbb, 2k) views (needs one host sync for the boxes); modes 1/2 return
+        (B, H, W, 2k)."""
+        self.bin()
+        out = self._out(out, 2 * k, torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_tore(*self._args(), int(k), int(frame_mode), float(scale), _ptr(out),
+                                      _stream_ptr()), "evrep_tore")
+        if frame_mode != 0:
+            return out
+        bb = self.bbox()
+        views = []
+        for b in range(self.B):
+            hb, wb = int(bb[b, 3] - bb[b, 1] + 1), int(bb[b, 2] - bb[b, 0] + 1)
+            flat = out[b].reshape(-1)
+            views.append(flat[: hb * wb * 2 * k].view(hb, wb, 2 * k))
+        return views
+
+    def voxel(self, bins=5, mode=0, scale=1.0, out=None):
+        self.bin()
+        out = self._out(out, bins, torch.float64)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_voxel(*self._args(), int(bins), int(mode), float(scale), _ptr(out), _stream_ptr()),
+                  "evrep_voxel")
+        return out
+
+
+def gwd_padded_l1(Xs, Xt, h=0.7):
+    """OTMI(Xs, Xt, h).solve()[1] on the GPU: Xs (n, ds), Xt (m, dt) array-likes -> 0-dim float64 cuda tensor."""
+    _require_gpu()
+    lib = _lib.load()
+    dev = Xs.device if isinstance(Xs, torch.Tensor) and Xs.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    a = torch.as_tensor(np.asarray(Xs) if not isinstance(Xs, torch.Tensor) else Xs).to(dev, torch.float64).contiguous()
+    b = torch.as_tensor(np.asarray(Xt) if not isinstance(Xt, torch.Tensor) else Xt).to(dev, torch.float64).contiguous()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] == 0 or b.shape[0] == 0:
+        raise ValueError("Xs and Xt must be non-empty 2-D point clouds")
+    n, m = int(a.shape[0]), int(b.shape[0])
+    scratch = torch.empty(int(lib.evrep_gwd_scratch_bytes(n, m)), dtype=torch.uint8, device=dev)
+    cost = torch.empty((), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.evrep_gwd_padded_l1(_ptr(a), n, int(a.shape[1]), _ptr(b), m, int(b.shape[1]), float(h),
+                                      _ptr(scratch), _ptr(cost), _stream_ptr()), "evrep_gwd_padded_l1")
+    return cost

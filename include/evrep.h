@@ -1,0 +1,140 @@
+/*
+ * evrep.h -- C ABI of libevrep.so, the MI355X (gfx950) event-representation engine.
+ *
+ * The reference (uzh-rpg/event_representation_study) has no FFI: its boundary is a set of
+ * importable Python names.  Each entry point below replaces the hot
+ * loop behind one of those names; the Python host mirror under
+ * event_representation_study_amd/representations/ binds them with ctypes (INTEGRATION.md shows
+ * the stub a reference maintainer would add).  Citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked DEVICE is a HIP device pointer, `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream);
+ *   - no global state, no allocation: the caller owns a workspace of evrep_workspace_bytes();
+ *   - every call is asynchronous on `stream` and returns an EVREP_* status (launch errors
+ *     included); data-dependent failures the reference reports as Python exceptions are
+ *     recorded per window in the workspace and read back with evrep_read_status();
+ *   - events are int32 rows [x, y, t, p] (the '<i4' structured array the reference adapters
+ *     build, ev-YOLOv6/yolov6/data/gen1_2yolo.py:567-571), time-sorted, B windows concatenated,
+ *     window b = rows [offsets[b], offsets[b+1]);
+ *   - outputs are dense, channel-last (B, H, W, C), written exactly once (zero fill fused).
+ */
+#ifndef EVREP_H_
+#define EVREP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVREP_ABI_VERSION 1
+
+/* return codes */
+#define EVREP_OK 0
+#define EVREP_EINVAL 1      /* bad argument (sizes, NULL pointers, unsupported C / k / bins) */
+#define EVREP_EWORKSPACE 2  /* workspace too small */
+#define EVREP_EHIP 3        /* a HIP launch failed; see evrep_last_hip_error() */
+#define EVREP_ENOTBINNED 4  /* builder called on a plan that has not been binned */
+
+/* per-window status bits (evrep_read_status) */
+#define EVREP_ST_EMPTY 1u      /* window has no events (reference: ValueError on t.min()) */
+#define EVREP_ST_OOB 2u        /* some x + y*W outside [0, H*W) (reference: IndexError in put / zero channel in MDES) */
+#define EVREP_ST_UNSORTED 4u   /* timestamps not ascending (reference behaviour differs; unsupported) */
+#define EVREP_ST_FLAT_TIME 8u  /* t[-1] == t[0] (reference divides by zero) */
+
+/* MDES function / aggregation codes (representation_search/operations.py:42-87, :16-34) */
+enum evrep_func { EVREP_F_TIMESTAMP = 0, EVREP_F_POLARITY, EVREP_F_COUNT, EVREP_F_TIMESTAMP_POS,
+                  EVREP_F_TIMESTAMP_NEG, EVREP_F_COUNT_POS, EVREP_F_COUNT_NEG };
+enum evrep_agg { EVREP_A_SUM = 0, EVREP_A_MEAN, EVREP_A_MAX, EVREP_A_VARIANCE };
+enum evrep_dtype { EVREP_F64 = 0, EVREP_F32 = 1 };
+
+#define EVREP_MAX_CHANNELS 16  /* MDES channels per launch (larger stacks: several launches) */
+#define EVREP_MAX_DIM 4096     /* H, W */
+
+/* Host-side description of one batch; filled by evrep_plan_init, read-only afterwards. */
+typedef struct evrep_plan {
+    int32_t abi_version;
+    int32_t B, H, W;
+    int64_t total_events;          /* offsets[B] */
+    int64_t max_events_per_window; /* upper bound used to size grids; no host sync needed */
+    int32_t chunk, nblk;           /* partition geometry (derived) */
+    size_t off_meta, off_table, off_rowoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
+    size_t workspace_bytes;
+} evrep_plan;
+
+int evrep_abi_version(void);
+const char *evrep_last_hip_error(void);
+
+/* Fill `plan` for B windows of an H x W sensor holding total_events events, at most
+ * max_events_per_window in any one window. */
+int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
+                    int64_t max_events_per_window);
+size_t evrep_workspace_bytes(const evrep_plan *plan);
+
+/* The (y,x) binning pass every builder consumes: a stable two-level partition of each window's
+ * events by pixel id x + y*W (row partition across workgroups, then column partition inside one
+ * workgroup per row), plus per-window statistics (t range, bounding box, MDES polarity flags).
+ * Replaces the per-builder `index = y*W + x` scatter of event_stack.py:123-125,
+ * operations.py:40, time_surface.py:67, tore.py:23-47.
+ * events DEVICE int32 [total,4]; offsets DEVICE int64 [B+1]; workspace DEVICE. */
+int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_t *offsets,
+                     void *workspace, void *stream);
+
+/* MixedDensityEventStack.stack (representation_search/mixed_density_event_stack.py:25-151) with
+ * Operations.exec/run (operations.py:15-89) for C <= EVREP_MAX_CHANNELS channels:
+ * window[c] in 0..6 (anything else = the reference's failed channel -> zeros), func[c], agg[c].
+ * out DEVICE (B,H,W,C) of out_dtype, each value multiplied by `scale` (1.0, or 255.0 as
+ * gen1_transforms.py:31 does). */
+int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+               int32_t C, const int32_t *window, const int32_t *func, const int32_t *agg, double scale,
+               int32_t out_dtype, void *out, void *stream);
+
+/* get_optimized_representation (optimized_representation.py:86-134): the ERGO-12 triples. */
+int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                    double scale, int32_t out_dtype, void *out, void *stream);
+
+/* EventStack.pre_stack + post_stack (event_stack.py:15-131) for last_timestamp = t[-1]:
+ * out DEVICE (B,H,W,S) float32; premap != 0 applies p -> (p+1)//2 first (gen1_transforms.py:34). */
+int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      int32_t stack_size, int32_t premap, float scale, float *out, void *stream);
+
+/* ToTimesurface.__call__ (time_surface.py:25-74) driven as gen1_transforms.py:69-87:
+ * S slices cut at searchsorted(t_norm, 1..S); out DEVICE (B,H,W,2S) float64/float32, c = 2s+p. */
+int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                       int32_t slices, double tau, int32_t premap, double scale, int32_t out_dtype,
+                       void *out, void *stream);
+
+/* events2ToreFeature (tore.py:6-83) for one sample time T = t[-1], k <= 8.
+ * frame_mode 0: the events' bounding box, origin-shifted (gen1_transforms.py:61-64); the window's
+ *               output is a compact (Hbb,Wbb,2k) array at out + b*H*W*2k, bbox via evrep_read_bbox;
+ * frame_mode 1: full (H,W) frame, origin-shifted by (xmin,ymin) (n_imagenet .../imagenet.py:1095-1103);
+ * frame_mode 2: full (H,W) frame, no shift (x, y used as 0-based pixel coordinates).
+ * out DEVICE float32. */
+int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+               int32_t k, int32_t frame_mode, float scale, float *out, void *stream);
+
+/* compute_repr (representation_search/gromov_wasserstein.py:72-82) with t normalised as :96;
+ * mode 0.  mode 1 = tonic.transforms.ToVoxelGrid as gen1_transforms.py:22-25 consumes it
+ * (restated from tonic's published algorithm; parity unpinned).  out DEVICE (B,H,W,bins) float64. */
+int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                int32_t bins, int32_t mode, double scale, double *out, void *stream);
+
+/* Synchronous read-backs (they synchronise `stream`). status: HOST uint32 [B];
+ * bbox: HOST int32 [B,4] = xmin, ymin, xmax, ymax of each window's in-frame events. */
+int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream);
+int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox, void *stream);
+
+/* OTMI(Xs, Xt, h).solve()[1] (representation_search/compute_otmi.py:61-93) in closed form for
+ * POT's max_iter=0 path: mean over the LxL zero-padded grid of |Ks - Kt|.
+ * Xs DEVICE double [n,ds], Xt DEVICE double [m,dt] (ds, dt <= 32); scratch DEVICE of
+ * evrep_gwd_scratch_bytes(n, m); cost DEVICE double [1]. */
+size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m);
+int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt,
+                        double h, void *scratch, double *cost, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVREP_H_ */

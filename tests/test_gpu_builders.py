@@ -1,0 +1,106 @@
+"""-m gpu: the HIP path (through the C ABI) against the golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import STANDARD_CASES, assert_bit_equal, load_golden
+
+from event_representation_study_amd.synthetic import make_events
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from event_representation_study_amd import engine
+    return engine
+
+
+def _batch(eng, ev, H, W):
+    return eng.EventBatch.from_numpy(ev, H, W)
+
+
+@pytest.mark.parametrize("name", STANDARD_CASES)
+def test_golden_all_builders(eng, name):
+    g = load_golden(name)
+    H, W = int(g["H"]), int(g["W"])
+    eb = _batch(eng, g["events"], H, W)
+    assert_bit_equal(eb.optimized()[0].cpu().numpy(), g["ergo12"], name + " ergo12")
+    assert_bit_equal(eb.event_stack(12, premap=True)[0].cpu().numpy(), g["event_stack"], name + " event_stack")
+    if "voxel5" in g:
+        assert_bit_equal(eb.voxel(5)[0].cpu().numpy(), g["voxel5"], name + " voxel5")
+    if "time_surface" in g:
+        ts = eb.time_surface(6, 50000.0, premap=True)[0].cpu().numpy()
+        np.testing.assert_allclose(ts, g["time_surface"], rtol=1e-12, atol=0)   # budget: 1e-5 rel
+        assert np.array_equal(ts == 0, g["time_surface"] == 0)
+    tore = eb.tore(6, frame_mode=0)[0].cpu().numpy()
+    assert tore.shape == g["tore"].shape
+    np.testing.assert_allclose(tore, g["tore"], rtol=1e-6, atol=1e-6)             # budget: 1e-5 rel
+    assert np.array_equal(tore == 0, g["tore"] == 0)
+
+
+@pytest.mark.parametrize("enc", ["pm1", "01"])
+def test_golden_mdes_all_triples(eng, enc):
+    g = load_golden("mdes_all_triples_40x30_n3001_" + enc)
+    eb = _batch(eng, g["events"], int(g["H"]), int(g["W"]))
+    got = eb.mdes(list(g["windows"]), [str(s) for s in g["funcs"]], [str(s) for s in g["aggs"]])[0].cpu().numpy()
+    assert_bit_equal(got, g["rep"], enc)
+
+
+def test_golden_mdes_none_channels(eng):
+    g = load_golden("mdes_none_channels_40x30_n999")
+    eb = _batch(eng, g["events"], int(g["H"]), int(g["W"]))
+    got = eb.mdes([0, None, 6, None], ["count", None, "polarity", None], ["sum", None, "sum", None])[0].cpu().numpy()
+    assert_bit_equal(got, g["rep"])
+
+
+def test_batch_of_ragged_windows_vs_oracle(eng, oracle):
+    H, W = 60, 80
+    sizes = [5000, 1, 0, 777, 4097, 64, 65, 3]
+    wins = [make_events(n, W, H, seed=900 + i, polarity="pm1" if i % 2 else "01") for i, n in enumerate(sizes)]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    st = eb.status()
+    opt = eb.optimized().cpu().numpy()
+    es = eb.event_stack().cpu().numpy()
+    for b, (n, ev) in enumerate(zip(sizes, wins)):
+        if n == 0:
+            assert st[b] & 1 and not opt[b].any() and not es[b].any()
+            continue
+        assert not (st[b] & 1)
+        assert_bit_equal(opt[b], oracle.ergo12(ev, H, W), "ergo12 window %d" % b)
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event_stack window %d" % b)
+
+
+def test_scale_and_f32_output(eng, oracle):
+    H, W = 48, 64
+    ev = make_events(9000, W, H, seed=31)
+    eb = _batch(eng, ev, H, W)
+    ref = oracle.ergo12(ev, H, W)
+    assert_bit_equal(eb.optimized(scale=255.0)[0].cpu().numpy(), ref * 255, "x255")
+    assert_bit_equal(eb.optimized(dtype=torch.float32)[0].cpu().numpy(), ref.astype(np.float32), "f32")
+
+
+def test_big_640x480_digest(eng):
+    import hashlib
+    g = load_golden("big_640x480_n50000_pm1")
+    W, H, N, seed = int(g["W"]), int(g["H"]), int(g["N"]), int(g["seed"])
+    ev = make_events(N, W, H, seed=seed, polarity="pm1")
+    eb = _batch(eng, ev, H, W)
+    for key, t in (("ergo12", eb.optimized()), ("event_stack", eb.event_stack()), ("voxel5", eb.voxel(5))):
+        a = np.ascontiguousarray(t[0].cpu().numpy())
+        assert hashlib.sha256(a.tobytes()).hexdigest() == str(g[key + "_sha256"]), key
+    ts = eb.time_surface()[0].cpu().numpy().reshape(-1)
+    np.testing.assert_allclose(ts[g["time_surface_pos"]], g["time_surface_val"], rtol=1e-12)
+    tore = eb.tore(6, 0)[0].cpu().numpy()
+    assert tore.shape == tuple(g["tore_shape"])
+    np.testing.assert_allclose(tore.reshape(-1)[g["tore_pos"]], g["tore_val"], rtol=1e-6, atol=1e-6)
+
+
+def test_out_of_frame_events(eng, oracle):
+    H, W = 12, 16
+    ev = make_events(100, W, H, seed=5)
+    ev[50, 0] = 16 * 12 * 4
+    eb = _batch(eng, ev, H, W)
+    assert eb.status()[0] & 2
+    got = eb.mdes([0, 1, 6], ["count"] * 3, ["sum"] * 3)[0].cpu().numpy()
+    assert_bit_equal(got, oracle.mdes(ev, H, W, [0, 1, 6], ["count"] * 3, ["sum"] * 3))
