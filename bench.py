@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on MI355X: OptimizedRepresentation (ERGO-12) over a batch of windows.
+
+One "step" = one pass of the hot path over one batch of synthetic event windows that is already
+resident in HBM: the (y,x) binning pass + the ERGO-12 builder, device-resident events in,
+device-resident (B, H, W, 12) float64 out (the reference's dtype, mixed_density_event_stack.py:36).
+Workload = BASELINE.json configs[1]: 640x480, 12 channels, 50 000 events per window (the reference's
+window size, gen1_2yolo.py:41), batch of 32 windows.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 launch under ``python -m torch.distributed.run --nproc-per-node N``; every rank owns its own
+windows (weak scaling, no data-path collective); the only collective is the all-gather of GWD scalars.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, C = 480, 640, 12
+EVENTS_PER_WINDOW = 50000
+BATCH = 32
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--events", type=int, default=EVENTS_PER_WINDOW)
+    ap.add_argument("--out-dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gwd", action="store_true")
+    ap.add_argument("--gwd-pairs", type=int, default=36)
+    return ap.parse_args()
+
+
+def cpu_baseline(events_per_window, budget_s=12.0):
+    """The oracle (C port of the reference's per-channel scatter passes), one host core."""
+    import oracle
+    from event_representation_study_amd.synthetic import make_events
+    oracle.build()
+    wins = [make_events(events_per_window, W, H, seed=1000 + i) for i in range(4)]
+    oracle.ergo12(wins[0], H, W)  # warm
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        oracle.ergo12(wins[done % len(wins)], H, W)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 256:
+            break
+    return {"value": done * events_per_window / el, "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": "%d windows of %d events, 640x480x12 f64, oracle/evrep_oracle.c single thread, %.1f s"
+                      % (done, events_per_window, el),
+            "windows_per_s": done / el}
+
+
+def gwd_leg(rank, world, pairs, device):
+    """Wall time of `pairs` GWD solves at the reference's size (n ~ 12.5k events/quadrant, m = 14.4k
+    representation points of C+2 = 14 features), sharded over ranks, scalars all-gathered."""
+    from event_representation_study_amd.engine import gwd_padded_l1
+    rng = np.random.default_rng(77)
+    n, m = 12500, 14400
+    Xs = torch.from_numpy(rng.random((n, 4))).to(device)
+    Xt = torch.from_numpy(rng.random((m, 14)) * np.array([255.0] * 12 + [1.0, 1.0])).to(device)
+    mine = list(range(rank, pairs, world))
+    gwd_padded_l1(Xs, Xt)  # warm
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    costs = torch.zeros(pairs, dtype=torch.float64, device=device)
+    for i in mine:
+        costs[i] = gwd_padded_l1(Xs + 1e-3 * i, Xt)
+    if world > 1:
+        gathered = [torch.zeros_like(costs) for _ in range(world)]
+        torch.distributed.all_gather(gathered, costs)
+        costs = torch.stack(gathered).sum(0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    entries = pairs * (n * n + m * m)
+    return {"pairs": pairs, "n": n, "m": m, "wall_ms": el * 1e3, "kernel_entries_per_s": entries / el,
+            "first_cost": float(costs[0].item())}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    from event_representation_study_amd.engine import EventBatch
+    from event_representation_study_amd.synthetic import make_events
+
+    B, N = args.batch, args.events
+    wins = [make_events(N, W, H, seed=rank * 100000 + i) for i in range(B)]  # seed = window index
+    batch = EventBatch.from_numpy(wins, H, W, device=device)
+    dtype = torch.float64 if args.out_dtype == "f64" else torch.float32
+    out = torch.empty((B, H, W, C), dtype=dtype, device=device)
+
+    def step(ev_pair=None):
+        batch._binned = False
+        batch.bin()
+        if ev_pair is not None:
+            ev_pair[0].record()
+        batch.optimized(scale=1.0, dtype=dtype, out=out)
+        if ev_pair is not None:
+            ev_pair[1].record()
+
+    for _ in range(args.warmup):
+        step()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(pairs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el = float(t.item())
+
+    builder_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))  # the k_mdes launch, HIP events on its stream
+    elem = 8 if dtype == torch.float64 else 4
+    alg_bytes = B * (16 * N + elem * H * W * C)  # read every event once, write every output once
+    achieved = alg_bytes / (builder_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "events/sec/GPU (OptimizedRep, Gen1 640x480) + 12-rep GWD matrix wall-time",
+        "value": world * B * N * args.steps / el,
+        "unit": "events/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if dtype == torch.float64 else "f32",
+        "data": "synthetic",
+        "config": {"workload": "OptimizedRepresentation (ERGO-12) 640x480x12, %d events/window, batch %d windows/GPU, "
+                               "bin + build per step, events and output resident in HBM" % (N, B),
+                   "events_per_window": N, "batch": B, "height": H, "width": W, "channels": C,
+                   "parallelism": "windows sharded over %d GPU(s), no data-path collective" % world},
+        "windows_per_s": world * B * args.steps / el,
+        "algorithmic_GBps_whole_step": world * alg_bytes * args.steps / el / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_mdes<%s>" % ("double" if elem == 8 else "float"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "avg_launch_ms": builder_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            with open(tr) as f:
+                trj = json.load(f)
+            key = "k_mdes_f64" if elem == 8 else "k_mdes_f32"
+            if key in trj and trj[key].get("batch") == B and trj[key].get("events") == N:
+                result["roofline"]["traffic"] = trj[key]["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = trj[key].get("source")
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(N)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if not args.no_gwd:
+        g = gwd_leg(rank, world, args.gwd_pairs, device)
+        result["gwd"] = g
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

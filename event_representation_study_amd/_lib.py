@@ -27,7 +27,9 @@ class Plan(ctypes.Structure):
         ("total_events", ctypes.c_int64),
         ("max_events_per_window", ctypes.c_int64),
         ("chunk", ctypes.c_int32), ("nblk", ctypes.c_int32),
+        ("nchunk", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("off_meta", ctypes.c_size_t), ("off_table", ctypes.c_size_t), ("off_rowoff", ctypes.c_size_t),
+        ("off_chunkoff", ctypes.c_size_t),
         ("off_sorted1", ctypes.c_size_t), ("off_sorted2", ctypes.c_size_t), ("off_cuts", ctypes.c_size_t),
         ("off_scratch", ctypes.c_size_t),
         ("workspace_bytes", ctypes.c_size_t),
@@ -47,8 +49,8 @@ SYMBOLS = {
     "evrep_mdes": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _I32P, _I32P, _I32P, _f64, _i32, _vp, _vp]),
     "evrep_optimized": (ctypes.c_int, [_PP, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
     "evrep_event_stack": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
-    "evrep_time_surface": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _f64, _i32, _f64, _i32, _vp, _vp]),
-    "evrep_tore": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
+    "evrep_time_surface": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _vp, _f64, _i32, _f64, _i32, _vp, _vp]),
+    "evrep_tore": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _vp, _vp]),
     "evrep_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f64, _vp, _vp]),
     "evrep_read_status": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
     "evrep_read_bbox": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
@@ -68,6 +70,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the process's HIP runtime (same SONAME as
+    # /opt/rocm's), otherwise device pointers / streams from torch are foreign to our launches.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EvrepError(
             "libevrep.so is missing (%s). Build it with `python -m event_representation_study_amd.build`; "

@@ -200,15 +200,22 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
 }
 
 // grid (H, B), 256 threads, dynamic LDS = (4 * W + 8) * 4 bytes.  Stable placement by column
-// inside one row: afterwards sorted2 is ordered by (window, pixel id, rank).
+// inside one row: afterwards sorted2 is ordered by (window, pixel id, rank).  Also emits, per row,
+// the record offsets of every kChunkPx-pixel column chunk (what one builder wavefront consumes).
 __global__ __launch_bounds__(kThreads) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
-                                                      int H, int W, Rec *__restrict__ sorted2) {
+                                                      int H, int W, int nchunk, Rec *__restrict__ sorted2,
+                                                      uint32_t *__restrict__ chunk_off) {
     extern __shared__ uint32_t cnt[];  // [kWaves][W] + tmp[8]
     uint32_t *tmp = cnt + kWaves * W;
     const int b = blockIdx.y, row = blockIdx.x;
     const uint32_t rs = row_off[(size_t)b * (H + 1) + row], re = row_off[(size_t)b * (H + 1) + row + 1];
     const uint32_t n = re - rs;
-    if (n == 0) return;
+    // chunk_off[b][row][c] = global index of the first record whose column is >= c * kChunkPx
+    uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+    if (n == 0) {
+        for (int c = threadIdx.x; c <= nchunk; c += kThreads) co[c] = rs;
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wlo = rs + (uint32_t)((uint64_t)n * wave / kWaves), whi = rs + (uint32_t)((uint64_t)n * (wave + 1) / kWaves);
     const int rowbase = row * W;
@@ -232,6 +239,8 @@ __global__ __launch_bounds__(kThreads) void k_col_sort(const Rec *__restrict__ s
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) { const uint32_t t = cnt[w * W + c0 + k]; cnt[w * W + c0 + k] = run; run += t; }
         }
+    __syncthreads();
+    for (int c = threadIdx.x; c <= nchunk; c += kThreads) co[c] = (c * kChunkPx < W) ? rs + cnt[c * kChunkPx] : re;
     __syncthreads();
     const int nbits = bits_for(W);
     volatile uint32_t *vcnt = mycnt;

@@ -1,70 +1,114 @@
 // evrep_builders.hip -- the event->dense-tensor builders as per-pixel segmented reductions over
 // the binned stream (evrep_bin.hip), gfx950.
 //
-// One workgroup (4 wave64) owns one sensor row of one window.  It finds every pixel's segment
-// [start, end) in the row's column-sorted events, reduces it with one thread per pixel IN TIME
-// ORDER (so float64 sums round exactly as the reference's sequential scatter does), stages the
-// (pixels, C) tile in LDS in output layout, and streams it out with 16-byte-per-lane coalesced
-// stores.  Every output element is written exactly once; the zero / background fill is fused.
-// HBM traffic per window = 16 B per event (binned record) + sizeof(out) per output element.
+// Work unit = one wavefront (a 64-thread workgroup) owning a chunk of kChunkPx = 128 consecutive
+// pixels of one sensor row of one window.  The wave
+//   1. fills its private LDS tile (npix x C, output layout) with the channel background
+//      (zero, or the builder's empty-pixel value),
+//   2. lists the non-empty pixels of the chunk (segment heads of the pixel-sorted records, found
+//      with a ballot prefix) -- one lane per NON-EMPTY pixel, so VALU work scales with events,
+//   3. reduces each segment IN TIME ORDER (float64 sums round exactly as the reference's
+//      sequential scatter does) and patches the pixel's C values into the tile,
+//   4. streams the tile out with 16-byte-per-lane coalesced stores.
+// No block barrier is needed (one wave per workgroup), every output element is written exactly
+// once, and HBM traffic per window = 16 B per event (binned record) + sizeof(out) per element.
 #include "evrep_common.h"
 
 namespace evrep {
 
-// --------------------------------------------------------------------------------------------
-// shared pieces
-// --------------------------------------------------------------------------------------------
-struct RowCtx {
-    uint32_t rs;  // global index of the row's first record
-    uint32_t n;   // records in the row
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+constexpr int kMaxSegs = 2 * kChunkPx;  // TORE's shifted frame can straddle two sensor chunks
+
+// LDS carve of one builder wave: tile, per-channel background, segment list.
+template <typename OutT>
+struct WaveTile {
+    OutT *tile;    // npix * C elements, output layout (pixel-major, channel-minor)
+    OutT *bg;      // EVREP_MAX_CHANNELS background values
+    uint2 *segs;   // (pixel offset inside the chunk, first record index); entry nseg = sentinel
+    __device__ explicit WaveTile(unsigned char *smem, int C) {
+        tile = reinterpret_cast<OutT *>(smem);
+        bg = reinterpret_cast<OutT *>(smem + align16((size_t)kChunkPx * C * sizeof(OutT)));
+        segs = reinterpret_cast<uint2 *>(smem + align16((size_t)kChunkPx * C * sizeof(OutT)) + 16 * sizeof(OutT));
+    }
 };
 
-// seg_start / seg_end (W entries each, LDS): per column, the [start, end) range inside the row.
-__device__ inline void build_segments(const Rec *__restrict__ sorted, RowCtx rc, int rowbase, int W,
-                                      uint32_t *seg_start, uint32_t *seg_end) {
-    for (int i = threadIdx.x; i < W; i += kThreads) { seg_start[i] = 0; seg_end[i] = 0; }
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < rc.n; j += kThreads) {
-        const int key = sorted[rc.rs + j].x;
-        const int prev = j > 0 ? sorted[rc.rs + j - 1].x : -1;
-        const int next = j + 1 < rc.n ? sorted[rc.rs + j + 1].x : -1;
-        if (prev != key) seg_start[key - rowbase] = j;
-        if (next != key) seg_end[key - rowbase] = j + 1;
-    }
-    __syncthreads();
+static size_t builder_lds_bytes(int C, size_t elem) {
+    return align16((size_t)kChunkPx * C * elem) + 16 * elem + (size_t)(kMaxSegs + 1) * sizeof(uint2) + 16;
 }
 
-// Stream `count` staged elements (LDS, output layout) to global memory, 16 B per lane when the
-// destination is 16-byte aligned.  Contains no barrier.
 template <typename OutT>
-__device__ inline void copy_out(const OutT *stage, int count, OutT *__restrict__ dst) {
+__device__ inline void tile_fill_zero(OutT *tile, int count) {
+    constexpr int V = 16 / (int)sizeof(OutT);
+    float4 *t4 = reinterpret_cast<float4 *>(tile);
+    const int nvec = (count + V - 1) / V;  // the tile is padded to a multiple of 16 bytes
+    for (int v = threadIdx.x; v < nvec; v += kWave) t4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <typename OutT>
+__device__ inline void tile_fill_pattern(OutT *tile, int npix, int C, const OutT *bg) {
+    for (int e = threadIdx.x; e < npix * C; e += kWave) tile[e] = bg[e % C];
+}
+
+// Stream `count` tile elements to global memory, 16 B per lane when the destination is aligned.
+template <typename OutT>
+__device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict__ dst) {
     constexpr int V = 16 / (int)sizeof(OutT);
     if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
         const int nvec = count / V;
-        const float4 *s4 = reinterpret_cast<const float4 *>(stage);
+        const float4 *s4 = reinterpret_cast<const float4 *>(tile);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int v = threadIdx.x; v < nvec; v += kThreads) d4[v] = s4[v];
-        for (int e = nvec * V + threadIdx.x; e < count; e += kThreads) dst[e] = stage[e];
+        for (int v = threadIdx.x; v < nvec; v += kWave) d4[v] = s4[v];
+        for (int e = nvec * V + threadIdx.x; e < count; e += kWave) dst[e] = tile[e];
     } else {
-        for (int e = threadIdx.x; e < count; e += kThreads) dst[e] = stage[e];
+        for (int e = threadIdx.x; e < count; e += kWave) dst[e] = tile[e];
     }
 }
 
-// Fill `count` staged elements with a per-channel pattern pat[ch], element e -> ch = e % C.
-template <typename OutT>
-__device__ inline void fill_pattern(OutT *stage, int count, int C, const OutT *pat) {
-    for (int e = threadIdx.x; e < count; e += kThreads) stage[e] = pat[e % C];
+// List the segments (runs of equal pixel id) among records [cs, ce): segs[k] = (key - key0, first
+// record).  Returns the number of segments; segs[nseg].y = ce.  Keys are sorted, so the pixel
+// offsets are increasing; offsets outside [0, npix) (TORE's straddle) are skipped by the caller.
+__device__ inline int list_segments(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, uint2 *segs) {
+    const int lane = threadIdx.x;
+    int nseg = 0;
+    int carry = INT32_MIN;
+    for (uint32_t j0 = cs; j0 < ce; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        const bool valid = j < ce;
+        const int key = valid ? sorted[j].x : INT32_MIN;
+        int prev = __shfl_up(key, 1, 64);
+        if (lane == 0) prev = carry;
+        const bool head = valid && key != prev;
+        const uint64_t hm = __ballot(head);
+        if (head) {
+            const int idx = nseg + __popcll(hm & ((1ull << lane) - 1ull));
+            if (idx < kMaxSegs) segs[idx] = make_uint2((uint32_t)(key - key0), j);
+        }
+        nseg += __popcll(hm);
+        carry = __shfl(key, 63, 64);
+    }
+    if (nseg > kMaxSegs) nseg = kMaxSegs;  // cannot happen: <= 2*kChunkPx distinct pixels are ever listed
+    if (lane == 0) segs[nseg] = make_uint2(0u, ce);
+    return nseg;
 }
 
-template <typename OutT>
-__device__ inline void fill_zero(OutT *stage, int count) {
-    constexpr int V = 16 / (int)sizeof(OutT);
-    float4 *s4 = reinterpret_cast<float4 *>(stage);
-    const int nvec = (count + V - 1) / V;  // stage is padded to a multiple of 16 bytes
-    for (int v = threadIdx.x; v < nvec; v += kThreads) s4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
+struct ChunkGeom {
+    int b, row, c0, npix;
+    uint32_t cs, ce;
+};
 
-__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+__device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk) {
+    ChunkGeom g;
+    const int chunk = blockIdx.x;
+    g.row = blockIdx.y;
+    g.b = blockIdx.z;
+    g.c0 = chunk * kChunkPx;
+    g.npix = min(kChunkPx, W - g.c0);
+    const uint32_t *co = chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
+    g.cs = co[chunk];
+    g.ce = co[chunk + 1];
+    return g;
+}
 
 // --------------------------------------------------------------------------------------------
 // A3/A4/A5: MixedDensityEventStack.stack + Operations
@@ -77,23 +121,29 @@ struct MdesParams {
 
 constexpr int kWantAny = 2;
 
-// grid (H, B); dynamic LDS = 2*W*4 + align16(256*C*sizeof(OutT)).
+// grid (nchunk, H, B), 64 threads; dynamic LDS = builder_lds_bytes(C, sizeof(OutT)).
 template <typename OutT>
-__global__ __launch_bounds__(kThreads) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ row_off,
-                                                  const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
-                                                  MdesParams P, int H, int W, double scale, OutT *__restrict__ out) {
+__global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+                                               const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
+                                               MdesParams P, int H, int W, int nchunk, double scale,
+                                               OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *seg_start = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *seg_end = seg_start + W;
-    OutT *stage = reinterpret_cast<OutT *>(smem + align16((size_t)2 * W * 4));
-
-    const int b = blockIdx.y, row = blockIdx.x;
     const int C = P.C;
-    const int64_t n_win = off[b + 1] - off[b];
-    RowCtx rc;
-    rc.rs = row_off[(size_t)b * (H + 1) + row];
-    rc.n = row_off[(size_t)b * (H + 1) + row + 1] - rc.rs;
-    const WindowMeta m = meta[b];
+    WaveTile<OutT> wt(smem, C);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+
+    tile_fill_zero(wt.tile, g.npix * C);
+    if (g.ce == g.cs) {  // empty chunk: pure zero fill
+        __syncthreads();
+        tile_store(wt.tile, g.npix * C, dst);
+        return;
+    }
+    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
+    __syncthreads();
+
+    const int64_t n_win = off[g.b + 1] - off[g.b];
+    const WindowMeta m = meta[g.b];
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
@@ -125,90 +175,82 @@ __global__ __launch_bounds__(kThreads) void k_mdes(const Rec *__restrict__ sorte
         }
     }
 
-    build_segments(sorted, rc, row * W, W, seg_start, seg_end);
-
-    OutT *out_row = out + ((size_t)b * H + row) * (size_t)W * C;
-    for (int cb = 0; cb < W; cb += kThreads) {
-        const int npix = min(kThreads, W - cb);
-        fill_zero(stage, npix * C);
-        __syncthreads();
-        const int col = cb + threadIdx.x;
-        if (col < W) {
-            const uint32_t js = seg_start[col], je = seg_end[col];
-            if (je > js) {
-                double s[EVREP_MAX_CHANNELS], s2[EVREP_MAX_CHANNELS];
-                int cnt[EVREP_MAX_CHANNELS];
+    for (int k = threadIdx.x; k < nseg; k += kWave) {
+        const uint2 sg = wt.segs[k];
+        const uint32_t je = wt.segs[k + 1].y;
+        double s[EVREP_MAX_CHANNELS], s2[EVREP_MAX_CHANNELS];
+        int cnt[EVREP_MAX_CHANNELS];
 #pragma unroll
-                for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
-                for (uint32_t j = js; j < je; ++j) {
-                    const Rec e = sorted[rc.rs + j];
-                    const int rank = e.y, p = e.w;
-                    const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
-                    const double pv = (double)p;
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
+        for (uint32_t j = sg.y; j < je; ++j) {
+            const Rec e = sorted[j];
+            const int rank = e.y, p = e.w;
+            const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
+            const double pv = (double)p;
 #pragma unroll
-                    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
-                        if (c < C && active[c]) {
-                            const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
-                            const int f = P.func[c];
-                            const double v = (f == EVREP_F_POLARITY) ? pv
-                                           : ((f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG) ? 1.0 : tn);
-                            if (hit) {
-                                if (P.agg[c] == EVREP_A_MAX) {
-                                    if (cnt[c] == 0 || v > s[c]) s[c] = v;
-                                } else {
-                                    s[c] = s[c] + v;
-                                    const double vv = v * v;
-                                    s2[c] = s2[c] + vv;
-                                }
-                                ++cnt[c];
-                            }
+            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+                if (c < C && active[c]) {
+                    const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
+                    const int f = P.func[c];
+                    const double v = (f == EVREP_F_POLARITY) ? pv
+                                   : ((f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG) ? 1.0 : tn);
+                    if (hit) {
+                        if (P.agg[c] == EVREP_A_MAX) {
+                            if (cnt[c] == 0 || v > s[c]) s[c] = v;
+                        } else {
+                            s[c] = s[c] + v;
+                            const double vv = v * v;
+                            s2[c] = s2[c] + vv;
                         }
-                    }
-                }
-                OutT *mine = stage + (size_t)threadIdx.x * C;
-#pragma unroll
-                for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
-                    if (c < C) {
-                        double r = 0.0;
-                        if (active[c]) {
-                            const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
-                            const int a = P.agg[c];
-                            if (a == EVREP_A_SUM) r = s[c];
-                            else if (a == EVREP_A_MEAN) r = s[c] / d;
-                            else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
-                            else {
-                                const double mean = s[c] / d, mean2 = s2[c] / d;
-                                const double mm = mean * mean;
-                                r = mean2 - mm;
-                            }
-                        }
-                        mine[c] = (OutT)(r * scale);
+                        ++cnt[c];
                     }
                 }
             }
         }
-        __syncthreads();
-        copy_out(stage, npix * C, out_row + (size_t)cb * C);
-        __syncthreads();
+        OutT *mine = wt.tile + (size_t)sg.x * C;
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+            if (c < C) {
+                double r = 0.0;
+                if (active[c]) {
+                    const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
+                    const int a = P.agg[c];
+                    if (a == EVREP_A_SUM) r = s[c];
+                    else if (a == EVREP_A_MEAN) r = s[c] / d;
+                    else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+                    else {
+                        const double mean = s[c] / d, mean2 = s2[c] / d;
+                        const double mm = mean * mean;
+                        r = mean2 - mm;
+                    }
+                }
+                mine[c] = (OutT)(r * scale);
+            }
+        }
     }
+    __syncthreads();
+    tile_store(wt.tile, g.npix * C, dst);
 }
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
-// grid (H, B); dynamic LDS = 2*W*4 + align16(256*S*4).
-__global__ __launch_bounds__(kThreads) void k_event_stack(const Rec *__restrict__ sorted, const uint32_t *__restrict__ row_off,
-                                                         const int64_t *__restrict__ off, int H, int W, int S, int premap,
-                                                         float scale, float *__restrict__ out) {
+__global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+                                                      const int64_t *__restrict__ off, int H, int W, int nchunk, int S,
+                                                      int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *seg_start = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *seg_end = seg_start + W;
-    float *stage = reinterpret_cast<float *>(smem + align16((size_t)2 * W * 4));
-    const int b = blockIdx.y, row = blockIdx.x;
-    const int64_t n_win = off[b + 1] - off[b];
-    RowCtx rc;
-    rc.rs = row_off[(size_t)b * (H + 1) + row];
-    rc.n = row_off[(size_t)b * (H + 1) + row + 1] - rc.rs;
+    WaveTile<float> wt(smem, S);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
+    tile_fill_zero(wt.tile, g.npix * S);
+    if (g.ce == g.cs) {
+        __syncthreads();
+        tile_store(wt.tile, g.npix * S, dst);
+        return;
+    }
+    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
+    __syncthreads();
+    const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
     int offk[EVREP_MAX_CHANNELS];
     {
@@ -216,30 +258,20 @@ __global__ __launch_bounds__(kThreads) void k_event_stack(const Rec *__restrict_
 #pragma unroll
         for (int k = 0; k < EVREP_MAX_CHANNELS; ++k) { offk[k] = o; cur /= 2; o += cur; }
     }
-    build_segments(sorted, rc, row * W, W, seg_start, seg_end);
-    float *out_row = out + ((size_t)b * H + row) * (size_t)W * S;
-    for (int cb = 0; cb < W; cb += kThreads) {
-        const int npix = min(kThreads, W - cb);
-        fill_zero(stage, npix * S);
-        __syncthreads();
-        const int col = cb + threadIdx.x;
-        if (col < W) {
-            const uint32_t js = seg_start[col], je = seg_end[col];
-            if (je > js) {
-                const Rec e = sorted[rc.rs + je - 1];  // ndarray.put is last-write-wins (event_stack.py:125)
-                int p = e.w;
-                if (premap) p = (p + 1) >> 1;               // (p + 1) // 2   (gen1_transforms.py:34)
-                const float v = (float)(int8_t)(2 * p - 1) * scale;  // 2*p - 1 as int8 (event_stack.py:18)
-                float *mine = stage + (size_t)threadIdx.x * S;
+    for (int k = threadIdx.x; k < nseg; k += kWave) {
+        const uint2 sg = wt.segs[k];
+        const uint32_t je = wt.segs[k + 1].y;
+        const Rec e = sorted[je - 1];  // ndarray.put is last-write-wins (event_stack.py:125)
+        int p = e.w;
+        if (premap) p = (p + 1) >> 1;                        // (p + 1) // 2   (gen1_transforms.py:34)
+        const float v = (float)(int8_t)(2 * p - 1) * scale;  // 2*p - 1 as int8 (event_stack.py:18)
+        float *mine = wt.tile + (size_t)sg.x * S;
 #pragma unroll
-                for (int k = 0; k < EVREP_MAX_CHANNELS; ++k)
-                    if (k < S) mine[k] = (e.y >= offk[k]) ? v : 0.0f;
-            }
-        }
-        __syncthreads();
-        copy_out(stage, npix * S, out_row + (size_t)cb * S);
-        __syncthreads();
+        for (int l = 0; l < EVREP_MAX_CHANNELS; ++l)
+            if (l < S) mine[l] = (e.y >= offk[l]) ? v : 0.0f;
     }
+    __syncthreads();
+    tile_store(wt.tile, g.npix * S, dst);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -247,15 +279,17 @@ __global__ __launch_bounds__(kThreads) void k_event_stack(const Rec *__restrict_
 // --------------------------------------------------------------------------------------------
 constexpr int kMaxSlices = 8;
 struct TsCuts {
-    int32_t idx[kMaxSlices];   // searchsorted(t_norm, s+1, 'left')
+    int32_t idx[kMaxSlices];   // searchsorted(t_norm, s+1, 'left')  (or the caller's indices)
     int32_t tcut[kMaxSlices];  // t[idx[s]]
     int32_t live[kMaxSlices];  // 1 iff the sequential scan reaches this slice (strictly increasing idx)
     int32_t pad[8];
 };
 static_assert(sizeof(TsCuts) == 128, "TsCuts");
 
-// grid (B), 64 threads.
-__global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S, TsCuts *__restrict__ cuts) {
+// grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
+// int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
+__global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
+                          const int32_t *__restrict__ indices, TsCuts *__restrict__ cuts) {
     const int b = blockIdx.x, s = threadIdx.x;
     __shared__ int sidx[kMaxSlices];
     const int64_t beg = off[b];
@@ -263,19 +297,23 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
     if (s < S) {
         int idx = 0, tc = 0;
         if (n > 0) {
-            const int32_t t0 = ev[beg].z, tl = ev[beg + n - 1].z;
-            const double den = (double)(int32_t)(tl - t0);
-            const double target = (double)(s + 1);
-            int64_t lo = 0, hi = n;
-            while (lo < hi) {
-                const int64_t mid = lo + (hi - lo) / 2;
-                // t_norm = (t - t[0]) / (t[-1] - t[0]) * 6   (gen1_transforms.py:80)
-                const double q = (double)(int32_t)(ev[beg + mid].z - t0) / den;
-                const double tn = q * (double)S;
-                if (tn < target) lo = mid + 1; else hi = mid;
+            if (indices) {
+                idx = indices[b * S + s];
+            } else {
+                const int32_t t0 = ev[beg].z, tl = ev[beg + n - 1].z;
+                const double den = (double)(int32_t)(tl - t0);
+                const double target = (double)(s + 1);
+                int64_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const int64_t mid = lo + (hi - lo) / 2;
+                    // t_norm = (t - t[0]) / (t[-1] - t[0]) * 6   (gen1_transforms.py:80)
+                    const double q = (double)(int32_t)(ev[beg + mid].z - t0) / den;
+                    const double tn = q * (double)S;
+                    if (tn < target) lo = mid + 1; else hi = mid;
+                }
+                idx = (int)lo;
             }
-            idx = (int)lo;
-            tc = idx < n ? ev[beg + idx].z : 0;
+            tc = (idx >= 0 && idx < n) ? ev[beg + idx].z : 0;
         }
         sidx[s] = idx;
         cuts[b].idx[s] = idx;
@@ -285,10 +323,10 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
     if (s == 0) {
         bool alive = n > 0;
         for (int k = 0; k < kMaxSlices; ++k) {
-            // `if index == indices[pos]` fires once per event: a repeated idx is never reached
+            // `if index == indices[pos]` fires once per event: a repeated / decreasing idx is never reached
             if (k < S) {
                 if (k > 0 && sidx[k] <= sidx[k - 1]) alive = false;
-                if (sidx[k] >= n) alive = false;
+                if (sidx[k] < 0 || sidx[k] >= n) alive = false;
                 cuts[b].live[k] = alive ? 1 : 0;
             } else {
                 cuts[b].live[k] = 0;
@@ -299,85 +337,74 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
     }
 }
 
-// grid (H, B); dynamic LDS = 2*W*4 + align16(256*2S*sizeof(OutT)) + 16*sizeof(OutT).
 template <typename OutT>
-__global__ __launch_bounds__(kThreads) void k_time_surface(const Rec *__restrict__ sorted, const uint32_t *__restrict__ row_off,
-                                                          const TsCuts *__restrict__ cuts, int H, int W, int S, double tau,
-                                                          int premap, double scale, OutT *__restrict__ out) {
+__global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+                                                       const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int S,
+                                                       double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *seg_start = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *seg_end = seg_start + W;
     const int C = 2 * S;
-    OutT *stage = reinterpret_cast<OutT *>(smem + align16((size_t)2 * W * 4));
-    OutT *pat = reinterpret_cast<OutT *>(smem + align16((size_t)2 * W * 4) + align16((size_t)kThreads * C * sizeof(OutT)));
-    const int b = blockIdx.y, row = blockIdx.x;
-    RowCtx rc;
-    rc.rs = row_off[(size_t)b * (H + 1) + row];
-    rc.n = row_off[(size_t)b * (H + 1) + row + 1] - rc.rs;
-    const TsCuts cu = cuts[b];
+    WaveTile<OutT> wt(smem, C);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    const TsCuts cu = cuts[g.b];
     const double init = -(tau * 3.0 + 1.0);  // timestamp_memory -= tau*3 + 1 (time_surface.py:29)
     if (threadIdx.x < C) {
         const int s = threadIdx.x >> 1;
         double v = 0.0;
         // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau)
         if (cu.live[s]) { const double d = init - (double)cu.tcut[s]; v = exp(d / tau) * scale; }
-        pat[threadIdx.x] = (OutT)v;
+        wt.bg[threadIdx.x] = (OutT)v;
     }
-    build_segments(sorted, rc, row * W, W, seg_start, seg_end);  // (barriers inside also publish pat)
-    OutT *out_row = out + ((size_t)b * H + row) * (size_t)W * C;
-    for (int cb = 0; cb < W; cb += kThreads) {
-        const int npix = min(kThreads, W - cb);
-        fill_pattern(stage, npix * C, C, pat);
-        __syncthreads();
-        const int col = cb + threadIdx.x;
-        if (col < W) {
-            const uint32_t js = seg_start[col], je = seg_end[col];
-            if (je > js) {
-                OutT *mine = stage + (size_t)threadIdx.x * C;
-                double mem0 = init, mem1 = init;
-                bool touched0 = false, touched1 = false;
-                int s = 0;
-                for (uint32_t j = js; j <= je; ++j) {
-                    int rank = INT32_MAX, t = 0, p = 0;
-                    if (j < je) { const Rec e = sorted[rc.rs + j]; rank = e.y; t = e.z; p = e.w; }
-                    // slices cut strictly before this event see the memory as it stands
-                    while (s < S && cu.idx[s] < rank) {
-                        if (cu.live[s]) {
-                            const double tc = (double)cu.tcut[s];
-                            if (touched0) mine[2 * s] = (OutT)(exp((mem0 - tc) / tau) * scale);
-                            if (touched1) mine[2 * s + 1] = (OutT)(exp((mem1 - tc) / tau) * scale);
-                        }
-                        ++s;
-                    }
-                    if (j < je) {
-                        if (premap) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
-                        if (p & 1) { mem1 = (double)t; touched1 = true; } else { mem0 = (double)t; touched0 = true; }
-                    }
+    __syncthreads();
+    tile_fill_pattern(wt.tile, g.npix, C, wt.bg);
+    int nseg = 0;
+    if (g.ce > g.cs) nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nseg; k += kWave) {
+        const uint2 sg = wt.segs[k];
+        const uint32_t je = wt.segs[k + 1].y;
+        OutT *mine = wt.tile + (size_t)sg.x * C;
+        double mem0 = init, mem1 = init;
+        bool touched0 = false, touched1 = false;
+        int s = 0;
+        for (uint32_t j = sg.y; j <= je; ++j) {
+            int rank = INT32_MAX, t = 0, p = 0;
+            if (j < je) { const Rec e = sorted[j]; rank = e.y; t = e.z; p = e.w; }
+            // slices cut strictly before this event see the memory as it stands
+            while (s < S && cu.idx[s] < rank) {
+                if (cu.live[s]) {
+                    const double tc = (double)cu.tcut[s];
+                    if (touched0) mine[2 * s] = (OutT)(exp((mem0 - tc) / tau) * scale);
+                    if (touched1) mine[2 * s + 1] = (OutT)(exp((mem1 - tc) / tau) * scale);
                 }
+                ++s;
+            }
+            if (j < je) {
+                if (premap) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
+                if (p & 1) { mem1 = (double)t; touched1 = true; } else { mem0 = (double)t; touched0 = true; }
             }
         }
-        __syncthreads();
-        copy_out(stage, npix * C, out_row + (size_t)cb * C);
-        __syncthreads();
     }
+    __syncthreads();
+    tile_store(wt.tile, g.npix * C, dst);
 }
 
 // --------------------------------------------------------------------------------------------
-// A8: events2ToreFeature (tore.py:6-83), one sample time T = t[-1]
+// A8: events2ToreFeature (tore.py:6-83), one sample time per window
 // --------------------------------------------------------------------------------------------
 constexpr int kMaxToreK = 8;
 
-// grid (H, B); dynamic LDS = 2*W*4 + align16(256*2k*4).
-__global__ __launch_bounds__(kThreads) void k_tore(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
-                                                  const uint32_t *__restrict__ row_off, const int64_t *__restrict__ off,
-                                                  const WindowMeta *__restrict__ meta, int H, int W, int K, int frame_mode,
-                                                  float scale, float *__restrict__ out) {
+// grid (ceil(W/128), H, B) over OUTPUT chunks / rows, 64 threads.
+// sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
+__global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
+                                               const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
+                                               const WindowMeta *__restrict__ meta, const int32_t *__restrict__ sample_times,
+                                               int H, int W, int nchunk, int K, int frame_mode, float scale,
+                                               float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *seg_start = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *seg_end = seg_start + W;
-    float *stage = reinterpret_cast<float *>(smem + align16((size_t)2 * W * 4));
-    const int b = blockIdx.y, orow = blockIdx.x;  // orow = output row
     const int C = 2 * K;
+    WaveTile<float> wt(smem, C);
+    const int b = blockIdx.z, orow = blockIdx.y, oc0 = blockIdx.x * kChunkPx;
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
     if (n_win <= 0) return;
@@ -385,139 +412,128 @@ __global__ __launch_bounds__(kThreads) void k_tore(const int4 *__restrict__ ev, 
     int x0 = 0, y0 = 0, Hf = H, Wf = W;
     if (frame_mode == 0 || frame_mode == 1) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
     if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
-    if (orow >= Hf) return;
-    const int row = orow + y0;  // sensor row feeding this output row
-    const int T = ev[beg + n_win - 1].z;  // sampleTimes = ts[-1]
-    RowCtx rc; rc.rs = 0; rc.n = 0;
-    if (row >= 0 && row < H) {
-        rc.rs = row_off[(size_t)b * (H + 1) + row];
-        rc.n = row_off[(size_t)b * (H + 1) + row + 1] - rc.rs;
-    }
-    build_segments(sorted, rc, row * W, W, seg_start, seg_end);
+    if (orow >= Hf || oc0 >= Wf) return;
+    const int npix = min(kChunkPx, Wf - oc0);
+    const int row = orow + y0;                      // sensor row feeding this output row
+    const int T = sample_times ? sample_times[b] : ev[beg + n_win - 1].z;
     // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
     const double log_min = log(151.0);
-    const float bg = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
-    float *out_row = out + (size_t)b * H * W * C + (size_t)orow * Wf * C;
-    for (int cb = 0; cb < Wf; cb += kThreads) {
-        const int npix = min(kThreads, Wf - cb);
-        for (int e = threadIdx.x; e < npix * C; e += kThreads) stage[e] = bg;
-        __syncthreads();
-        const int ocol = cb + threadIdx.x;
-        const int col = ocol + x0;
-        if (ocol < Wf && col >= 0 && col < W) {
-            const uint32_t js = seg_start[col], je = seg_end[col];
-            if (je > js) {
-                int fp[kMaxToreK], fn[kMaxToreK];
-                int np_ = 0, nn_ = 0;
+    const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
+    for (int e = threadIdx.x; e < npix * C; e += kWave) wt.tile[e] = bgv;
+    // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle two sensor chunks
+    int nseg = 0;
+    const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;  // sensor column range
+    if (row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
+        const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
+        const uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+        const uint32_t cs = co[ch_lo], ce = co[ch_hi + 1];
+        if (ce > cs) nseg = list_segments(sorted, cs, ce, row * W + sc_lo, wt.segs);
+    }
+    __syncthreads();
+    float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
+    for (int k = threadIdx.x; k < nseg; k += kWave) {
+        const uint2 sg = wt.segs[k];
+        if (sg.x >= (uint32_t)npix) continue;  // a pixel of the neighbouring output chunk
+        const uint32_t je = wt.segs[k + 1].y;
+        int fp[kMaxToreK], fn[kMaxToreK];
+        int np_ = 0, nn_ = 0;
 #pragma unroll
-                for (int k = 0; k < kMaxToreK; ++k) { fp[k] = 0; fn[k] = 0; }
-                for (uint32_t j = js; j < je; ++j) {
-                    const Rec e = sorted[rc.rs + j];
-                    if (!(e.z < T)) continue;  // ts < currentSampleTime (tore.py:17): events at T are dropped
-                    if (e.w > 0) {
+        for (int q = 0; q < kMaxToreK; ++q) { fp[q] = 0; fn[q] = 0; }
+        for (uint32_t j = sg.y; j < je; ++j) {
+            const Rec e = sorted[j];
+            if (!(e.z < T)) continue;  // ts < currentSampleTime (tore.py:17): events at T are dropped
+            if (e.w > 0) {
 #pragma unroll
-                        for (int k = kMaxToreK - 1; k > 0; --k) fp[k] = fp[k - 1];
-                        fp[0] = e.z; ++np_;
-                    } else {
+                for (int q = kMaxToreK - 1; q > 0; --q) fp[q] = fp[q - 1];
+                fp[0] = e.z; ++np_;
+            } else {
 #pragma unroll
-                        for (int k = kMaxToreK - 1; k > 0; --k) fn[k] = fn[k - 1];
-                        fn[0] = e.z; ++nn_;
-                    }
+                for (int q = kMaxToreK - 1; q > 0; --q) fn[q] = fn[q - 1];
+                fn[0] = e.z; ++nn_;
+            }
+        }
+        float *mine = wt.tile + (size_t)sg.x * C;
+#pragma unroll
+        for (int q = 0; q < kMaxToreK; ++q) {
+            if (q < K) {
+                if (q < np_) {
+                    float v = (float)(double)((int64_t)T - (int64_t)fp[q]);
+                    v = fminf(v, 500e6f);
+                    const float r = (float)((double)logf(v + 1.0f) - log_min);
+                    mine[q] = fmaxf(r, 0.0f) * scale;
                 }
-                float *mine = stage + (size_t)threadIdx.x * C;
-#pragma unroll
-                for (int k = 0; k < kMaxToreK; ++k) {
-                    if (k < K) {
-                        if (k < np_) {
-                            float v = (float)(double)((int64_t)T - (int64_t)fp[k]);
-                            v = fminf(v, 500e6f);
-                            const float r = (float)((double)logf(v + 1.0f) - log_min);
-                            mine[k] = fmaxf(r, 0.0f) * scale;
-                        }
-                        if (k < nn_) {
-                            float v = (float)(double)((int64_t)T - (int64_t)fn[k]);
-                            v = fminf(v, 500e6f);
-                            const float r = (float)((double)logf(v + 1.0f) - log_min);
-                            mine[K + k] = fmaxf(r, 0.0f) * scale;
-                        }
-                    }
+                if (q < nn_) {
+                    float v = (float)(double)((int64_t)T - (int64_t)fn[q]);
+                    v = fminf(v, 500e6f);
+                    const float r = (float)((double)logf(v + 1.0f) - log_min);
+                    mine[K + q] = fmaxf(r, 0.0f) * scale;
                 }
             }
         }
-        __syncthreads();
-        copy_out(stage, npix * C, out_row + (size_t)cb * C);
-        __syncthreads();
     }
+    __syncthreads();
+    tile_store(wt.tile, npix * C, dst);
 }
 
 // --------------------------------------------------------------------------------------------
 // A2: compute_repr (representation_search/gromov_wasserstein.py:72-82), t normalised as :96.
 // mode 1: tonic.transforms.ToVoxelGrid as consumed at gen1_transforms.py:22-25 (parity unpinned).
 // --------------------------------------------------------------------------------------------
-// grid (H, B); dynamic LDS = 2*W*4 + align16(256*bins*8).
-__global__ __launch_bounds__(kThreads) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
-                                                   const uint32_t *__restrict__ row_off, const int64_t *__restrict__ off,
-                                                   int H, int W, int bins, int mode, double scale, double *__restrict__ out) {
+__global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
+                                                const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
+                                                int H, int W, int nchunk, int bins, int mode, double scale,
+                                                double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *seg_start = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *seg_end = seg_start + W;
-    double *stage = reinterpret_cast<double *>(smem + align16((size_t)2 * W * 4));
-    const int b = blockIdx.y, row = blockIdx.x;
-    const int64_t beg = off[b];
-    const int64_t n_win = off[b + 1] - beg;
-    RowCtx rc;
-    rc.rs = row_off[(size_t)b * (H + 1) + row];
-    rc.n = row_off[(size_t)b * (H + 1) + row + 1] - rc.rs;
-    double t0 = 0.0, den = 0.0;
-    if (n_win > 0) { t0 = (double)ev[beg].z; den = (double)ev[beg + n_win - 1].z - t0; }
-    build_segments(sorted, rc, row * W, W, seg_start, seg_end);
-    double *out_row = out + ((size_t)b * H + row) * (size_t)W * bins;
-    for (int cb = 0; cb < W; cb += kThreads) {
-        const int npix = min(kThreads, W - cb);
-        fill_zero(stage, npix * bins);
+    WaveTile<double> wt(smem, bins);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
+    tile_fill_zero(wt.tile, g.npix * bins);
+    if (g.ce == g.cs) {
         __syncthreads();
-        const int col = cb + threadIdx.x;
-        if (col < W) {
-            const uint32_t js = seg_start[col], je = seg_end[col];
-            double *mine = stage + (size_t)threadIdx.x * bins;
-            // two np.add.at passes: lower bin for every event, then upper bin for every event
-            for (int pass = 0; pass < 2 && je > js; ++pass) {
-                for (uint32_t j = js; j < je; ++j) {
-                    const Rec e = sorted[rc.rs + j];
-                    double p = (double)e.w;
-                    double bpos;
-                    if (mode == 0) {
-                        const double tn = ((double)e.z - t0) / den;
-                        bpos = (double)(bins - 1) * tn;
-                    } else {
-                        const double num = (double)bins * ((double)e.z - t0);
-                        bpos = num / den;
-                        if (e.w == 0) p = -1.0;
-                    }
-                    const int bi = (int)bpos;
-                    const int blim = bi + pass;
-                    if (blim < bins && blim >= 0) {
-                        double w;
-                        if (mode == 0) w = 1.0 - fabs((double)blim - bpos);
-                        else { const double dts = bpos - (double)bi; w = pass ? dts : 1.0 - dts; }
-                        const double wp = mode == 0 ? w * p : p * w;
-                        mine[blim] = mine[blim] + wp;
-                    }
+        tile_store(wt.tile, g.npix * bins, dst);
+        return;
+    }
+    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
+    __syncthreads();
+    const int64_t beg = off[g.b];
+    const int64_t n_win = off[g.b + 1] - beg;
+    const double t0 = (double)ev[beg].z;
+    const double den = (double)ev[beg + n_win - 1].z - t0;
+    for (int k = threadIdx.x; k < nseg; k += kWave) {
+        const uint2 sg = wt.segs[k];
+        const uint32_t je = wt.segs[k + 1].y;
+        double *mine = wt.tile + (size_t)sg.x * bins;
+        // two np.add.at passes: lower bin for every event, then upper bin for every event
+        for (int pass = 0; pass < 2; ++pass) {
+            for (uint32_t j = sg.y; j < je; ++j) {
+                const Rec e = sorted[j];
+                double p = (double)e.w;
+                double bpos;
+                if (mode == 0) {
+                    const double tn = ((double)e.z - t0) / den;
+                    bpos = (double)(bins - 1) * tn;
+                } else {
+                    const double num = (double)bins * ((double)e.z - t0);
+                    bpos = num / den;
+                    if (e.w == 0) p = -1.0;
+                }
+                if (!(bpos >= 0.0 && bpos < 1.0e9)) continue;  // flat time span (0/0): the reference yields NaN garbage
+                const int bi = (int)bpos;
+                const int blim = bi + pass;
+                if (blim < bins) {
+                    double w;
+                    if (mode == 0) w = 1.0 - fabs((double)blim - bpos);
+                    else { const double dts = bpos - (double)bi; w = pass ? dts : 1.0 - dts; }
+                    const double wp = w * p;
+                    mine[blim] = mine[blim] + wp;
                 }
             }
-            if (scale != 1.0 && je > js)
-                for (int k = 0; k < bins; ++k) mine[k] = mine[k] * scale;
         }
-        __syncthreads();
-        copy_out(stage, npix * bins, out_row + (size_t)cb * bins);
-        __syncthreads();
+        if (scale != 1.0)
+            for (int q = 0; q < bins; ++q) mine[q] = mine[q] * scale;
     }
+    __syncthreads();
+    tile_store(wt.tile, g.npix * bins, dst);
 }
-
-// explicit instantiations used by the C API
-template __global__ void k_mdes<double>(const Rec *, const uint32_t *, const int64_t *, const WindowMeta *, MdesParams, int, int, double, double *);
-template __global__ void k_mdes<float>(const Rec *, const uint32_t *, const int64_t *, const WindowMeta *, MdesParams, int, int, double, float *);
-template __global__ void k_time_surface<double>(const Rec *, const uint32_t *, const TsCuts *, int, int, int, double, int, double, double *);
-template __global__ void k_time_surface<float>(const Rec *, const uint32_t *, const TsCuts *, int, int, int, double, int, double, float *);
 
 }  // namespace evrep

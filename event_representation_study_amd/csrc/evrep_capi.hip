@@ -50,10 +50,12 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     if (nblk < 1) nblk = 1;
     plan->chunk = (int32_t)chunk;
     plan->nblk = (int32_t)nblk;
+    plan->nchunk = (W + kChunkPx - 1) / kChunkPx;
     size_t o = 0;
     plan->off_meta = o;    o += up256((size_t)B * sizeof(WindowMeta));
     plan->off_table = o;   o += up256((size_t)B * nblk * H * sizeof(uint32_t));
     plan->off_rowoff = o;  o += up256((size_t)B * (H + 1) * sizeof(uint32_t));
+    plan->off_chunkoff = o; o += up256((size_t)B * H * (plan->nchunk + 1) * sizeof(uint32_t));
     plan->off_sorted1 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
     plan->off_sorted2 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
     plan->off_cuts = o;    o += up256((size_t)B * sizeof(TsCuts));
@@ -94,12 +96,13 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     LAUNCH_CHECK("k_row_scan");
     k_row_scatter<<<dim3(nblk, B), kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, H, W, chunk, nblk, table, row_off, s1);
     LAUNCH_CHECK("k_row_scatter");
-    k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, s2);
+    k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
+                                                                                WS(uint32_t, off_chunkoff));
     LAUNCH_CHECK("k_col_sort");
     return EVREP_OK;
 }
 
-static size_t builder_lds(int W, int C, size_t elem) { return align16((size_t)2 * W * 4) + align16((size_t)kThreads * C * elem) + 256; }
+#define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
 
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
                const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
@@ -113,15 +116,14 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     memset(&P, 0, sizeof(P));
     P.C = C;
     for (int c = 0; c < C; ++c) { P.win[c] = window[c]; P.func[c] = func[c]; P.agg[c] = agg[c]; }
-    const dim3 grid(plan->H, plan->B);
     if (out_dtype == EVREP_F64) {
-        k_mdes<double><<<grid, kThreads, builder_lds(plan->W, C, 8), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
-            scale, static_cast<double *>(out));
+        k_mdes<double><<<BUILDER_GRID, kWave, builder_lds_bytes(C, 8), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
+            plan->nchunk, scale, static_cast<double *>(out));
     } else {
-        k_mdes<float><<<grid, kThreads, builder_lds(plan->W, C, 4), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
-            scale, static_cast<float *>(out));
+        k_mdes<float><<<BUILDER_GRID, kWave, builder_lds_bytes(C, 4), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
+            plan->nchunk, scale, static_cast<float *>(out));
     }
     LAUNCH_CHECK("k_mdes");
     return EVREP_OK;
@@ -145,46 +147,46 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_event_stack<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, stack_size, 4), stream>>>(
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, plan->H, plan->W, stack_size, premap, scale, out);
+    k_event_stack<<<BUILDER_GRID, kWave, builder_lds_bytes(stack_size, 4), stream>>>(
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, stack_size, premap,
+        scale, out);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
 }
 
 int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
-                       int32_t slices, double tau, int32_t premap, double scale, int32_t out_dtype, void *out,
-                       void *stream_) {
+                       int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
+                       int32_t out_dtype, void *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (slices <= 0 || slices > kMaxSlices || !out || !(tau > 0.0)) return EVREP_EINVAL;
     if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TsCuts *cuts = WS(TsCuts, off_cuts);
-    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, cuts);
+    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, cuts);
     LAUNCH_CHECK("k_ts_cuts");
-    const dim3 grid(plan->H, plan->B);
     if (out_dtype == EVREP_F64) {
-        k_time_surface<double><<<grid, kThreads, builder_lds(plan->W, 2 * slices, 8), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), cuts, plan->H, plan->W, slices, tau, premap, scale,
-            static_cast<double *>(out));
+        k_time_surface<double><<<BUILDER_GRID, kWave, builder_lds_bytes(2 * slices, 8), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
+            premap, scale, static_cast<double *>(out));
     } else {
-        k_time_surface<float><<<grid, kThreads, builder_lds(plan->W, 2 * slices, 4), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), cuts, plan->H, plan->W, slices, tau, premap, scale,
-            static_cast<float *>(out));
+        k_time_surface<float><<<BUILDER_GRID, kWave, builder_lds_bytes(2 * slices, 4), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
+            premap, scale, static_cast<float *>(out));
     }
     LAUNCH_CHECK("k_time_surface");
     return EVREP_OK;
 }
 
 int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t k,
-               int32_t frame_mode, float scale, float *out, void *stream_) {
+               int32_t frame_mode, const int32_t *sample_times, float scale, float *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_tore<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, 2 * k, 4), stream>>>(
-        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets,
-        CWS(WindowMeta, off_meta), plan->H, plan->W, k, frame_mode, scale, out);
+    k_tore<<<BUILDER_GRID, kWave, builder_lds_bytes(2 * k, 4), stream>>>(
+        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
+        CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, k, frame_mode, scale, out);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
 }
@@ -195,9 +197,9 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     if (rc) return rc;
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 1 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_voxel<<<dim3(plan->H, plan->B), kThreads, builder_lds(plan->W, bins, 8), stream>>>(
-        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_rowoff), offsets, plan->H,
-        plan->W, bins, mode, scale, out);
+    k_voxel<<<BUILDER_GRID, kWave, builder_lds_bytes(bins, 8), stream>>>(
+        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
+        plan->W, plan->nchunk, bins, mode, scale, out);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }

@@ -10,6 +10,7 @@ namespace evrep {
 constexpr int kThreads = 256;  // 4 wave64 per workgroup
 constexpr int kWaves = 4;
 constexpr int kWave = 64;
+constexpr int kChunkPx = 128;  // pixels of one row that one builder wavefront owns
 
 // Per-window statistics produced by the binning pass (workspace, one per window).
 struct WindowMeta {

@@ -163,23 +163,39 @@ class EventBatch:
                                              _ptr(out), _stream_ptr()), "evrep_event_stack")
         return out
 
-    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None):
+    def _i32_dev(self, values, per_window):
+        """None -> NULL; else a (B, per_window) int32 device tensor (a list is taken as one row per window)."""
+        if values is None:
+            return None, ctypes.c_void_p(None)
+        t = torch.as_tensor(np.asarray(values, dtype=np.int32)).reshape(-1)
+        if t.numel() == per_window and self.B > 1:
+            t = t.repeat(self.B)
+        if t.numel() != self.B * per_window:
+            raise ValueError("expected %d x %d int32 values" % (self.B, per_window))
+        t = t.to(self.device)
+        return t, _ptr(t)
+
+    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None, indices=None):
+        """ToTimesurface for every window -> (B, H, W, 2*slices), channel c = 2*s + p.  indices=None: the
+        dispatcher's cuts searchsorted(t_norm, 1..slices); else explicit event indices per window."""
         self.bin()
         out = self._out(out, 2 * slices, dtype)
+        keep, iptr = self._i32_dev(indices, slices)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_time_surface(*self._args(), int(slices), float(tau), int(bool(premap)),
+            check(self.lib.evrep_time_surface(*self._args(), int(slices), iptr, float(tau), int(bool(premap)),
                                               float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
                   "evrep_time_surface")
         return out
 
-    def tore(self, k=6, frame_mode=0, scale=1.0, out=None):
+    def tore(self, k=6, frame_mode=0, scale=1.0, out=None, sample_times=None):
         """TORE.  frame_mode 0 (bounding box, the gen1/gen4 dispatcher's behaviour) returns a list of
         per-window (Hbb, Wbb, 2k) views (needs one host sync for the boxes); modes 1/2 return
         (B, H, W, 2k)."""
         self.bin()
         out = self._out(out, 2 * k, torch.float32)
+        keep, tptr = self._i32_dev(sample_times, 1)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_tore(*self._args(), int(k), int(frame_mode), float(scale), _ptr(out),
+            check(self.lib.evrep_tore(*self._args(), int(k), int(frame_mode), tptr, float(scale), _ptr(out),
                                       _stream_ptr()), "evrep_tore")
         if frame_mode != 0:
             return out

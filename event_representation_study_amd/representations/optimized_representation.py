@@ -1,0 +1,12 @@
+"""get_optimized_representation -- mirrors representations/optimized_representation.py:86-134."""
+from ._common import raise_for_status, single_batch
+
+N_CHANNELS = 12
+
+
+def get_optimized_representation(reshaped_return_data, num_events, height, width):
+    """ERGO-12: the 12 (window, function, aggregation) triples of the reference's second search,
+    as an (H, W, 12) float64 array."""
+    batch = single_batch(reshaped_return_data, height, width)
+    raise_for_status(batch, allow_oob=True, what="get_optimized_representation")
+    return batch.optimized(scale=1.0)[0].cpu().numpy()

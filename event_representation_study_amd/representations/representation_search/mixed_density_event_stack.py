@@ -1,0 +1,26 @@
+"""MixedDensityEventStack -- mirrors representation_search/mixed_density_event_stack.py:8-151."""
+from .._common import raise_for_status, single_batch
+
+
+class MixedDensityEventStack(object):
+    def __init__(self, stack_size, num_of_events, height, width, indexes_functions_aggregations, stacking_type):
+        self.stack_size = stack_size
+        self.num_of_events = num_of_events
+        self.height = height
+        self.width = width
+        self.indexes_functions_aggregations = indexes_functions_aggregations
+        self.stacking_type = stacking_type
+
+    def stack(self, event_sequence):
+        """(H, W, stack_size) float64.  A channel whose triple is unusable (``None`` window, unknown
+        function, out-of-frame events in its window) is all zeros, like the reference's try/except."""
+        if self.stacking_type != "SBN":
+            raise NotImplementedError("only the 'SBN' stacking the reference selects is implemented")
+        windows, funcs, aggs = self.indexes_functions_aggregations
+        batch = single_batch(event_sequence, self.height, self.width)
+        raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
+        from ... import _lib
+        w = [v if isinstance(v, int) and 0 <= v <= 6 else None for v in list(windows)[: self.stack_size]]
+        f = [v if v in _lib.FUNCS else None for v in list(funcs)[: self.stack_size]]
+        a = [v if v in _lib.AGGS else None for v in list(aggs)[: self.stack_size]]
+        return batch.mdes(w, f, a, scale=1.0)[0].cpu().numpy()

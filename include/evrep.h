@@ -59,8 +59,9 @@ typedef struct evrep_plan {
     int32_t B, H, W;
     int64_t total_events;          /* offsets[B] */
     int64_t max_events_per_window; /* upper bound used to size grids; no host sync needed */
-    int32_t chunk, nblk;           /* partition geometry (derived) */
-    size_t off_meta, off_table, off_rowoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
+    int32_t chunk, nblk;           /* row-partition geometry (derived) */
+    int32_t nchunk, reserved;      /* 128-pixel column chunks per row (derived) */
+    size_t off_meta, off_table, off_rowoff, off_chunkoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
     size_t workspace_bytes;
 } evrep_plan;
 
@@ -100,20 +101,24 @@ int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t
 int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                       int32_t stack_size, int32_t premap, float scale, float *out, void *stream);
 
-/* ToTimesurface.__call__ (time_surface.py:25-74) driven as gen1_transforms.py:69-87:
- * S slices cut at searchsorted(t_norm, 1..S); out DEVICE (B,H,W,2S) float64/float32, c = 2s+p. */
+/* ToTimesurface.__call__ (time_surface.py:25-74): S <= 8 surfaces sampled at event indices.
+ * indices == NULL: the cuts gen1_transforms.py:79-81 computes, searchsorted(t_norm, 1..S);
+ * otherwise DEVICE int32 [B,S], the `indices` argument of ToTimesurface.__call__.
+ * premap != 0 applies p -> int8((p+1)/2) first (gen1_transforms.py:70-72).
+ * out DEVICE (B,H,W,2S) float64/float32, channel c = 2s+p. */
 int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
-                       int32_t slices, double tau, int32_t premap, double scale, int32_t out_dtype,
-                       void *out, void *stream);
+                       int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
+                       int32_t out_dtype, void *out, void *stream);
 
-/* events2ToreFeature (tore.py:6-83) for one sample time T = t[-1], k <= 8.
+/* events2ToreFeature (tore.py:6-83) for one sample time per window, k <= 8.
+ * sample_times == NULL: T = t[-1] (gen1_transforms.py:63); otherwise DEVICE int32 [B].
  * frame_mode 0: the events' bounding box, origin-shifted (gen1_transforms.py:61-64); the window's
  *               output is a compact (Hbb,Wbb,2k) array at out + b*H*W*2k, bbox via evrep_read_bbox;
  * frame_mode 1: full (H,W) frame, origin-shifted by (xmin,ymin) (n_imagenet .../imagenet.py:1095-1103);
  * frame_mode 2: full (H,W) frame, no shift (x, y used as 0-based pixel coordinates).
  * out DEVICE float32. */
 int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
-               int32_t k, int32_t frame_mode, float scale, float *out, void *stream);
+               int32_t k, int32_t frame_mode, const int32_t *sample_times, float scale, float *out, void *stream);
 
 /* compute_repr (representation_search/gromov_wasserstein.py:72-82) with t normalised as :96;
  * mode 0.  mode 1 = tonic.transforms.ToVoxelGrid as gen1_transforms.py:22-25 consumes it
