@@ -33,7 +33,7 @@ struct WaveTile {
     }
 };
 
-static size_t builder_lds_bytes(int C, size_t elem) {
+__host__ __device__ inline size_t builder_lds_bytes(int C, size_t elem) {
     return align16((size_t)kChunkPx * C * elem) + 16 * elem + (size_t)(kMaxSegs + 1) * sizeof(uint2) + 16;
 }
 
@@ -119,44 +119,114 @@ struct MdesParams {
     int32_t win[EVREP_MAX_CHANNELS], func[EVREP_MAX_CHANNELS], agg[EVREP_MAX_CHANNELS];
 };
 
-constexpr int kWantAny = 2;
+// Descriptor sources: RuntimeDesc reads the caller's triples from the kernel arguments;
+// StaticDesc<T> reads a constexpr table, so after unrolling every per-channel branch folds away
+// and unused accumulators disappear (ERGO-12: 2 variance, 3 max, 1 mean-of-timestamps, ...).
+struct RuntimeDesc {
+    static constexpr bool kStatic = false;
+    static constexpr int kMaxC = EVREP_MAX_CHANNELS;
+    __device__ static inline int C(const MdesParams &P) { return P.C; }
+    __device__ static inline int win(const MdesParams &P, int c) { return P.win[c]; }
+    __device__ static inline int func(const MdesParams &P, int c) { return P.func[c]; }
+    __device__ static inline int agg(const MdesParams &P, int c) { return P.agg[c]; }
+};
 
-// grid (nchunk, H, B), 64 threads; dynamic LDS = builder_lds_bytes(C, sizeof(OutT)).
-template <typename OutT>
+// the ERGO-12 triples, optimized_representation.py:87-115
+struct Ergo12Table {
+    static constexpr int kC = 12;
+    static constexpr int kWin[12] = {0, 3, 2, 6, 5, 6, 2, 5, 1, 0, 4, 1};
+    static constexpr int kFunc[12] = {EVREP_F_POLARITY, EVREP_F_TIMESTAMP_NEG, EVREP_F_COUNT_NEG, EVREP_F_POLARITY,
+                                      EVREP_F_COUNT_POS, EVREP_F_COUNT, EVREP_F_TIMESTAMP_POS, EVREP_F_COUNT_NEG,
+                                      EVREP_F_TIMESTAMP_NEG, EVREP_F_TIMESTAMP_POS, EVREP_F_TIMESTAMP, EVREP_F_COUNT};
+    static constexpr int kAgg[12] = {EVREP_A_VARIANCE, EVREP_A_VARIANCE, EVREP_A_MEAN, EVREP_A_SUM, EVREP_A_MEAN,
+                                     EVREP_A_SUM, EVREP_A_MEAN, EVREP_A_MEAN, EVREP_A_MAX, EVREP_A_MAX, EVREP_A_MAX,
+                                     EVREP_A_MEAN};
+};
+
+template <typename T>
+struct StaticDesc {
+    static constexpr bool kStatic = true;
+    static constexpr int kMaxC = T::kC;
+    __device__ static inline int C(const MdesParams &) { return T::kC; }
+    __device__ static inline int win(const MdesParams &, int c) { return T::kWin[c]; }
+    __device__ static inline int func(const MdesParams &, int c) { return T::kFunc[c]; }
+    __device__ static inline int agg(const MdesParams &, int c) { return T::kAgg[c]; }
+};
+
+constexpr int kWantAny = 2;
+constexpr int kEvCap = 128;  // records of a chunk staged in LDS; denser chunks read the rest from HBM/L2
+
+__device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG; }
+__device__ inline bool is_ts_func(int f) { return f == EVREP_F_TIMESTAMP || f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_TIMESTAMP_NEG; }
+
+// grid (nchunk, H, B), 64 threads; dynamic LDS = builder_lds_bytes(C, sizeof(OutT)) + kEvCap*16.
+template <typename OutT, typename D>
 __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
                                                const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
                                                MdesParams P, int H, int W, int nchunk, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = P.C;
+    const int C = D::C(P);
     WaveTile<OutT> wt(smem, C);
+    Rec *evbuf = reinterpret_cast<Rec *>(smem + builder_lds_bytes(C, sizeof(OutT)));
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    const int lane = threadIdx.x;
+
+    // issue every independent global load first: the chunk's records (one coalesced 16 B/lane
+    // load per 64 records), the window's statistics and extent
+    const uint32_t nrec = g.ce - g.cs;
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0), r1 = make_int4(INT32_MIN, 0, 0, 0);
+    if (lane < (int)nrec) r0 = sorted[g.cs + lane];
+    if (lane + kWave < (int)nrec) r1 = sorted[g.cs + kWave + lane];
+    const int64_t n_win = off[g.b + 1] - off[g.b];
+    const WindowMeta m = meta[g.b];
 
     tile_fill_zero(wt.tile, g.npix * C);
-    if (g.ce == g.cs) {  // empty chunk: pure zero fill
+    if (nrec == 0) {  // empty chunk: pure zero fill
         __syncthreads();
         tile_store(wt.tile, g.npix * C, dst);
         return;
     }
-    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
+    evbuf[lane] = r0;
+    evbuf[kWave + lane] = r1;
+
+    // segment heads (runs of equal pixel id); records beyond kEvCap are walked from global memory
+    const int key0 = g.row * W + g.c0;
+    int nseg = 0;
+    {
+        int carry = INT32_MIN;
+        for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            const bool valid = j < nrec;
+            int key = INT32_MIN;
+            if (j0 == 0) key = r0.x; else if (j0 == kWave) key = r1.x; else if (valid) key = sorted[g.cs + j].x;
+            if (!valid) key = INT32_MIN;
+            int prev = __shfl_up(key, 1, 64);
+            if (lane == 0) prev = carry;
+            const bool head = valid && key != prev;
+            const uint64_t hm = __ballot(head);
+            if (head) wt.segs[nseg + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(key - key0), j);
+            nseg += __popcll(hm);
+            carry = __shfl(key, 63, 64);
+        }
+        if (lane == 0) wt.segs[nseg] = make_uint2(0u, nrec);
+    }
     __syncthreads();
 
-    const int64_t n_win = off[g.b + 1] - off[g.b];
-    const WindowMeta m = meta[g.b];
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
     const MdesWindows mw = mdes_windows(n_win);
 
     // per-channel uniform setup
-    int lo[EVREP_MAX_CHANNELS], hi[EVREP_MAX_CHANNELS], want[EVREP_MAX_CHANNELS];
-    bool active[EVREP_MAX_CHANNELS];
+    int lo[D::kMaxC], hi[D::kMaxC], want[D::kMaxC];
+    bool active[D::kMaxC];
 #pragma unroll
-    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+    for (int c = 0; c < D::kMaxC; ++c) {
         lo[c] = 0; hi[c] = 0; want[c] = kWantAny; active[c] = false;
         if (c < C) {
-            const int w = P.win[c], f = P.func[c], a = P.agg[c];
+            const int w = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
             bool ok = w >= 0 && w <= 6 && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
             int l = 0, h = 0;
 #pragma unroll
@@ -165,42 +235,42 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { wn = 1; field = 1; }
             if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
                 // rows with p == -1; if the window has none, rows with p == 0 (operations.py:59-61,78-80)
-                const bool has_neg = ok && ((m.neg_flags >> w) & 1u);
+                const bool has_neg = ok && ((m.neg_flags >> (w & 7)) & 1u);
                 wn = has_neg ? -1 : 0;
                 field = has_neg ? 2 : 3;
             }
             // an out-of-range index inside the selected rows raises in torch_scatter -> zero channel
-            if (ok && ((m.oob_flags >> (7 * field + w)) & 1u)) ok = false;
+            if (ok && ((m.oob_flags >> (7 * field + (w & 7))) & 1u)) ok = false;
             lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
         }
     }
 
-    for (int k = threadIdx.x; k < nseg; k += kWave) {
+    for (int k = lane; k < nseg; k += kWave) {
         const uint2 sg = wt.segs[k];
         const uint32_t je = wt.segs[k + 1].y;
-        double s[EVREP_MAX_CHANNELS], s2[EVREP_MAX_CHANNELS];
-        int cnt[EVREP_MAX_CHANNELS];
+        double s[D::kMaxC], s2[D::kMaxC];
+        int cnt[D::kMaxC];
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
+        for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
         for (uint32_t j = sg.y; j < je; ++j) {
-            const Rec e = sorted[j];
+            const Rec e = j < (uint32_t)kEvCap ? evbuf[j] : sorted[g.cs + j];
             const int rank = e.y, p = e.w;
             const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
             const double pv = (double)p;
 #pragma unroll
-            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+            for (int c = 0; c < D::kMaxC; ++c) {
                 if (c < C && active[c]) {
                     const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
-                    const int f = P.func[c];
-                    const double v = (f == EVREP_F_POLARITY) ? pv
-                                   : ((f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG) ? 1.0 : tn);
+                    const int f = D::func(P, c), a = D::agg(P, c);
+                    const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
                     if (hit) {
-                        if (P.agg[c] == EVREP_A_MAX) {
+                        if (a == EVREP_A_MAX) {
                             if (cnt[c] == 0 || v > s[c]) s[c] = v;
+                        } else if (is_count_func(f)) {
+                            // src = ones: sum, sum of squares and count coincide (exact small integers)
                         } else {
                             s[c] = s[c] + v;
-                            const double vv = v * v;
-                            s2[c] = s2[c] + vv;
+                            if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
                         }
                         ++cnt[c];
                     }
@@ -209,13 +279,17 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
         }
         OutT *mine = wt.tile + (size_t)sg.x * C;
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+        for (int c = 0; c < D::kMaxC; ++c) {
             if (c < C) {
                 double r = 0.0;
                 if (active[c]) {
+                    const int f = D::func(P, c), a = D::agg(P, c);
+                    const double n = (double)cnt[c];
                     const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
-                    const int a = P.agg[c];
-                    if (a == EVREP_A_SUM) r = s[c];
+                    if (is_count_func(f) && a != EVREP_A_MAX) {
+                        // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
+                        r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
+                    } else if (a == EVREP_A_SUM) r = s[c];
                     else if (a == EVREP_A_MEAN) r = s[c] / d;
                     else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
                     else {

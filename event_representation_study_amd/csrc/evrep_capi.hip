@@ -116,28 +116,28 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     memset(&P, 0, sizeof(P));
     P.C = C;
     for (int c = 0; c < C; ++c) { P.win[c] = window[c]; P.func[c] = func[c]; P.agg[c] = agg[c]; }
+    // the ERGO-12 triples get the kernel instance with compile-time descriptors
+    bool ergo = C == Ergo12Table::kC;
+    for (int c = 0; ergo && c < C; ++c)
+        ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
+#define MDES_LAUNCH(T, DESC)                                                                                          \
+    k_mdes<T, DESC><<<BUILDER_GRID, kWave, builder_lds_bytes(C, sizeof(T)) + kEvCap * sizeof(Rec), stream>>>(          \
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
+        plan->nchunk, scale, static_cast<T *>(out))
     if (out_dtype == EVREP_F64) {
-        k_mdes<double><<<BUILDER_GRID, kWave, builder_lds_bytes(C, 8), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
-            plan->nchunk, scale, static_cast<double *>(out));
+        if (ergo) MDES_LAUNCH(double, StaticDesc<Ergo12Table>); else MDES_LAUNCH(double, RuntimeDesc);
     } else {
-        k_mdes<float><<<BUILDER_GRID, kWave, builder_lds_bytes(C, 4), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,
-            plan->nchunk, scale, static_cast<float *>(out));
+        if (ergo) MDES_LAUNCH(float, StaticDesc<Ergo12Table>); else MDES_LAUNCH(float, RuntimeDesc);
     }
+#undef MDES_LAUNCH
     LAUNCH_CHECK("k_mdes");
     return EVREP_OK;
 }
 
 int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                     double scale, int32_t out_dtype, void *out, void *stream) {
-    // the ERGO-12 triples, optimized_representation.py:87-115
-    static const int32_t win[12] = {0, 3, 2, 6, 5, 6, 2, 5, 1, 0, 4, 1};
-    static const int32_t func[12] = {EVREP_F_POLARITY, EVREP_F_TIMESTAMP_NEG, EVREP_F_COUNT_NEG, EVREP_F_POLARITY,
-                                     EVREP_F_COUNT_POS, EVREP_F_COUNT, EVREP_F_TIMESTAMP_POS, EVREP_F_COUNT_NEG,
-                                     EVREP_F_TIMESTAMP_NEG, EVREP_F_TIMESTAMP_POS, EVREP_F_TIMESTAMP, EVREP_F_COUNT};
-    static const int32_t agg[12] = {EVREP_A_VARIANCE, EVREP_A_VARIANCE, EVREP_A_MEAN, EVREP_A_SUM, EVREP_A_MEAN, EVREP_A_SUM,
-                                    EVREP_A_MEAN, EVREP_A_MEAN, EVREP_A_MAX, EVREP_A_MAX, EVREP_A_MAX, EVREP_A_MEAN};
+    int32_t win[12], func[12], agg[12];
+    for (int c = 0; c < 12; ++c) { win[c] = Ergo12Table::kWin[c]; func[c] = Ergo12Table::kFunc[c]; agg[c] = Ergo12Table::kAgg[c]; }
     return evrep_mdes(plan, events, offsets, workspace, 12, win, func, agg, scale, out_dtype, out, stream);
 }
 
