@@ -28,7 +28,8 @@ class Plan(ctypes.Structure):
         ("max_events_per_window", ctypes.c_int64),
         ("chunk", ctypes.c_int32), ("nblk", ctypes.c_int32),
         ("nchunk", ctypes.c_int32), ("reserved", ctypes.c_int32),
-        ("off_meta", ctypes.c_size_t), ("off_table", ctypes.c_size_t), ("off_rowoff", ctypes.c_size_t),
+        ("off_meta", ctypes.c_size_t), ("off_table", ctypes.c_size_t), ("off_stats", ctypes.c_size_t),
+        ("off_rowoff", ctypes.c_size_t),
         ("off_chunkoff", ctypes.c_size_t),
         ("off_sorted1", ctypes.c_size_t), ("off_sorted2", ctypes.c_size_t), ("off_cuts", ctypes.c_size_t),
         ("off_scratch", ctypes.c_size_t),

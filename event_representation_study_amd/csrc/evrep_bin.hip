@@ -14,18 +14,6 @@
 
 namespace evrep {
 
-__global__ void k_init_meta(WindowMeta *meta, int B) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    WindowMeta m;
-    m.tmin = INT32_MAX; m.tmax = INT32_MIN;
-    m.xmin = INT32_MAX; m.xmax = INT32_MIN;
-    m.ymin = INT32_MAX; m.ymax = INT32_MIN;
-    m.neg_flags = 0; m.oob_flags = 0; m.status = 0; m.n_valid = 0;
-    for (int i = 0; i < 6; ++i) m.pad[i] = 0;
-    meta[b] = m;
-}
-
 __device__ inline int wave_min(int v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
@@ -47,83 +35,144 @@ __device__ inline int wave_sum(int v) {
     return v;
 }
 
-// grid (nblk, B), 256 threads, dynamic LDS = H * 4 bytes.
+// Per-(window, block) partial statistics; reduced into WindowMeta by k_row_scan (no global atomics).
+struct BlockStats {
+    int32_t tmin, tmax, xmin, xmax, ymin, ymax;
+    uint32_t neg_flags, oob_flags, status;
+    int32_t n_valid;
+    int32_t pad[2];
+};
+static_assert(sizeof(BlockStats) == 48, "BlockStats");
+
+__device__ inline void stats_identity(BlockStats &s) {
+    s.tmin = INT32_MAX; s.tmax = INT32_MIN; s.xmin = INT32_MAX; s.xmax = INT32_MIN; s.ymin = INT32_MAX; s.ymax = INT32_MIN;
+    s.neg_flags = 0; s.oob_flags = 0; s.status = 0; s.n_valid = 0; s.pad[0] = 0; s.pad[1] = 0;
+}
+__device__ inline void stats_merge(BlockStats &a, const BlockStats &b) {
+    a.tmin = min(a.tmin, b.tmin); a.tmax = max(a.tmax, b.tmax);
+    a.xmin = min(a.xmin, b.xmin); a.xmax = max(a.xmax, b.xmax);
+    a.ymin = min(a.ymin, b.ymin); a.ymax = max(a.ymax, b.ymax);
+    a.neg_flags |= b.neg_flags; a.oob_flags |= b.oob_flags; a.status |= b.status; a.n_valid += b.n_valid;
+}
+__device__ inline void stats_wave_reduce(BlockStats &s) {
+    s.tmin = wave_min(s.tmin); s.tmax = wave_max(s.tmax);
+    s.xmin = wave_min(s.xmin); s.xmax = wave_max(s.xmax);
+    s.ymin = wave_min(s.ymin); s.ymax = wave_max(s.ymax);
+    s.neg_flags = wave_or(s.neg_flags); s.oob_flags = wave_or(s.oob_flags); s.status = wave_or(s.status);
+    s.n_valid = wave_sum(s.n_valid);
+}
+
+constexpr int kRegBatch = 8;  // records a lane keeps in registers at a time
+
+// XCD-aware decode of a 1-D grid into (window, block): workgroup id i runs on XCD i % 8 (observed
+// dispatch order), so all blocks of window b are given ids congruent to b mod 8.  A window's
+// scattered 16-byte record writes then meet in ONE XCD's L2 and leave it as full lines, and the
+// events the histogram pass pulled through that L2 are re-read there by the scatter pass.
+// Grid size = 8 * ceil(B/8) * nblk; placement only affects speed, never results.
+__device__ inline bool decode_window_block(int B, int nblk, int &b, int &blk) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, s = id >> 3;
+    b = (s / nblk) * 8 + xcd;
+    blk = s % nblk;
+    return b < B;
+}
+
+// grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = H * 4 bytes.
 __global__ __launch_bounds__(kThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
-                                                      int H, int W, int chunk, int nblk,
-                                                      uint32_t *__restrict__ table, WindowMeta *__restrict__ meta) {
+                                                      int B, int H, int W, int chunk, int nblk,
+                                                      uint32_t *__restrict__ table, BlockStats *__restrict__ stats) {
     extern __shared__ uint32_t hist[];
-    const int b = blockIdx.y, blk = blockIdx.x;
+    __shared__ BlockStats wstats[kWaves];
+    int b, blk;
+    if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
     const int64_t lo = (int64_t)blk * chunk;
-    if (lo >= n) {
-        if (blk == 0 && threadIdx.x == 0) atomicOr(&meta[b].status, EVREP_ST_EMPTY);
-        return;
-    }
+    if (lo >= n) return;  // k_row_scan only reads the blocks a window really has
     for (int i = threadIdx.x; i < H; i += kThreads) hist[i] = 0;
     __syncthreads();
     const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
     const MdesWindows mw = mdes_windows(n);
     const int64_t HW = (int64_t)H * W;
-    int tmin = INT32_MAX, tmax = INT32_MIN, xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
-    uint32_t negf = 0, oobf = 0, st = 0;
-    int nvalid = 0;
-    for (int64_t r = lo + threadIdx.x; r < hi; r += kThreads) {
-        const int4 e = ev[beg + r];
-        const int64_t key = (int64_t)e.x + (int64_t)e.y * W;
-        const uint32_t memb = mdes_membership(mw, (int32_t)r);
-        if (e.w == -1) negf |= memb;
-        if (key >= 0 && key < HW) {
-            atomicAdd(&hist[(uint32_t)key / (uint32_t)W], 1u);
-            ++nvalid;
-        } else {
-            st |= EVREP_ST_OOB;
-            const int cls = e.w == 1 ? 1 : (e.w == -1 ? 2 : (e.w == 0 ? 3 : 0));
-            oobf |= memb | (cls ? (memb << (7 * cls)) : 0u);
+    BlockStats st;
+    stats_identity(st);
+    for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)kRegBatch * kThreads) {
+        int4 e[kRegBatch];
+        int tprev[kRegBatch];
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {  // all loads of the batch in flight together
+            const int64_t r = r0 + (int64_t)i * kThreads + threadIdx.x;
+            e[i] = make_int4(0, 0, 0, 0);
+            tprev[i] = INT32_MIN;
+            if (r < hi) {
+                e[i] = ev[beg + r];
+                if (r > 0) tprev[i] = ev[beg + r - 1].z;
+            }
         }
-        if (r > 0 && ev[beg + r - 1].z > e.z) st |= EVREP_ST_UNSORTED;
-        tmin = min(tmin, e.z); tmax = max(tmax, e.z);
-        xmin = min(xmin, e.x); xmax = max(xmax, e.x);
-        ymin = min(ymin, e.y); ymax = max(ymax, e.y);
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {
+            const int64_t r = r0 + (int64_t)i * kThreads + threadIdx.x;
+            if (r < hi) {
+                const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+                const uint32_t memb = mdes_membership(mw, (int32_t)r);
+                if (e[i].w == -1) st.neg_flags |= memb;
+                if (key >= 0 && key < HW) {
+                    atomicAdd(&hist[(uint32_t)key / (uint32_t)W], 1u);
+                    ++st.n_valid;
+                } else {
+                    st.status |= EVREP_ST_OOB;
+                    const int cls = e[i].w == 1 ? 1 : (e[i].w == -1 ? 2 : (e[i].w == 0 ? 3 : 0));
+                    st.oob_flags |= memb | (cls ? (memb << (7 * cls)) : 0u);
+                }
+                if (tprev[i] > e[i].z) st.status |= EVREP_ST_UNSORTED;
+                st.tmin = min(st.tmin, e[i].z); st.tmax = max(st.tmax, e[i].z);
+                st.xmin = min(st.xmin, e[i].x); st.xmax = max(st.xmax, e[i].x);
+                st.ymin = min(st.ymin, e[i].y); st.ymax = max(st.ymax, e[i].y);
+            }
+        }
     }
-    tmin = wave_min(tmin); tmax = wave_max(tmax);
-    xmin = wave_min(xmin); xmax = wave_max(xmax);
-    ymin = wave_min(ymin); ymax = wave_max(ymax);
-    negf = wave_or(negf); oobf = wave_or(oobf); st = wave_or(st);
-    nvalid = wave_sum(nvalid);
-    if ((threadIdx.x & 63) == 0) {
-        WindowMeta *m = meta + b;
-        atomicMin(&m->tmin, tmin); atomicMax(&m->tmax, tmax);
-        atomicMin(&m->xmin, xmin); atomicMax(&m->xmax, xmax);
-        atomicMin(&m->ymin, ymin); atomicMax(&m->ymax, ymax);
-        if (negf) atomicOr(&m->neg_flags, negf);
-        if (oobf) atomicOr(&m->oob_flags, oobf);
-        if (st) atomicOr(&m->status, st);
-        if (nvalid) atomicAdd(&m->n_valid, nvalid);
-    }
+    stats_wave_reduce(st);
+    if ((threadIdx.x & 63) == 0) wstats[threadIdx.x >> 6] = st;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        BlockStats t = wstats[0];
+        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        stats[(size_t)b * nblk + blk] = t;
+    }
     uint32_t *dst = table + ((size_t)b * nblk + blk) * H;
     for (int i = threadIdx.x; i < H; i += kThreads) dst[i] = hist[i];
 }
 
 // grid (B), 256 threads, dynamic LDS = (H + 8) * 4 bytes.
-// table[b][blk][row] -> exclusive prefix over blk; row_off[b][row] = global start of the row.
+// table[b][blk][row] -> exclusive prefix over blk; row_off[b][row] = global start of the row;
+// meta[b] = reduction of the window's block statistics.
 __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, uint32_t *__restrict__ row_off,
-                                                      WindowMeta *__restrict__ meta) {
+                                                      const BlockStats *__restrict__ stats, WindowMeta *__restrict__ meta) {
     extern __shared__ uint32_t rowtot[];
+    __shared__ BlockStats wstats[kWaves];
     uint32_t *tmp = rowtot + H;
     const int b = blockIdx.x;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
     const int nb = (int)((n + chunk - 1) / chunk);
+    // window statistics
+    BlockStats st;
+    stats_identity(st);
+    for (int blk = threadIdx.x; blk < nb; blk += kThreads) stats_merge(st, stats[(size_t)b * nblk + blk]);
+    stats_wave_reduce(st);
+    if ((threadIdx.x & 63) == 0) wstats[threadIdx.x >> 6] = st;
+    // exclusive prefix over the window's blocks, row by row (batched so the loads overlap)
     for (int r = threadIdx.x; r < H; r += kThreads) {
         uint32_t run = 0;
-        for (int blk = 0; blk < nb; ++blk) {
-            const size_t idx = ((size_t)b * nblk + blk) * H + r;
-            const uint32_t v = table[idx];
-            table[idx] = run;
-            run += v;
+        for (int b0 = 0; b0 < nb; b0 += kRegBatch) {
+            uint32_t v[kRegBatch];
+#pragma unroll
+            for (int i = 0; i < kRegBatch; ++i)
+                v[i] = (b0 + i < nb) ? table[((size_t)b * nblk + b0 + i) * H + r] : 0u;
+#pragma unroll
+            for (int i = 0; i < kRegBatch; ++i)
+                if (b0 + i < nb) { table[((size_t)b * nblk + b0 + i) * H + r] = run; run += v[i]; }
         }
         rowtot[r] = run;
     }
@@ -141,17 +190,28 @@ __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict
     for (int r = threadIdx.x; r < H; r += kThreads) ro[r] = (uint32_t)beg + rowtot[r];
     if (threadIdx.x == 0) {
         ro[H] = (uint32_t)beg + total;
-        if (n > 0 && meta[b].tmin == meta[b].tmax) atomicOr(&meta[b].status, EVREP_ST_FLAT_TIME);
+        BlockStats t = wstats[0];
+        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        WindowMeta m;
+        m.tmin = t.tmin; m.tmax = t.tmax; m.xmin = t.xmin; m.xmax = t.xmax; m.ymin = t.ymin; m.ymax = t.ymax;
+        m.neg_flags = t.neg_flags; m.oob_flags = t.oob_flags; m.status = t.status; m.n_valid = t.n_valid;
+        if (n <= 0) m.status |= EVREP_ST_EMPTY;
+        else if (t.tmin == t.tmax) m.status |= EVREP_ST_FLAT_TIME;
+        for (int i = 0; i < 6; ++i) m.pad[i] = 0;
+        meta[b] = m;
     }
 }
 
-// grid (nblk, B), 256 threads, dynamic LDS = 4 * H * 4 bytes.  Stable placement by sensor row.
+// grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = 4 * H * 4 bytes.  Stable placement by sensor row.
+// Each wave owns a contiguous quarter of the block's events and keeps them in registers between
+// the counting and the placement phase (one HBM read of the events for both).
 __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
-                                                         int H, int W, int chunk, int nblk,
+                                                         int B, int H, int W, int chunk, int nblk,
                                                          const uint32_t *__restrict__ table,
                                                          const uint32_t *__restrict__ row_off, Rec *__restrict__ sorted1) {
     extern __shared__ uint32_t cnt[];  // [kWaves][H]
-    const int b = blockIdx.y, blk = blockIdx.x;
+    int b, blk;
+    if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
     const int64_t lo = (int64_t)blk * chunk;
@@ -161,13 +221,25 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wlo = lo + nloc * wave / kWaves, whi = lo + nloc * (wave + 1) / kWaves;
     const int64_t HW = (int64_t)H * W;
+    constexpr int kSuper = kRegBatch * kWave;  // 512 events per register-resident super batch
+    const int nsuper = (int)((whi - wlo + kSuper - 1) / kSuper);
     for (int i = threadIdx.x; i < kWaves * H; i += kThreads) cnt[i] = 0;
     __syncthreads();
     uint32_t *mycnt = cnt + wave * H;
-    for (int64_t r = wlo + lane; r < whi; r += kWave) {
-        const int4 e = ev[beg + r];
-        const int64_t key = (int64_t)e.x + (int64_t)e.y * W;
-        if (key >= 0 && key < HW) atomicAdd(&mycnt[(uint32_t)key / (uint32_t)W], 1u);
+    int4 e[kRegBatch];
+    for (int sb = 0; sb < nsuper; ++sb) {
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {
+            const int64_t r = wlo + (int64_t)sb * kSuper + i * kWave + lane;
+            e[i] = make_int4(-1, -1, 0, 0);
+            if (r < whi) e[i] = ev[beg + r];
+        }
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {
+            const int64_t r = wlo + (int64_t)sb * kSuper + i * kWave + lane;
+            const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+            if (r < whi && key >= 0 && key < HW) atomicAdd(&mycnt[(uint32_t)key / (uint32_t)W], 1u);
+        }
     }
     __syncthreads();
     for (int row = threadIdx.x; row < H; row += kThreads) {
@@ -178,23 +250,98 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
     __syncthreads();
     const int nbits = bits_for(H);
     volatile uint32_t *vcnt = mycnt;
-    for (int64_t c0 = wlo; c0 < whi; c0 += kWave) {
-        const int64_t r = c0 + lane;
-        bool valid = r < whi;
-        int4 e = make_int4(0, 0, 0, 0);
-        if (valid) e = ev[beg + r];
-        const int64_t key = (int64_t)e.x + (int64_t)e.y * W;
-        valid = valid && key >= 0 && key < HW;
-        const uint32_t row = valid ? (uint32_t)key / (uint32_t)W : 0u;
+    for (int sb = 0; sb < nsuper; ++sb) {
+        if (nsuper > 1) {  // otherwise the registers still hold the only super batch
+#pragma unroll
+            for (int i = 0; i < kRegBatch; ++i) {
+                const int64_t r = wlo + (int64_t)sb * kSuper + i * kWave + lane;
+                e[i] = make_int4(-1, -1, 0, 0);
+                if (r < whi) e[i] = ev[beg + r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {
+            const int64_t r0 = wlo + (int64_t)sb * kSuper + i * kWave;
+            if (r0 >= whi) break;  // uniform
+            const int64_t r = r0 + lane;
+            const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+            const bool valid = r < whi && key >= 0 && key < HW;
+            const uint32_t row = valid ? (uint32_t)key / (uint32_t)W : 0u;
+            uint32_t rk; bool last;
+            wave_match(row, nbits, valid, lane, rk, last);
+            uint32_t pos = 0;
+            if (valid) {
+                pos = vcnt[row] + rk;
+                sorted1[pos] = make_int4((int)key, (int)r, e[i].z, e[i].w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && last) vcnt[row] = pos + 1;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+constexpr uint32_t kSmallRow = 4 * kWave;  // rows up to 256 records are column-sorted by a single wave
+
+// grid (H, B), 64 threads, dynamic LDS = W * 4 bytes.  Column sort of a short row by one wave:
+// records stay in registers, no block barrier.  Longer rows are left to k_col_sort.
+__global__ __launch_bounds__(kWave) void k_col_sort_small(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
+                                                         int H, int W, int nchunk, Rec *__restrict__ sorted2,
+                                                         uint32_t *__restrict__ chunk_off) {
+    extern __shared__ uint32_t cnt[];  // [W]
+    const int b = blockIdx.y, row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t rs = row_off[(size_t)b * (H + 1) + row], re = row_off[(size_t)b * (H + 1) + row + 1];
+    const uint32_t n = re - rs;
+    uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+    if (n == 0) {
+        for (int c = lane; c <= nchunk; c += kWave) co[c] = rs;
+        return;
+    }
+    if (n > kSmallRow) return;
+    const int rowbase = row * W;
+    Rec e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e[i] = make_int4(0, 0, 0, 0);
+        if (i * kWave + lane < (int)n) e[i] = sorted1[rs + i * kWave + lane];
+    }
+    for (int i = lane; i < W; i += kWave) cnt[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i * kWave + lane < (int)n) atomicAdd(&cnt[e[i].x - rowbase], 1u);
+    __syncthreads();
+    // exclusive scan over the W column counters: `per` consecutive columns per lane
+    const int per = (W + kWave - 1) / kWave;
+    const int c0 = lane * per;
+    uint32_t local = 0;
+    for (int k = 0; k < per; ++k) if (c0 + k < W) local += cnt[c0 + k];
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    uint32_t run = incl - local;
+    for (int k = 0; k < per; ++k)
+        if (c0 + k < W) { const uint32_t t = cnt[c0 + k]; cnt[c0 + k] = run; run += t; }
+    __syncthreads();
+    for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rs + cnt[c * kChunkPx] : re;
+    __syncthreads();
+    const int nbits = bits_for(W);
+    volatile uint32_t *vcnt = cnt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i * kWave >= (int)n) break;  // uniform
+        const bool valid = i * kWave + lane < (int)n;
+        const uint32_t col = valid ? (uint32_t)(e[i].x - rowbase) : 0u;
         uint32_t rk; bool last;
-        wave_match(row, nbits, valid, lane, rk, last);
+        wave_match(col, nbits, valid, lane, rk, last);
         uint32_t pos = 0;
         if (valid) {
-            pos = vcnt[row] + rk;
-            sorted1[pos] = make_int4((int)key, (int)r, e.z, e.w);
+            pos = vcnt[col] + rk;
+            sorted2[rs + pos] = e[i];
         }
         __builtin_amdgcn_wave_barrier();
-        if (valid && last) vcnt[row] = pos + 1;
+        if (valid && last) vcnt[col] = pos + 1;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -212,10 +359,7 @@ __global__ __launch_bounds__(kThreads) void k_col_sort(const Rec *__restrict__ s
     const uint32_t n = re - rs;
     // chunk_off[b][row][c] = global index of the first record whose column is >= c * kChunkPx
     uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-    if (n == 0) {
-        for (int c = threadIdx.x; c <= nchunk; c += kThreads) co[c] = rs;
-        return;
-    }
+    if (n <= kSmallRow) return;  // empty and short rows belong to k_col_sort_small
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wlo = rs + (uint32_t)((uint64_t)n * wave / kWaves), whi = rs + (uint32_t)((uint64_t)n * (wave + 1) / kWaves);
     const int rowbase = row * W;

@@ -54,6 +54,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     size_t o = 0;
     plan->off_meta = o;    o += up256((size_t)B * sizeof(WindowMeta));
     plan->off_table = o;   o += up256((size_t)B * nblk * H * sizeof(uint32_t));
+    plan->off_stats = o;   o += up256((size_t)B * nblk * sizeof(BlockStats));
     plan->off_rowoff = o;  o += up256((size_t)B * (H + 1) * sizeof(uint32_t));
     plan->off_chunkoff = o; o += up256((size_t)B * H * (plan->nchunk + 1) * sizeof(uint32_t));
     plan->off_sorted1 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
@@ -88,17 +89,22 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     uint32_t *row_off = WS(uint32_t, off_rowoff);
     Rec *s1 = WS(Rec, off_sorted1);
     Rec *s2 = WS(Rec, off_sorted2);
-    k_init_meta<<<(B + 63) / 64, 64, 0, stream>>>(meta, B);
-    LAUNCH_CHECK("k_init_meta");
-    k_row_hist<<<dim3(nblk, B), kThreads, (size_t)H * 4, stream>>>(ev, offsets, H, W, chunk, nblk, table, meta);
+    BlockStats *stats = WS(BlockStats, off_stats);
+    const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
+    k_row_hist<<<xgrid, kThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
-    k_row_scan<<<B, kThreads, (size_t)(H + 8) * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, meta);
+    k_row_scan<<<B, kThreads, (size_t)(H + 8) * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
     LAUNCH_CHECK("k_row_scan");
-    k_row_scatter<<<dim3(nblk, B), kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, H, W, chunk, nblk, table, row_off, s1);
+    k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
     LAUNCH_CHECK("k_row_scatter");
-    k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
-                                                                                WS(uint32_t, off_chunkoff));
-    LAUNCH_CHECK("k_col_sort");
+    k_col_sort_small<<<dim3(H, B), kWave, (size_t)W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
+                                                                   WS(uint32_t, off_chunkoff));
+    LAUNCH_CHECK("k_col_sort_small");
+    if (plan->max_events_per_window > (int64_t)kSmallRow) {  // a row can only be long if a window is
+        k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
+                                                                                    WS(uint32_t, off_chunkoff));
+        LAUNCH_CHECK("k_col_sort");
+    }
     return EVREP_OK;
 }
 

@@ -61,7 +61,7 @@ typedef struct evrep_plan {
     int64_t max_events_per_window; /* upper bound used to size grids; no host sync needed */
     int32_t chunk, nblk;           /* row-partition geometry (derived) */
     int32_t nchunk, reserved;      /* 128-pixel column chunks per row (derived) */
-    size_t off_meta, off_table, off_rowoff, off_chunkoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
+    size_t off_meta, off_table, off_stats, off_rowoff, off_chunkoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
     size_t workspace_bytes;
 } evrep_plan;
 
