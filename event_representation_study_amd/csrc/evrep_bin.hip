@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict
                                                       const BlockStats *__restrict__ stats, WindowMeta *__restrict__ meta) {
     extern __shared__ uint32_t rowtot[];
     __shared__ BlockStats wstats[kWaves];
-    uint32_t *tmp = rowtot + H;
+    __shared__ uint32_t tmp[8];
     const int b = blockIdx.x;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(kWave) void k_col_sort_small(const Rec *__restrict_
 __global__ __launch_bounds__(kThreads) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
                                                       int H, int W, int nchunk, Rec *__restrict__ sorted2,
                                                       uint32_t *__restrict__ chunk_off) {
-    extern __shared__ uint32_t cnt[];  // [kWaves][W] + tmp[8]
-    uint32_t *tmp = cnt + kWaves * W;
+    extern __shared__ uint32_t cnt[];  // [kWaves][W]
+    __shared__ uint32_t tmp[8];
     const int b = blockIdx.y, row = blockIdx.x;
     const uint32_t rs = row_off[(size_t)b * (H + 1) + row], re = row_off[(size_t)b * (H + 1) + row + 1];
     const uint32_t n = re - rs;

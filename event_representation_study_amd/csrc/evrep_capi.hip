@@ -93,7 +93,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
     k_row_hist<<<xgrid, kThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
-    k_row_scan<<<B, kThreads, (size_t)(H + 8) * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
+    k_row_scan<<<B, kThreads, (size_t)H * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
     LAUNCH_CHECK("k_row_scan");
     k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
     LAUNCH_CHECK("k_row_scatter");
@@ -101,7 +101,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
                                                                    WS(uint32_t, off_chunkoff));
     LAUNCH_CHECK("k_col_sort_small");
     if (plan->max_events_per_window > (int64_t)kSmallRow) {  // a row can only be long if a window is
-        k_col_sort<<<dim3(H, B), kThreads, (size_t)(kWaves * W + 8) * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
+        k_col_sort<<<dim3(H, B), kThreads, (size_t)kWaves * W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
                                                                                     WS(uint32_t, off_chunkoff));
         LAUNCH_CHECK("k_col_sort");
     }

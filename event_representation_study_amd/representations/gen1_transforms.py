@@ -1,0 +1,83 @@
+"""``get_item_transform`` -- drop-in for representations/gen1_transforms.py:12-89 of the reference.
+
+Same contract: the representation is chosen by substring tests on ``representation_name`` (the
+``str()`` of whatever the caller keeps in its name->class table), hyper-parameters are fixed at the
+dispatch site (12 bins / 12 stack levels / k = 6 / tau = 50000 / 6 slices), three branches rewrite
+the caller's ``["p"]`` field in place, and the result is scaled by 255.  Here every in-repo branch is
+one fused launch sequence on the GPU (binning pass + builder, the x255 folded into the kernel).
+"""
+import numpy as np
+
+from ._common import raise_for_status, single_batch
+
+STACK_LEVELS = 12      # gen1_transforms.py:35
+VOXEL_BINS = 12        # :22
+TORE_K = 6             # :52
+TS_TAU = 50000         # :76
+TS_SLICES = 6          # :81
+SCALE = 255
+
+
+def _third_party(events, transform, height, width, **kw):
+    # tonic-style transforms are classes taking sensor_size=(W, H, 2); ours live in tonic_compat
+    return transform((width, height, 2), **kw)(events)
+
+
+def _voxel_grid(events, transform, height, width, num_events):
+    grid = _third_party(events, transform, height, width, n_time_bins=VOXEL_BINS)   # (T, 1, H, W)
+    return np.moveaxis(grid[:, 0], 0, -1) * SCALE                                   # (H, W, T)
+
+
+def _optimized(events, transform, height, width, num_events):
+    batch = single_batch(events, height, width)
+    raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
+    return batch.optimized(scale=float(SCALE))[0].cpu().numpy()
+
+
+def _event_stack(events, transform, height, width, num_events):
+    batch = single_batch(events, height, width)
+    events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34)
+    raise_for_status(batch, what="EventStack")
+    return batch.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE))[0].cpu().numpy()
+
+
+def _histogram(events, transform, height, width, num_events):
+    frames = transform((width, height, 2))
+    events["p"] = (events["p"] + 1) // 2                      # (:46)
+    img = np.moveaxis(frames(events), 0, -1)
+    img *= SCALE
+    return img
+
+
+def _tore(events, transform, height, width, num_events):
+    batch = single_batch(events, height, width)
+    raise_for_status(batch, what="TORE")
+    # bounding-box frame, origin-shifted, sample time t[-1] (:61-66): frame_mode 0
+    return batch.tore(k=TORE_K, frame_mode=0, scale=float(SCALE))[0].cpu().numpy()
+
+
+def _time_surface(events, transform, height, width, num_events):
+    batch = single_batch(events, height, width)
+    events["p"] = ((events["p"] + 1) / 2).astype(np.int8)     # (:70-72)
+    raise_for_status(batch, what="ToTimesurface")
+    # the six cuts searchsorted(t_norm, 1..6) are taken on the device from the same float64 formula
+    return batch.time_surface(TS_SLICES, float(TS_TAU), premap=True, scale=float(SCALE))[0].cpu().numpy()
+
+
+# order matters: "MixedDensityEventStack" contains "EventStack" (:27 is tested before :33)
+_BRANCHES = (
+    ("ToVoxelGrid", False, _voxel_grid),
+    ("MixedDensityEventStack", False, _optimized),
+    ("EventStack", False, _event_stack),
+    ("ToImage", False, _histogram),
+    ("TORE", True, _tore),                # matched case-insensitively: the repr of events2ToreFeature
+    ("ToTimesurface", False, _time_surface),
+)
+
+
+def get_item_transform(reshaped_return_data, representation_name, transform, height, width, num_events,
+                       time_window):
+    for needle, fold_case, build in _BRANCHES:
+        if needle in (representation_name.upper() if fold_case else representation_name):
+            return build(reshaped_return_data, transform, height, width, num_events)
+    raise UnboundLocalError("local variable 'rep' referenced before assignment")   # what the reference does

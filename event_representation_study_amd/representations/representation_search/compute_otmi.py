@@ -1,0 +1,81 @@
+"""otmi / OTMI -- mirrors representation_search/compute_otmi.py:50-211 of the reference.
+
+The reference calls ``ot.gromov.sampled_gromov_wasserstein(..., max_iter=0)`` with a ``loss_fun``
+that ignores its arguments; what POT then returns as ``gw_dist_estimated`` is the mean over the
+L x L zero-padded grid of ``|Ks - Kt|`` (POT is absent here, so this last
+step is PARITY-UNPINNED).  ``OTMI.solve`` evaluates exactly that on the GPU, fused, without ever
+materialising an n x n matrix."""
+import numpy as np
+
+from ...engine import gwd_padded_l1
+
+
+class OTMI:
+    """Solver for OTMI.  Xs: source points (n, ds); Xt: target points (m, dt); h: bandwidth;
+    reg is stored and unused, as in the reference."""
+
+    def __init__(self, Xs, Xt, h, reg=0.05):
+        self.Xs = Xs
+        self.Xt = Xt
+        self.h = h
+        self.reg = reg
+        self.P = None
+
+    def solve(self):
+        n, m = len(self.Xs), len(self.Xt)
+        cost = float(gwd_padded_l1(np.asarray(self.Xs, dtype=np.float64), np.asarray(self.Xt, dtype=np.float64),
+                                   self.h).item())
+        # max_iter=0 leaves the coupling at p q^T with uniform p, q; returned as a read-only view
+        T = np.broadcast_to(np.float64(1.0 / n) * np.float64(1.0 / m), (n, m))
+        return T, cost
+
+
+def _quadrants(ev, width, height):
+    """The four sensor-frame quadrants of compute_otmi.py:97-132 (closed / half-open exactly as there)."""
+    x, y = ev[:, 0], ev[:, 1]
+    hx, hy = width / 2 - 1, height / 2 - 1
+    left, right = (x >= 0) & (x <= hx), (x > hx) & (x <= width - 1)
+    top, bottom = (y >= 0) & (y <= hy), (y > hy) & (y <= height - 1)
+    return [ev[left & top].copy(), ev[right & top].copy(), ev[left & bottom].copy(), ev[right & bottom].copy()]
+
+
+def otmi_point_clouds(events, rep, height, width, rep_size):
+    """(Xs, Xt) pairs for the three quadrants the reference scores (the most populated one is skipped)."""
+    ev = np.asarray(events.cpu() if hasattr(events, "cpu") else events).astype(np.int64)
+    quads = _quadrants(ev, width, height)
+    skip = int(np.argmax([q.shape[0] for q in quads]))           # list.index(max(...)) = first maximum
+    for q in quads[1:]:                                           # re-origin quadrants 2..4 (:140-147)
+        q[:, 0] -= q[:, 0].min()
+        q[:, 1] -= q[:, 1].min()
+    half = rep_size / 2 - 1
+    boxes = [((0, rep_size // 2 - 1), (0, half)), ((half, rep_size - 1), (0, half)),
+             ((0, half), (half, rep_size - 1)), ((half, rep_size - 1), (half, rep_size - 1))]
+    f32 = np.float32
+    pairs = []
+    for i, q in enumerate(quads):
+        if i == skip:
+            continue
+        # integer tensor / python int -> float32 in torch (:164-169)
+        xs = q[:, 0].astype(f32) / f32((width - 1) // 2)
+        ys = q[:, 1].astype(f32) / f32((height - 1) // 2)
+        t = (q[:, 2] - q[0, 2]).astype(f32) / f32(q[-1, 2] - q[0, 2])
+        p = (q[:, 3] - q[:, 3].min()).astype(f32) / f32(q[:, 3].max() - q[:, 3].min())
+        keep = (q[:, 0] < (width - 1) // 2) & (q[:, 1] < (height - 1) // 2)
+        Xs = np.stack([xs[keep], ys[keep], t[keep], p[keep]], axis=-1)
+        (x0, x1), (y0, y1) = boxes[i]
+        r = rep[int(y0): int(y1) + 1, int(x0): int(x1) + 1, :]
+        rows = np.arange(r.shape[0], dtype=np.float64)[:, None] / (r.shape[0] - 1)
+        cols = np.arange(r.shape[1], dtype=np.float64)[None, :] / (r.shape[1] - 1)
+        feat = np.concatenate((r, np.broadcast_to(rows, r.shape[:2])[..., None],
+                               np.broadcast_to(cols, r.shape[:2])[..., None]), axis=2)
+        feat = feat.reshape(-1, rep.shape[2] + 2)
+        Xt = feat[np.abs(feat[:, :-2]).sum(-1) > 0]
+        pairs.append((Xs, Xt))
+    return pairs
+
+
+def otmi(events, rep, height, width, rep_size):
+    """Mean GWD of the three scored quadrants (compute_otmi.py:96-211)."""
+    costs = [OTMI(Xs.copy(), Xt.copy(), h=0.7, reg=0.05).solve()[1]
+             for Xs, Xt in otmi_point_clouds(events, rep, height, width, rep_size)]
+    return np.mean(costs)

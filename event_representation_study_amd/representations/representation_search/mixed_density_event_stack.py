@@ -1,4 +1,6 @@
 """MixedDensityEventStack -- mirrors representation_search/mixed_density_event_stack.py:8-151."""
+import numpy as np
+
 from .._common import raise_for_status, single_batch
 
 
@@ -20,7 +22,10 @@ class MixedDensityEventStack(object):
         batch = single_batch(event_sequence, self.height, self.width)
         raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
         from ... import _lib
-        w = [v if isinstance(v, int) and 0 <= v <= 6 else None for v in list(windows)[: self.stack_size]]
+        def window(v):      # anything that cannot index the 7-window list fails the channel (-> zeros)
+            ok = isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -7 <= int(v) <= 6
+            return (int(v) % 7) if ok else None
+        w = [window(v) for v in list(windows)[: self.stack_size]]
         f = [v if v in _lib.FUNCS else None for v in list(funcs)[: self.stack_size]]
         a = [v if v in _lib.AGGS else None for v in list(aggs)[: self.stack_size]]
         return batch.mdes(w, f, a, scale=1.0)[0].cpu().numpy()

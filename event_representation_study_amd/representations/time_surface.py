@@ -23,22 +23,22 @@ class ToTimesurface:
     def __call__(self, events, indices):
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
         indices = [int(i) for i in np.asarray(indices).reshape(-1)]
+        out = np.zeros((len(indices), self.sensor_size[2], H, W))
         if len(indices) == 0:
-            return np.zeros((0, self.sensor_size[2], H, W))
+            return out
         ev = events_from_fields(events["x"], events["y"], events["t"], events["p"])
         batch = EventBatch.from_numpy(ev, H, W)
         raise_for_status(batch, what="ToTimesurface")
-        out = np.empty((len(indices), 2, H, W), dtype=np.float64)
-        for s0 in range(0, len(indices), 8):                       # 8 slices per launch
-            chunk = indices[s0:s0 + 8]
-            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=False, indices=chunk)
-            rep = rep[0].cpu().numpy().reshape(H, W, len(chunk), 2)  # channel c = 2*s + p
-            out[s0:s0 + len(chunk)] = rep.transpose(2, 3, 0, 1)
-            if s0 + 8 < len(indices) and not _chain_alive(chunk, ev.shape[0]):
-                out[s0 + 8:] = 0.0
+        # the reference's scan tests `index == indices[pos]` once per event: only a strictly increasing
+        # prefix of in-range indices is ever reached, every later surface stays all-zero
+        live, prev = 0, -1
+        for i in indices:
+            if not (prev < i < ev.shape[0]):
                 break
+            live, prev = live + 1, i
+        for s0 in range(0, live, 8):                                  # up to 8 surfaces per launch
+            chunk = indices[s0:min(s0 + 8, live)]
+            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=False, indices=chunk)
+            rep = rep[0].cpu().numpy().reshape(H, W, len(chunk), 2)    # channel c = 2*s + p
+            out[s0:s0 + len(chunk)] = rep.transpose(2, 3, 0, 1)
         return out
-
-
-def _chain_alive(chunk, n):
-    return all(b > a for a, b in zip(chunk, chunk[1:])) and chunk[-1] < n

@@ -1,0 +1,191 @@
+"""-m gpu: the reference's own Python names, re-hosted on the HIP path, against
+the golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, load_golden
+
+from event_representation_study_amd.synthetic import make_events, to_structured
+
+pytestmark = pytest.mark.gpu
+
+TORE_NAME = "<function events2ToreFeature at 0x7f0000000000>"
+
+
+@pytest.mark.parametrize("enc", ["pm1", "01"])
+@pytest.mark.parametrize("which", ["gen1", "gen4"])
+def test_dispatcher_golden(enc, which):
+    from event_representation_study_amd.representations import gen1_transforms, gen4_transforms
+    g = load_golden("dispatch_80x60_n5000_" + enc)
+    H, W, N = int(g["H"]), int(g["W"]), g["events"].shape[0]
+    for label, name in (("mdes", "MixedDensityEventStack"), ("event_stack", "EventStack"),
+                        ("tore", TORE_NAME), ("time_surface", "ToTimesurface")):
+        rec = to_structured(g["events"])
+        if which == "gen1":
+            rep = gen1_transforms.get_item_transform(rec, name, None, H, W, N, 50000)
+        else:
+            rep = gen4_transforms.get_item_transform(rec, name, None, H, W, N)
+        want = g["rep_" + label]
+        assert rep.shape == want.shape and rep.dtype == want.dtype, label
+        if label in ("mdes", "event_stack"):
+            assert_bit_equal(rep, want, label)
+        else:
+            # north_star budget: 1e-5 relative.  TORE = log(dt+1) - log(151) in float32 cancels near dt ~ 150,
+            # which turns a 1-ulp logf difference into ~6e-6 relative; the time surface agrees to 1e-12.
+            np.testing.assert_allclose(rep, want, rtol=1e-5 if label == "tore" else 1e-12, atol=0)
+        assert np.array_equal(rec["p"], g["p_after_" + label]), "in-place rewrite of ['p'] (%s)" % label
+
+
+def test_dispatcher_name_matching():
+    from event_representation_study_amd.representations import gen1_transforms
+    from event_representation_study_amd.representations.tonic_compat import ToImage, ToVoxelGrid
+    from event_representation_study_amd.representations.event_stack import EventStack
+    from event_representation_study_amd.representations.time_surface import ToTimesurface
+    from event_representation_study_amd.representations.tore import events2ToreFeature
+    from event_representation_study_amd.representations.representation_search.mixed_density_event_stack import \
+        MixedDensityEventStack
+    H, W, N = 24, 32, 500
+    shapes = {}
+    for cls in (ToVoxelGrid, MixedDensityEventStack, EventStack, ToImage, events2ToreFeature, ToTimesurface):
+        rec = to_structured(make_events(N, W, H, seed=3))
+        rep = gen1_transforms.get_item_transform(rec, str(cls), cls, H, W, N, 50000)
+        shapes[cls.__name__] = rep.shape
+    assert shapes["ToVoxelGrid"] == (H, W, 12) and shapes["ToImage"] == (H, W, 2)
+    assert shapes["MixedDensityEventStack"] == shapes["EventStack"] == shapes["ToTimesurface"] == (H, W, 12)
+    assert shapes["events2ToreFeature"][2] == 12
+    with pytest.raises(UnboundLocalError):
+        gen1_transforms.get_item_transform(rec, "NoSuchRepresentation", None, H, W, N, 50000)
+
+
+def test_event_stack_class():
+    from event_representation_study_amd.representations.event_stack import EventStack
+    g = load_golden("s_80x60_n5000_pm1")
+    H, W = int(g["H"]), int(g["W"])
+    rec = to_structured(g["events"])
+    rec["p"] = (rec["p"] + 1) // 2
+    es = EventStack(12, rec.shape[0], H, W)
+    post = es.post_stack(es.pre_stack(rec, rec[-1]["t"]))
+    assert post.shape == (H, W, 1, 12) and post.dtype == np.float32
+    assert_bit_equal(np.ascontiguousarray(post.transpose(0, 1, 3, 2)[..., 0]), g["event_stack"])
+    with pytest.raises(NotImplementedError):
+        es.pre_stack(rec, rec[10]["t"])                       # a non-empty "future" half
+    bad = rec.copy()
+    bad["x"][7] = W * H
+    with pytest.raises(IndexError):
+        es.pre_stack(bad, bad[-1]["t"])
+
+
+def test_to_timesurface_class():
+    from event_representation_study_amd.representations.time_surface import ToTimesurface
+    g = load_golden("c1_304x240_n10000_pm1")
+    H, W = int(g["H"]), int(g["W"])
+    rec = to_structured(g["events"])
+    rec["p"] = ((rec["p"] + 1) / 2).astype(np.int8)
+    ts = ToTimesurface(sensor_size=(W, H, 2), surface_dimensions=None, tau=50000, decay="exp")
+    assert "ToTimesurface" in str(ToTimesurface)
+    rep = ts(rec, g["ts_idx"])
+    assert rep.shape == (6, 2, H, W) and rep.dtype == np.float64
+    got = rep.reshape((-1, H, W)).transpose(1, 2, 0)
+    np.testing.assert_allclose(got, g["time_surface"], rtol=1e-12)
+    # arbitrary indices, including a repeated one: everything from the repeat on stays zero
+    rep2 = ts(rec, [100, 2000, 2000, 5000])
+    assert rep2[:2].all() and not rep2[2:].any()
+
+
+def test_tore_function():
+    from event_representation_study_amd.representations.tore import events2ToreFeature
+    g = load_golden("s_80x60_n4097_01")
+    ev = g["events"]
+    x, y = ev[:, 0] - ev[:, 0].min() + 1, ev[:, 1] - ev[:, 1].min() + 1
+    rep = events2ToreFeature(x, y, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (y.max(), x.max()))
+    assert rep.shape == g["tore"].shape and rep.dtype == np.float32
+    np.testing.assert_allclose(rep, g["tore"], rtol=1e-6, atol=1e-6)
+    # an explicit earlier sample time
+    import oracle
+    T = int(ev[3000, 2])
+    rep_t = events2ToreFeature(x, y, ev[:, 2], ev[:, 3], T, 3, (y.max(), x.max()))
+    np.testing.assert_allclose(rep_t, oracle.tore(x, y, ev[:, 2], ev[:, 3], T, 3, (y.max(), x.max())), rtol=1e-6, atol=1e-6)
+
+
+def test_optimized_and_mdes_classes():
+    from event_representation_study_amd.representations.optimized_representation import get_optimized_representation
+    from event_representation_study_amd.representations.representation_search.mixed_density_event_stack import \
+        MixedDensityEventStack
+    g = load_golden("c1_304x240_n10000_01")
+    H, W = int(g["H"]), int(g["W"])
+    rec = to_structured(g["events"])
+    assert_bit_equal(get_optimized_representation(rec, rec.shape[0], H, W), g["ergo12"])
+    a = load_golden("mdes_all_triples_40x30_n3001_pm1")
+    triples = (list(a["windows"]), [str(s) for s in a["funcs"]], [str(s) for s in a["aggs"]])
+    m = MixedDensityEventStack(len(triples[0]), 3001, int(a["H"]), int(a["W"]), triples, "SBN")
+    assert_bit_equal(m.stack(to_structured(a["events"])), a["rep"])
+    z = load_golden("mdes_none_channels_40x30_n999")
+    m = MixedDensityEventStack(4, 999, 30, 40, ([0, None, 6, None], ["count", None, "polarity", None],
+                                                  ["sum", None, "sum", None]), "SBN")
+    assert_bit_equal(m.stack(to_structured(z["events"])), z["rep"])
+    with pytest.raises(ValueError):
+        get_optimized_representation(to_structured(np.zeros((0, 4), np.int32)), 0, H, W)
+
+
+def test_compute_repr():
+    from event_representation_study_amd.representations.representation_search.gromov_wasserstein import \
+        compute_repr_from_events
+    g = load_golden("c1_304x240_n10000_01")                   # BASELINE.json configs[0]
+    assert_bit_equal(compute_repr_from_events(g["events"], int(g["W"]), int(g["H"]), bins=5), g["voxel5"])
+
+
+def test_otmi_and_OTMI():
+    import torch
+    from event_representation_study_amd.representations.representation_search.compute_otmi import OTMI, otmi
+    g = load_golden("gwd")
+    for tag in "abc":
+        T, cost = OTMI(g[tag + "_Xs"], g[tag + "_Xt"], h=0.7, reg=0.05).solve()
+        want = float(g[tag + "_cost"])
+        assert abs(cost - want) <= 1e-5 * want, (tag, cost, want)          # north_star tolerance: 1e-5 rel
+        assert T.shape == (g[tag + "_Xs"].shape[0], g[tag + "_Xt"].shape[0])
+        assert abs(float(T[0, 0]) - float(g[tag + "_T00"])) < 1e-18
+    cost = otmi(torch.from_numpy(g["otmi_events"].copy()), g["otmi_rep"], int(g["otmi_H"]), int(g["otmi_W"]),
+                int(g["otmi_S"]))
+    assert abs(cost - float(g["otmi_cost"])) <= 1e-5 * float(g["otmi_cost"])
+
+
+def test_tonic_standins_vs_numpy_restatement():
+    """ToVoxelGrid / ToImage follow tonic's published algorithms (parity unpinned: tonic is absent)."""
+    from event_representation_study_amd.representations.tonic_compat import ToImage, ToVoxelGrid
+    H, W, N, T = 30, 40, 3000, 12
+    ev = make_events(N, W, H, seed=77, polarity="01")
+    grid = ToVoxelGrid((W, H, 2), n_time_bins=T)(to_structured(ev))
+    assert grid.shape == (T, 1, H, W)
+    ref = np.zeros(T * H * W)
+    ts = T * (ev[:, 2].astype(float) - ev[0, 2]) / (ev[-1, 2] - ev[0, 2])
+    pol = np.where(ev[:, 3] == 0, -1, ev[:, 3]).astype(float)
+    tis = ts.astype(int)
+    dts = ts - tis
+    base = ev[:, 0] + ev[:, 1] * W
+    ok = tis < T
+    np.add.at(ref, base[ok] + tis[ok] * W * H, (pol * (1.0 - dts))[ok])
+    ok = (tis + 1) < T
+    np.add.at(ref, base[ok] + (tis[ok] + 1) * W * H, (pol * dts)[ok])
+    assert_bit_equal(np.ascontiguousarray(grid[:, 0]), ref.reshape(T, H, W))
+    img = ToImage((W, H, 2))(to_structured(ev))
+    want = np.zeros((2, H, W), np.int16)
+    np.add.at(want, (ev[:, 3], ev[:, 1], ev[:, 0]), 1)
+    assert img.dtype == np.int16 and np.array_equal(img, want)
+
+
+def test_api_aliases():
+    import torch
+    from event_representation_study_amd import api
+    import oracle
+    H, W = 48, 64
+    ev = make_events(4000, W, H, seed=12)
+    t = api.OptimizedRepresentation().construct(ev, H, W)
+    assert isinstance(t, torch.Tensor) and t.is_cuda and tuple(t.shape) == (H, W, 12)
+    assert_bit_equal(t.cpu().numpy(), oracle.ergo12(ev, H, W))
+    assert tuple(api.EventStack().construct(ev, H, W).shape) == (H, W, 12)
+    assert tuple(api.TimeSurface().construct(ev, H, W).shape) == (H, W, 12)
+    assert tuple(api.ToRE().construct(ev, H, W).shape) == (H, W, 12)
+    assert_bit_equal(api.VoxelGrid(5).construct(ev, H, W).cpu().numpy(), oracle.voxel(ev, H, W, 5))
+    rng = np.random.default_rng(1)
+    a, b = rng.random((200, 4)), rng.random((150, 6))
+    assert abs(api.gwd_point_clouds(a, b) - oracle.gwd(a, b)) <= 1e-5 * oracle.gwd(a, b)
