@@ -50,7 +50,17 @@ __device__ inline void tile_fill_pattern(OutT *tile, int npix, int C, const OutT
     for (int e = threadIdx.x; e < npix * C; e += kWave) tile[e] = bg[e % C];
 }
 
-// Stream `count` tile elements to global memory, 16 B per lane when the destination is aligned.
+// Ordering point between LDS phases of a ONE-WAVE workgroup.  LDS operations of a wave execute in
+// program order, so cross-lane producer/consumer phases only need the compiler to keep them in
+// order; unlike __syncthreads() nothing is drained (no s_waitcnt vmcnt(0), no s_barrier).
+__device__ inline void wave_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stream `count` tile elements to global memory, 16 B per lane (1 KiB per wave-instruction) when
+// the destination is aligned; four LDS reads are in flight before their four stores issue.
 template <typename OutT>
 __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict__ dst) {
     constexpr int V = 16 / (int)sizeof(OutT);
@@ -58,7 +68,12 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
         const int nvec = count / V;
         const float4 *s4 = reinterpret_cast<const float4 *>(tile);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int v = threadIdx.x; v < nvec; v += kWave) d4[v] = s4[v];
+        int v = threadIdx.x;
+        for (; v + 3 * kWave < nvec; v += 4 * kWave) {
+            const float4 a = s4[v], b = s4[v + kWave], c = s4[v + 2 * kWave], d = s4[v + 3 * kWave];
+            d4[v] = a; d4[v + kWave] = b; d4[v + 2 * kWave] = c; d4[v + 3 * kWave] = d;
+        }
+        for (; v < nvec; v += kWave) d4[v] = s4[v];
         for (int e = nvec * V + threadIdx.x; e < count; e += kWave) dst[e] = tile[e];
     } else {
         for (int e = threadIdx.x; e < count; e += kWave) dst[e] = tile[e];
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
 
     tile_fill_zero(wt.tile, g.npix * C);
     if (nrec == 0) {  // empty chunk: pure zero fill
-        __syncthreads();
+        wave_phase();
         tile_store(wt.tile, g.npix * C, dst);
         return;
     }
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
         }
         if (lane == 0) wt.segs[nseg] = make_uint2(0u, nrec);
     }
-    __syncthreads();
+    wave_phase();
 
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             }
         }
     }
-    __syncthreads();
+    wave_phase();
     tile_store(wt.tile, g.npix * C, dst);
 }
 
@@ -318,12 +333,12 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
     tile_fill_zero(wt.tile, g.npix * S);
     if (g.ce == g.cs) {
-        __syncthreads();
+        wave_phase();
         tile_store(wt.tile, g.npix * S, dst);
         return;
     }
     const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    __syncthreads();
+    wave_phase();
     const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
     int offk[EVREP_MAX_CHANNELS];
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
         for (int l = 0; l < EVREP_MAX_CHANNELS; ++l)
             if (l < S) mine[l] = (e.y >= offk[l]) ? v : 0.0f;
     }
-    __syncthreads();
+    wave_phase();
     tile_store(wt.tile, g.npix * S, dst);
 }
 
@@ -393,7 +408,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
         cuts[b].idx[s] = idx;
         cuts[b].tcut[s] = tc;
     }
-    __syncthreads();
+    wave_phase();
     if (s == 0) {
         bool alive = n > 0;
         for (int k = 0; k < kMaxSlices; ++k) {
@@ -429,11 +444,11 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
         if (cu.live[s]) { const double d = init - (double)cu.tcut[s]; v = exp(d / tau) * scale; }
         wt.bg[threadIdx.x] = (OutT)v;
     }
-    __syncthreads();
+    wave_phase();
     tile_fill_pattern(wt.tile, g.npix, C, wt.bg);
     int nseg = 0;
     if (g.ce > g.cs) nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    __syncthreads();
+    wave_phase();
     for (int k = threadIdx.x; k < nseg; k += kWave) {
         const uint2 sg = wt.segs[k];
         const uint32_t je = wt.segs[k + 1].y;
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
             }
         }
     }
-    __syncthreads();
+    wave_phase();
     tile_store(wt.tile, g.npix * C, dst);
 }
 
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
         const uint32_t cs = co[ch_lo], ce = co[ch_hi + 1];
         if (ce > cs) nseg = list_segments(sorted, cs, ce, row * W + sc_lo, wt.segs);
     }
-    __syncthreads();
+    wave_phase();
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
     for (int k = threadIdx.x; k < nseg; k += kWave) {
         const uint2 sg = wt.segs[k];
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
             }
         }
     }
-    __syncthreads();
+    wave_phase();
     tile_store(wt.tile, npix * C, dst);
 }
 
@@ -563,12 +578,12 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
     tile_fill_zero(wt.tile, g.npix * bins);
     if (g.ce == g.cs) {
-        __syncthreads();
+        wave_phase();
         tile_store(wt.tile, g.npix * bins, dst);
         return;
     }
     const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    __syncthreads();
+    wave_phase();
     const int64_t beg = off[g.b];
     const int64_t n_win = off[g.b + 1] - beg;
     const double t0 = (double)ev[beg].z;
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
         if (scale != 1.0)
             for (int q = 0; q < bins; ++q) mine[q] = mine[q] * scale;
     }
-    __syncthreads();
+    wave_phase();
     tile_store(wt.tile, g.npix * bins, dst);
 }
 
