@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libevrep.so")
+LIB_PATH = os.environ.get("EVREP_LIB_PATH") or os.path.join(_PKG, "libevrep.so")  # env override: A/B builds
 
 EVREP_OK, EVREP_EINVAL, EVREP_EWORKSPACE, EVREP_EHIP, EVREP_ENOTBINNED = 0, 1, 2, 3, 4
 ST_EMPTY, ST_OOB, ST_UNSORTED, ST_FLAT_TIME = 1, 2, 4, 8

@@ -174,7 +174,77 @@ constexpr int kEvCap = 128;  // records of a chunk staged in LDS; denser chunks 
 __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG; }
 __device__ inline bool is_ts_func(int f) { return f == EVREP_F_TIMESTAMP || f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_TIMESTAMP_NEG; }
 
-// grid (nchunk, H, B), 64 threads; dynamic LDS = builder_lds_bytes(C, sizeof(OutT)) + kEvCap*16.
+// One segment of an MDES chunk reduced in time order: fills vals[c] for every channel.
+template <typename OutT, typename D, typename GetRec>
+__device__ inline void mdes_reduce_segment(const MdesParams &P, int C, uint32_t jb, uint32_t je, GetRec get, int32_t tmin,
+                                           double interval, const int (&lo)[D::kMaxC], const int (&hi)[D::kMaxC],
+                                           const int (&want)[D::kMaxC], const bool (&active)[D::kMaxC], double scale,
+                                           OutT (&vals)[D::kMaxC]) {
+    double s[D::kMaxC], s2[D::kMaxC];
+    int cnt[D::kMaxC];
+#pragma unroll
+    for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
+    for (uint32_t j = jb; j < je; ++j) {
+        const Rec e = get(j);
+        const int rank = e.y, p = e.w;
+        const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
+        const double pv = (double)p;
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) {
+            if (c < C && active[c]) {
+                const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
+                const int f = D::func(P, c), a = D::agg(P, c);
+                const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
+                if (hit) {
+                    if (a == EVREP_A_MAX) {
+                        if (cnt[c] == 0 || v > s[c]) s[c] = v;
+                    } else if (is_count_func(f)) {
+                        // src = ones: sum, sum of squares and count coincide (exact small integers)
+                    } else {
+                        s[c] = s[c] + v;
+                        if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
+                    }
+                    ++cnt[c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < D::kMaxC; ++c) {
+        double r = 0.0;
+        if (c < C && active[c]) {
+            const int f = D::func(P, c), a = D::agg(P, c);
+            const double n = (double)cnt[c];
+            const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
+            if (is_count_func(f) && a != EVREP_A_MAX) {
+                // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
+                r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
+            } else if (a == EVREP_A_SUM) r = s[c];
+            else if (a == EVREP_A_MEAN) r = s[c] / d;
+            else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+            else {
+                const double mean = s[c] / d, mean2 = s2[c] / d;
+                const double mm = mean * mean;
+                r = mean2 - mm;
+            }
+        }
+        vals[c] = (OutT)(r * scale);
+    }
+}
+
+// The chunk is emitted as two half tiles of kHalfPx pixels through ONE half-size LDS tile: the
+// segments are reduced once, lanes whose pixel lies in the second half keep their C values in
+// registers while the first half tile is streamed out, then the tile is refilled.  LDS per wave
+// drops from 16.5 KB to ~9.5 KB (9 -> 16 resident waves per CU) while a wave still moves 12 KB, so
+// almost twice the store bytes are in flight per CU; the first half's stores drain while the second
+// half is staged.  Chunks with more than 64 non-empty pixels (dense data) take the two-pass branch.
+// grid (nchunk, H, B), 64 threads; dynamic LDS = mdes_lds_bytes(C, sizeof(OutT)).
+constexpr int kHalfPx = kChunkPx / 2;
+constexpr int kMdesEvCap = 64;
+__host__ __device__ inline size_t mdes_lds_bytes(int C, size_t elem) {
+    return align16((size_t)kHalfPx * C * elem) + (size_t)(kChunkPx + 1) * sizeof(uint2) + (size_t)kMdesEvCap * sizeof(Rec) + 16;
+}
+
 template <typename OutT, typename D>
 __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
                                                const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
@@ -182,31 +252,32 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
-    WaveTile<OutT> wt(smem, C);
-    Rec *evbuf = reinterpret_cast<Rec *>(smem + builder_lds_bytes(C, sizeof(OutT)));
+    OutT *tile = reinterpret_cast<OutT *>(smem);
+    uint2 *segs = reinterpret_cast<uint2 *>(smem + align16((size_t)kHalfPx * C * sizeof(OutT)));
+    Rec *evbuf = reinterpret_cast<Rec *>(smem + align16((size_t)kHalfPx * C * sizeof(OutT)) + (kChunkPx + 1) * sizeof(uint2));
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
+    const int npix0 = min(kHalfPx, g.npix), npix1 = g.npix - npix0;
 
     // issue every independent global load first: the chunk's records (one coalesced 16 B/lane
-    // load per 64 records), the window's statistics and extent
+    // load for the first 64), the window's statistics and extent
     const uint32_t nrec = g.ce - g.cs;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0), r1 = make_int4(INT32_MIN, 0, 0, 0);
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
     if (lane < (int)nrec) r0 = sorted[g.cs + lane];
-    if (lane + kWave < (int)nrec) r1 = sorted[g.cs + kWave + lane];
     const int64_t n_win = off[g.b + 1] - off[g.b];
     const WindowMeta m = meta[g.b];
 
-    tile_fill_zero(wt.tile, g.npix * C);
-    if (nrec == 0) {  // empty chunk: pure zero fill
+    tile_fill_zero(tile, npix0 * C);
+    if (nrec == 0) {  // empty chunk: pure zero fill (the zero tile is streamed twice)
         wave_phase();
-        tile_store(wt.tile, g.npix * C, dst);
+        tile_store(tile, npix0 * C, dst);
+        if (npix1 > 0) tile_store(tile, npix1 * C, dst + (size_t)kHalfPx * C);
         return;
     }
     evbuf[lane] = r0;
-    evbuf[kWave + lane] = r1;
 
-    // segment heads (runs of equal pixel id); records beyond kEvCap are walked from global memory
+    // segment heads (runs of equal pixel id); records beyond the LDS stage are read from HBM/L2
     const int key0 = g.row * W + g.c0;
     int nseg = 0;
     {
@@ -215,17 +286,17 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             const uint32_t j = j0 + lane;
             const bool valid = j < nrec;
             int key = INT32_MIN;
-            if (j0 == 0) key = r0.x; else if (j0 == kWave) key = r1.x; else if (valid) key = sorted[g.cs + j].x;
+            if (j0 == 0) key = r0.x; else if (valid) key = sorted[g.cs + j].x;
             if (!valid) key = INT32_MIN;
             int prev = __shfl_up(key, 1, 64);
             if (lane == 0) prev = carry;
             const bool head = valid && key != prev;
             const uint64_t hm = __ballot(head);
-            if (head) wt.segs[nseg + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(key - key0), j);
+            if (head) segs[nseg + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(key - key0), j);
             nseg += __popcll(hm);
             carry = __shfl(key, 63, 64);
         }
-        if (lane == 0) wt.segs[nseg] = make_uint2(0u, nrec);
+        if (lane == 0) segs[nseg] = make_uint2(0u, nrec);
     }
     wave_phase();
 
@@ -259,66 +330,56 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
         }
     }
+    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kMdesEvCap ? evbuf[j] : sorted[g.cs + j]; };
 
-    for (int k = lane; k < nseg; k += kWave) {
-        const uint2 sg = wt.segs[k];
-        const uint32_t je = wt.segs[k + 1].y;
-        double s[D::kMaxC], s2[D::kMaxC];
-        int cnt[D::kMaxC];
-#pragma unroll
-        for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
-        for (uint32_t j = sg.y; j < je; ++j) {
-            const Rec e = j < (uint32_t)kEvCap ? evbuf[j] : sorted[g.cs + j];
-            const int rank = e.y, p = e.w;
-            const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
-            const double pv = (double)p;
-#pragma unroll
-            for (int c = 0; c < D::kMaxC; ++c) {
-                if (c < C && active[c]) {
-                    const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
-                    const int f = D::func(P, c), a = D::agg(P, c);
-                    const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
-                    if (hit) {
-                        if (a == EVREP_A_MAX) {
-                            if (cnt[c] == 0 || v > s[c]) s[c] = v;
-                        } else if (is_count_func(f)) {
-                            // src = ones: sum, sum of squares and count coincide (exact small integers)
-                        } else {
-                            s[c] = s[c] + v;
-                            if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
-                        }
-                        ++cnt[c];
-                    }
-                }
-            }
+    if (nseg <= kWave) {
+        // one lane per non-empty pixel, reduced once; second-half pixels wait in registers
+        OutT vals[D::kMaxC];
+        int px = -1;
+        if (lane < nseg) {
+            const uint2 sg = segs[lane];
+            px = (int)sg.x;
+            mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[lane + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
         }
-        OutT *mine = wt.tile + (size_t)sg.x * C;
+        if (px >= 0 && px < kHalfPx) {
+            OutT *mine = tile + (size_t)px * C;
 #pragma unroll
-        for (int c = 0; c < D::kMaxC; ++c) {
-            if (c < C) {
-                double r = 0.0;
-                if (active[c]) {
-                    const int f = D::func(P, c), a = D::agg(P, c);
-                    const double n = (double)cnt[c];
-                    const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
-                    if (is_count_func(f) && a != EVREP_A_MAX) {
-                        // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
-                        r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
-                    } else if (a == EVREP_A_SUM) r = s[c];
-                    else if (a == EVREP_A_MEAN) r = s[c] / d;
-                    else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
-                    else {
-                        const double mean = s[c] / d, mean2 = s2[c] / d;
-                        const double mm = mean * mean;
-                        r = mean2 - mm;
-                    }
-                }
-                mine[c] = (OutT)(r * scale);
+            for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
+        }
+        wave_phase();
+        tile_store(tile, npix0 * C, dst);
+        if (npix1 > 0) {
+            wave_phase();
+            tile_fill_zero(tile, npix1 * C);
+            wave_phase();
+            if (px >= kHalfPx) {
+                OutT *mine = tile + (size_t)(px - kHalfPx) * C;
+#pragma unroll
+                for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
             }
+            wave_phase();
+            tile_store(tile, npix1 * C, dst + (size_t)kHalfPx * C);
+        }
+    } else {
+        // dense chunk: one pass per half tile, each segment reduced in the pass of its own half
+        for (int half = 0; half < 2; ++half) {
+            const int np = half ? npix1 : npix0;
+            if (np <= 0) break;
+            if (half) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
+            for (int k = lane; k < nseg; k += kWave) {
+                const uint2 sg = segs[k];
+                const int px = (int)sg.x - half * kHalfPx;
+                if (px < 0 || px >= kHalfPx) continue;
+                OutT vals[D::kMaxC];
+                mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[k + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
+                OutT *mine = tile + (size_t)px * C;
+#pragma unroll
+                for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
+            }
+            wave_phase();
+            tile_store(tile, np * C, dst + (size_t)half * kHalfPx * C);
         }
     }
-    wave_phase();
-    tile_store(wt.tile, g.npix * C, dst);
 }
 
 // --------------------------------------------------------------------------------------------

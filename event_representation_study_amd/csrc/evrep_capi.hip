@@ -127,7 +127,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<BUILDER_GRID, kWave, builder_lds_bytes(C, sizeof(T)) + kEvCap * sizeof(Rec), stream>>>(          \
+    k_mdes<T, DESC><<<BUILDER_GRID, kWave, mdes_lds_bytes(C, sizeof(T)), stream>>>(                                            \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
         plan->nchunk, scale, static_cast<T *>(out))
     if (out_dtype == EVREP_F64) {
