@@ -114,9 +114,26 @@ struct ChunkGeom {
 
 __device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk) {
     ChunkGeom g;
+#ifndef EVREP_XCD_MAP
+#define EVREP_XCD_MAP 1
+#endif
+#if EVREP_XCD_MAP
+    // XCD x (= linear workgroup id % 8, observed dispatch order) takes the x-th contiguous eighth of
+    // the (window, row, chunk) units, so each XCD streams one sequential region of the output
+    const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+    const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    const int per = (total + 7) >> 3;
+    int u = (lin & 7) * per + (lin >> 3);
+    if (u >= total || (lin >> 3) >= per) u = lin;
+    if (total & 7) u = lin;  // keep it a bijection when the unit count is not a multiple of 8
+    const int chunk = u % nchunk;
+    g.row = (u / nchunk) % H;
+    g.b = (u / nchunk) / H;
+#else
     const int chunk = blockIdx.x;
     g.row = blockIdx.y;
     g.b = blockIdx.z;
+#endif
     g.c0 = chunk * kChunkPx;
     g.npix = min(kChunkPx, W - g.c0);
     const uint32_t *co = chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
@@ -239,7 +256,11 @@ __device__ inline void mdes_reduce_segment(const MdesParams &P, int C, uint32_t 
 // almost twice the store bytes are in flight per CU; the first half's stores drain while the second
 // half is staged.  Chunks with more than 64 non-empty pixels (dense data) take the two-pass branch.
 // grid (nchunk, H, B), 64 threads; dynamic LDS = mdes_lds_bytes(C, sizeof(OutT)).
-constexpr int kHalfPx = kChunkPx / 2;
+#ifndef EVREP_MDES_PARTS
+#define EVREP_MDES_PARTS 2
+#endif
+constexpr int kParts = EVREP_MDES_PARTS;
+constexpr int kHalfPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kMdesEvCap = 64;
 __host__ __device__ inline size_t mdes_lds_bytes(int C, size_t elem) {
     return align16((size_t)kHalfPx * C * elem) + (size_t)(kChunkPx + 1) * sizeof(uint2) + (size_t)kMdesEvCap * sizeof(Rec) + 16;
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
-    const int npix0 = min(kHalfPx, g.npix), npix1 = g.npix - npix0;
+    const int npix0 = min(kHalfPx, g.npix);
 
     // issue every independent global load first: the chunk's records (one coalesced 16 B/lane
     // load for the first 64), the window's statistics and extent
@@ -269,10 +290,10 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
     const WindowMeta m = meta[g.b];
 
     tile_fill_zero(tile, npix0 * C);
-    if (nrec == 0) {  // empty chunk: pure zero fill (the zero tile is streamed twice)
+    if (nrec == 0) {  // empty chunk: pure zero fill (the same zero tile is streamed for every part)
         wave_phase();
-        tile_store(tile, npix0 * C, dst);
-        if (npix1 > 0) tile_store(tile, npix1 * C, dst + (size_t)kHalfPx * C);
+        for (int part = 0; part * kHalfPx < g.npix; ++part)
+            tile_store(tile, min(kHalfPx, g.npix - part * kHalfPx) * C, dst + (size_t)part * kHalfPx * C);
         return;
     }
     evbuf[lane] = r0;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
     auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kMdesEvCap ? evbuf[j] : sorted[g.cs + j]; };
 
     if (nseg <= kWave) {
-        // one lane per non-empty pixel, reduced once; second-half pixels wait in registers
+        // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
         OutT vals[D::kMaxC];
         int px = -1;
         if (lane < nseg) {
@@ -341,43 +362,35 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             px = (int)sg.x;
             mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[lane + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
         }
-        if (px >= 0 && px < kHalfPx) {
-            OutT *mine = tile + (size_t)px * C;
-#pragma unroll
-            for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
-        }
-        wave_phase();
-        tile_store(tile, npix0 * C, dst);
-        if (npix1 > 0) {
-            wave_phase();
-            tile_fill_zero(tile, npix1 * C);
-            wave_phase();
-            if (px >= kHalfPx) {
-                OutT *mine = tile + (size_t)(px - kHalfPx) * C;
+        for (int part = 0; part * kHalfPx < g.npix; ++part) {
+            const int np = min(kHalfPx, g.npix - part * kHalfPx);
+            if (part) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
+            const int q = px - part * kHalfPx;
+            if (px >= 0 && q >= 0 && q < kHalfPx) {
+                OutT *mine = tile + (size_t)q * C;
 #pragma unroll
                 for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
             }
             wave_phase();
-            tile_store(tile, npix1 * C, dst + (size_t)kHalfPx * C);
+            tile_store(tile, np * C, dst + (size_t)part * kHalfPx * C);
         }
     } else {
-        // dense chunk: one pass per half tile, each segment reduced in the pass of its own half
-        for (int half = 0; half < 2; ++half) {
-            const int np = half ? npix1 : npix0;
-            if (np <= 0) break;
-            if (half) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
+        // dense chunk: one pass per part tile, each segment reduced in the pass of its own part
+        for (int part = 0; part * kHalfPx < g.npix; ++part) {
+            const int np = min(kHalfPx, g.npix - part * kHalfPx);
+            if (part) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
             for (int k = lane; k < nseg; k += kWave) {
                 const uint2 sg = segs[k];
-                const int px = (int)sg.x - half * kHalfPx;
-                if (px < 0 || px >= kHalfPx) continue;
+                const int q = (int)sg.x - part * kHalfPx;
+                if (q < 0 || q >= kHalfPx) continue;
                 OutT vals[D::kMaxC];
                 mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[k + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
-                OutT *mine = tile + (size_t)px * C;
+                OutT *mine = tile + (size_t)q * C;
 #pragma unroll
                 for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
             }
             wave_phase();
-            tile_store(tile, np * C, dst + (size_t)half * kHalfPx * C);
+            tile_store(tile, np * C, dst + (size_t)part * kHalfPx * C);
         }
     }
 }
