@@ -216,6 +216,61 @@ class EventBatch:
         return out
 
 
+class BinBuildPipeline:
+    """Throughput path for a STREAM of batches: the binning pass of batch k+1 runs on a side HIP stream
+    while the builder of batch k runs on the caller's stream (the binning kernels are latency-bound and
+    barely touch HBM, the builders are HBM-bound, so they overlap almost for free).  Each EventBatch
+    owns its workspace, so two batches in flight = double buffering.
+
+        pipe = BinBuildPipeline(device)
+        for batch, out in work:              # e.g. alternating between two resident batches
+            pipe.submit(batch, lambda b: b.optimized(out=out))
+        pipe.drain()
+    """
+
+    def __init__(self, device=None):
+        _require_gpu()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.bin_stream = torch.cuda.Stream(device=self.device)
+        self._pending = None          # (batch, build_fn, binned_event)
+        self._built = {}              # id(batch) -> event recorded after the last build that read its workspace
+
+    def _start_bin(self, batch):
+        main = torch.cuda.current_stream(self.device)
+        done = self._built.get(id(batch))
+        with torch.cuda.stream(self.bin_stream):
+            if done is not None:
+                self.bin_stream.wait_event(done)      # the workspace is free once its previous build finished
+            else:
+                self.bin_stream.wait_stream(main)     # first use: inputs were produced on the caller's stream
+            batch.rebin()
+            ev = torch.cuda.Event()
+            ev.record(self.bin_stream)
+        return ev
+
+    def submit(self, batch, build_fn):
+        """Queue `batch`: its binning starts now on the side stream; the PREVIOUS submission is built now."""
+        ev = self._start_bin(batch)
+        self._flush()
+        self._pending = (batch, build_fn, ev)
+
+    def _flush(self):
+        if self._pending is None:
+            return None
+        batch, build_fn, ev = self._pending
+        self._pending = None
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        res = build_fn(batch)
+        done = torch.cuda.Event()
+        done.record(main)
+        self._built[id(batch)] = done
+        return res
+
+    def drain(self):
+        return self._flush()
+
+
 def gwd_padded_l1(Xs, Xt, h=0.7):
     """OTMI(Xs, Xt, h).solve()[1] on the GPU: Xs (n, ds), Xt (m, dt) array-likes -> 0-dim float64 cuda tensor."""
     _require_gpu()
