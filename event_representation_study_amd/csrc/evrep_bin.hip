@@ -14,26 +14,22 @@
 
 namespace evrep {
 
-__device__ inline int wave_min(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
+// Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, gfx9 family), result in every
+// lane via readlane(63).  No LDS traffic, no lgkmcnt waits -- ten of these run per block in k_row_hist.
+template <typename Op>
+__device__ inline int wave_reduce_dpp(int v, int identity, Op op) {
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1,3
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ inline int wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
-__device__ inline uint32_t wave_or(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ inline int wave_sum(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+__device__ inline int wave_min(int v) { return wave_reduce_dpp(v, INT32_MAX, [](int a, int b) { return min(a, b); }); }
+__device__ inline int wave_max(int v) { return wave_reduce_dpp(v, INT32_MIN, [](int a, int b) { return max(a, b); }); }
+__device__ inline uint32_t wave_or(uint32_t v) { return (uint32_t)wave_reduce_dpp((int)v, 0, [](int a, int b) { return a | b; }); }
+__device__ inline int wave_sum(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
 
 // Per-(window, block) partial statistics; reduced into WindowMeta by k_row_scan (no global atomics).
 struct BlockStats {
@@ -102,12 +98,18 @@ __global__ __launch_bounds__(kThreads) void k_row_hist(const int4 *__restrict__ 
 #pragma unroll
         for (int i = 0; i < kRegBatch; ++i) {  // all loads of the batch in flight together
             const int64_t r = r0 + (int64_t)i * kThreads + threadIdx.x;
-            e[i] = make_int4(0, 0, 0, 0);
+            e[i] = make_int4(0, 0, INT32_MAX, 0);
             tprev[i] = INT32_MIN;
             if (r < hi) {
                 e[i] = ev[beg + r];
-                if (r > 0) tprev[i] = ev[beg + r - 1].z;
+                // the predecessor's timestamp comes from the neighbouring lane; only lane 0 of a wave loads it
+                if ((threadIdx.x & 63) == 0 && r > 0) tprev[i] = ev[beg + r - 1].z;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < kRegBatch; ++i) {
+            const int up = __shfl_up(e[i].z, 1, 64);
+            if ((threadIdx.x & 63) != 0) tprev[i] = up;
         }
 #pragma unroll
         for (int i = 0; i < kRegBatch; ++i) {
@@ -281,13 +283,14 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
     }
 }
 
-constexpr uint32_t kSmallRow = 4 * kWave;  // rows up to 256 records are column-sorted by a single wave
-
-// grid (H, B), 64 threads, dynamic LDS = W * 4 bytes.  Column sort of a short row by one wave:
-// records stay in registers, no block barrier.  Longer rows are left to k_col_sort.
-__global__ __launch_bounds__(kWave) void k_col_sort_small(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
-                                                         int H, int W, int nchunk, Rec *__restrict__ sorted2,
-                                                         uint32_t *__restrict__ chunk_off) {
+// grid (H, B), 64 threads, dynamic LDS = W * 4 bytes.  Stable placement by column inside one row,
+// by ONE wave: afterwards sorted2 is ordered by (window, pixel id, rank).  Rows of up to 256 records
+// (the common case) keep their records in registers between counting and placement; longer rows
+// are walked twice.  Also emits, per row, the record offsets of every kChunkPx-pixel column chunk
+// (what one builder wavefront consumes).
+__global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
+                                                   int H, int W, int nchunk, Rec *__restrict__ sorted2,
+                                                   uint32_t *__restrict__ chunk_off) {
     extern __shared__ uint32_t cnt[];  // [W]
     const int b = blockIdx.y, row = blockIdx.x;
     const int lane = threadIdx.x;
@@ -298,19 +301,23 @@ __global__ __launch_bounds__(kWave) void k_col_sort_small(const Rec *__restrict_
         for (int c = lane; c <= nchunk; c += kWave) co[c] = rs;
         return;
     }
-    if (n > kSmallRow) return;
+    constexpr uint32_t kSuper = 4 * kWave;  // records per register-resident super batch
     const int rowbase = row * W;
+    const uint32_t nsuper = (n + kSuper - 1) / kSuper;
     Rec e[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        e[i] = make_int4(0, 0, 0, 0);
-        if (i * kWave + lane < (int)n) e[i] = sorted1[rs + i * kWave + lane];
-    }
     for (int i = lane; i < W; i += kWave) cnt[i] = 0;
     __syncthreads();
+    for (uint32_t sb = 0; sb < nsuper; ++sb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i * kWave + lane < (int)n) atomicAdd(&cnt[e[i].x - rowbase], 1u);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j = sb * kSuper + i * kWave + lane;
+            e[i] = make_int4(0, 0, 0, 0);
+            if (j < n) e[i] = sorted1[rs + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (sb * kSuper + i * kWave + lane < n) atomicAdd(&cnt[e[i].x - rowbase], 1u);
+    }
     __syncthreads();
     // exclusive scan over the W column counters: `per` consecutive columns per lane
     const int per = (W + kWave - 1) / kWave;
@@ -328,82 +335,32 @@ __global__ __launch_bounds__(kWave) void k_col_sort_small(const Rec *__restrict_
     __syncthreads();
     const int nbits = bits_for(W);
     volatile uint32_t *vcnt = cnt;
+    for (uint32_t sb = 0; sb < nsuper; ++sb) {
+        if (nsuper > 1) {  // otherwise the registers still hold the only super batch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i * kWave >= (int)n) break;  // uniform
-        const bool valid = i * kWave + lane < (int)n;
-        const uint32_t col = valid ? (uint32_t)(e[i].x - rowbase) : 0u;
-        uint32_t rk; bool last;
-        wave_match(col, nbits, valid, lane, rk, last);
-        uint32_t pos = 0;
-        if (valid) {
-            pos = vcnt[col] + rk;
-            sorted2[rs + pos] = e[i];
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t j = sb * kSuper + i * kWave + lane;
+                e[i] = make_int4(0, 0, 0, 0);
+                if (j < n) e[i] = sorted1[rs + j];
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && last) vcnt[col] = pos + 1;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// grid (H, B), 256 threads, dynamic LDS = (4 * W + 8) * 4 bytes.  Stable placement by column
-// inside one row: afterwards sorted2 is ordered by (window, pixel id, rank).  Also emits, per row,
-// the record offsets of every kChunkPx-pixel column chunk (what one builder wavefront consumes).
-__global__ __launch_bounds__(kThreads) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
-                                                      int H, int W, int nchunk, Rec *__restrict__ sorted2,
-                                                      uint32_t *__restrict__ chunk_off) {
-    extern __shared__ uint32_t cnt[];  // [kWaves][W]
-    __shared__ uint32_t tmp[8];
-    const int b = blockIdx.y, row = blockIdx.x;
-    const uint32_t rs = row_off[(size_t)b * (H + 1) + row], re = row_off[(size_t)b * (H + 1) + row + 1];
-    const uint32_t n = re - rs;
-    // chunk_off[b][row][c] = global index of the first record whose column is >= c * kChunkPx
-    uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-    if (n <= kSmallRow) return;  // empty and short rows belong to k_col_sort_small
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t wlo = rs + (uint32_t)((uint64_t)n * wave / kWaves), whi = rs + (uint32_t)((uint64_t)n * (wave + 1) / kWaves);
-    const int rowbase = row * W;
-    for (int i = threadIdx.x; i < kWaves * W; i += kThreads) cnt[i] = 0;
-    __syncthreads();
-    uint32_t *mycnt = cnt + wave * W;
-    for (uint32_t j = wlo + lane; j < whi; j += kWave) atomicAdd(&mycnt[sorted1[j].x - rowbase], 1u);
-    __syncthreads();
-    const int per = (W + kThreads - 1) / kThreads;
-    const int c0 = threadIdx.x * per;
-    uint32_t local = 0;
-    for (int k = 0; k < per; ++k)
-        if (c0 + k < W) {
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) local += cnt[w * W + c0 + k];
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j0 = sb * kSuper + i * kWave;
+            if (j0 >= n) break;  // uniform
+            const bool valid = j0 + lane < n;
+            const uint32_t col = valid ? (uint32_t)(e[i].x - rowbase) : 0u;
+            uint32_t rk; bool last;
+            wave_match(col, nbits, valid, lane, rk, last);
+            uint32_t pos = 0;
+            if (valid) {
+                pos = vcnt[col] + rk;
+                sorted2[rs + pos] = e[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && last) vcnt[col] = pos + 1;
+            __builtin_amdgcn_wave_barrier();
         }
-    uint32_t total;
-    uint32_t run = block_exclusive_scan(local, tmp, &total);
-    for (int k = 0; k < per; ++k)
-        if (c0 + k < W) {
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) { const uint32_t t = cnt[w * W + c0 + k]; cnt[w * W + c0 + k] = run; run += t; }
-        }
-    __syncthreads();
-    for (int c = threadIdx.x; c <= nchunk; c += kThreads) co[c] = (c * kChunkPx < W) ? rs + cnt[c * kChunkPx] : re;
-    __syncthreads();
-    const int nbits = bits_for(W);
-    volatile uint32_t *vcnt = mycnt;
-    for (uint32_t j0 = wlo; j0 < whi; j0 += kWave) {
-        const uint32_t j = j0 + lane;
-        const bool valid = j < whi;
-        Rec e = make_int4(0, 0, 0, 0);
-        if (valid) e = sorted1[j];
-        const uint32_t col = valid ? (uint32_t)(e.x - rowbase) : 0u;
-        uint32_t rk; bool last;
-        wave_match(col, nbits, valid, lane, rk, last);
-        uint32_t pos = 0;
-        if (valid) {
-            pos = vcnt[col] + rk;
-            sorted2[rs + pos] = e;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && last) vcnt[col] = pos + 1;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

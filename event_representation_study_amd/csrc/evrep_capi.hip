@@ -97,14 +97,8 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     LAUNCH_CHECK("k_row_scan");
     k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
     LAUNCH_CHECK("k_row_scatter");
-    k_col_sort_small<<<dim3(H, B), kWave, (size_t)W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
-                                                                   WS(uint32_t, off_chunkoff));
-    LAUNCH_CHECK("k_col_sort_small");
-    if (plan->max_events_per_window > (int64_t)kSmallRow) {  // a row can only be long if a window is
-        k_col_sort<<<dim3(H, B), kThreads, (size_t)kWaves * W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2,
-                                                                                    WS(uint32_t, off_chunkoff));
-        LAUNCH_CHECK("k_col_sort");
-    }
+    k_col_sort<<<dim3(H, B), kWave, (size_t)W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2, WS(uint32_t, off_chunkoff));
+    LAUNCH_CHECK("k_col_sort");
     return EVREP_OK;
 }
 
