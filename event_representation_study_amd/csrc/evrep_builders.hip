@@ -2,52 +2,63 @@
 // the binned stream (evrep_bin.hip), gfx950.
 //
 // Work unit = one wavefront (a 64-thread workgroup) owning a chunk of kChunkPx = 128 consecutive
-// pixels of one sensor row of one window.  The wave
-//   1. fills its private LDS tile (npix x C, output layout) with the channel background
-//      (zero, or the builder's empty-pixel value),
-//   2. lists the non-empty pixels of the chunk (segment heads of the pixel-sorted records, found
-//      with a ballot prefix) -- one lane per NON-EMPTY pixel, so VALU work scales with events,
-//   3. reduces each segment IN TIME ORDER (float64 sums round exactly as the reference's
-//      sequential scatter does) and patches the pixel's C values into the tile,
-//   4. streams the tile out with 16-byte-per-lane coalesced stores.
-// No block barrier is needed (one wave per workgroup), every output element is written exactly
-// once, and HBM traffic per window = 16 B per event (binned record) + sizeof(out) per element.
+// pixels of one sensor row of one window.  The wave (emit_chunk)
+//   1. has the chunk's first 64 records in flight (one coalesced 16 B/lane load) before anything else,
+//   2. fills its private LDS part tile (kPartPx pixels x C, output layout) with the channel
+//      background (zero, or the builder's empty-pixel value),
+//   3. lists the non-empty pixels of the chunk (segment heads of the pixel-sorted records, ballot
+//      prefix) -- one lane per NON-EMPTY pixel, so VALU work scales with events, not pixels,
+//   4. reduces each segment IN TIME ORDER (float64 sums round exactly as the reference's
+//      sequential scatter does) into the lane's registers,
+//   5. emits the chunk as kParts part tiles through the ONE part-size LDS tile: lanes whose pixel
+//      lies in a later part keep their values in registers while the earlier part is streamed
+//      out with 16-byte-per-lane coalesced stores.  Halving the tile takes the float64 12-channel
+//      builder from 9 to 16 resident waves per CU while a wave still moves 12 KB, so almost twice the
+//      store bytes are in flight per CU (202 -> 168 us for the headline kernel).
+// No block barrier exists (one wave per workgroup; wave_phase() only orders LDS phases), every
+// output element is written exactly once, and HBM traffic per window = 16 B per event (binned
+// record) + sizeof(out) per element.
+//
+// XCD awareness (chunk_unit): workgroup i runs on XCD i % 8 (observed dispatch order); XCD x is
+// given the x-th contiguous eighth of the linear (window, row, chunk) order, so every XCD streams one
+// sequential region of the output instead of interleaving 12 KiB tiles with the other seven
+// (6.9 vs 6.2 TB/s of raw HBM writes for 12 KiB one-wave tiles, tools/microbench/store_patterns5.hip).
 #include "evrep_common.h"
 
 namespace evrep {
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-constexpr int kMaxSegs = 2 * kChunkPx;  // TORE's shifted frame can straddle two sensor chunks
+#ifndef EVREP_PARTS
+#define EVREP_PARTS 2
+#endif
+#ifndef EVREP_XCD_MAP
+#define EVREP_XCD_MAP 1
+#endif
+constexpr int kParts = EVREP_PARTS;
+constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
+constexpr int kMaxSegs = 2 * kChunkPx;      // TORE's shifted frame can straddle two sensor chunks
+constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
 
-// LDS carve of one builder wave: tile, per-channel background, segment list.
+// LDS carve of one builder wave.
 template <typename OutT>
-struct WaveTile {
-    OutT *tile;    // npix * C elements, output layout (pixel-major, channel-minor)
-    OutT *bg;      // EVREP_MAX_CHANNELS background values
-    uint2 *segs;   // (pixel offset inside the chunk, first record index); entry nseg = sentinel
-    __device__ explicit WaveTile(unsigned char *smem, int C) {
-        tile = reinterpret_cast<OutT *>(smem);
-        bg = reinterpret_cast<OutT *>(smem + align16((size_t)kChunkPx * C * sizeof(OutT)));
-        segs = reinterpret_cast<uint2 *>(smem + align16((size_t)kChunkPx * C * sizeof(OutT)) + 16 * sizeof(OutT));
+struct WaveLds {
+    OutT *tile;   // kPartPx * C elements, output layout (pixel-major, channel-minor)
+    OutT *bg;     // EVREP_MAX_CHANNELS background values (the empty-pixel value of every channel)
+    uint2 *segs;  // (pixel offset inside the chunk, first record index); entry nseg = sentinel
+    Rec *evbuf;   // the chunk's first kEvStage records
+    __device__ WaveLds(unsigned char *smem, int C) {
+        size_t o = 0;
+        tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)kPartPx * C * sizeof(OutT));
+        bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
+        segs = reinterpret_cast<uint2 *>(smem + o); o += align16((size_t)(kMaxSegs + 1) * sizeof(uint2));
+        evbuf = reinterpret_cast<Rec *>(smem + o);
     }
 };
 
-__host__ __device__ inline size_t builder_lds_bytes(int C, size_t elem) {
-    return align16((size_t)kChunkPx * C * elem) + 16 * elem + (size_t)(kMaxSegs + 1) * sizeof(uint2) + 16;
-}
-
-template <typename OutT>
-__device__ inline void tile_fill_zero(OutT *tile, int count) {
-    constexpr int V = 16 / (int)sizeof(OutT);
-    float4 *t4 = reinterpret_cast<float4 *>(tile);
-    const int nvec = (count + V - 1) / V;  // the tile is padded to a multiple of 16 bytes
-    for (int v = threadIdx.x; v < nvec; v += kWave) t4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-template <typename OutT>
-__device__ inline void tile_fill_pattern(OutT *tile, int npix, int C, const OutT *bg) {
-    for (int e = threadIdx.x; e < npix * C; e += kWave) tile[e] = bg[e % C];
+__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem) {
+    return align16((size_t)kPartPx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
+           align16((size_t)(kMaxSegs + 1) * sizeof(uint2)) + (size_t)kEvStage * sizeof(Rec);
 }
 
 // Ordering point between LDS phases of a ONE-WAVE workgroup.  LDS operations of a wave execute in
@@ -57,6 +68,18 @@ __device__ inline void wave_phase() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename OutT>
+__device__ inline void tile_fill(OutT *tile, int npix, int C, const OutT *bg) {
+    if (bg) {
+        for (int e = threadIdx.x; e < npix * C; e += kWave) tile[e] = bg[e % C];
+    } else {
+        constexpr int V = 16 / (int)sizeof(OutT);
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+        const int nvec = (npix * C + V - 1) / V;  // the tile is padded to a multiple of 16 bytes
+        for (int v = threadIdx.x; v < nvec; v += kWave) t4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // Stream `count` tile elements to global memory, 16 B per lane (1 KiB per wave-instruction) when
@@ -80,31 +103,13 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
     }
 }
 
-// List the segments (runs of equal pixel id) among records [cs, ce): segs[k] = (key - key0, first
-// record).  Returns the number of segments; segs[nseg].y = ce.  Keys are sorted, so the pixel
-// offsets are increasing; offsets outside [0, npix) (TORE's straddle) are skipped by the caller.
-__device__ inline int list_segments(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, uint2 *segs) {
-    const int lane = threadIdx.x;
-    int nseg = 0;
-    int carry = INT32_MIN;
-    for (uint32_t j0 = cs; j0 < ce; j0 += kWave) {
-        const uint32_t j = j0 + lane;
-        const bool valid = j < ce;
-        const int key = valid ? sorted[j].x : INT32_MIN;
-        int prev = __shfl_up(key, 1, 64);
-        if (lane == 0) prev = carry;
-        const bool head = valid && key != prev;
-        const uint64_t hm = __ballot(head);
-        if (head) {
-            const int idx = nseg + __popcll(hm & ((1ull << lane) - 1ull));
-            if (idx < kMaxSegs) segs[idx] = make_uint2((uint32_t)(key - key0), j);
-        }
-        nseg += __popcll(hm);
-        carry = __shfl(key, 63, 64);
-    }
-    if (nseg > kMaxSegs) nseg = kMaxSegs;  // cannot happen: <= 2*kChunkPx distinct pixels are ever listed
-    if (lane == 0) segs[nseg] = make_uint2(0u, ce);
-    return nseg;
+// Linear work-unit id of this workgroup among `total` units (see the XCD note in the file header).
+__device__ inline int chunk_unit(int total) {
+    const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+#if EVREP_XCD_MAP
+    if ((total & 7) == 0) return (lin & 7) * (total >> 3) + (lin >> 3);
+#endif
+    return lin;
 }
 
 struct ChunkGeom {
@@ -112,34 +117,107 @@ struct ChunkGeom {
     uint32_t cs, ce;
 };
 
+// grid (nchunk, H, B): unit -> (window, sensor row, 128-pixel chunk) and its record range.
 __device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk) {
     ChunkGeom g;
-#ifndef EVREP_XCD_MAP
-#define EVREP_XCD_MAP 1
-#endif
-#if EVREP_XCD_MAP
-    // XCD x (= linear workgroup id % 8, observed dispatch order) takes the x-th contiguous eighth of
-    // the (window, row, chunk) units, so each XCD streams one sequential region of the output
-    const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
-    const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-    const int per = (total + 7) >> 3;
-    int u = (lin & 7) * per + (lin >> 3);
-    if (u >= total || (lin >> 3) >= per) u = lin;
-    if (total & 7) u = lin;  // keep it a bijection when the unit count is not a multiple of 8
+    const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
     const int chunk = u % nchunk;
     g.row = (u / nchunk) % H;
     g.b = (u / nchunk) / H;
-#else
-    const int chunk = blockIdx.x;
-    g.row = blockIdx.y;
-    g.b = blockIdx.z;
-#endif
     g.c0 = chunk * kChunkPx;
     g.npix = min(kChunkPx, W - g.c0);
     const uint32_t *co = chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
     g.cs = co[chunk];
     g.ce = co[chunk + 1];
     return g;
+}
+
+// The shared back end of every builder.  `reduce(jb, je, get, vals)` turns one pixel's records
+// [jb, je) (time-ordered; get(j) fetches record j of the chunk) into that pixel's C output values;
+// pixels without records keep the background.  `r0` = record `lane` of the chunk, loaded by the
+// caller before its own independent loads.  Pixel offsets outside [0, npix) (TORE's straddle)
+// are ignored.
+template <typename OutT, int CMAX, typename Reduce>
+__device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, int npix, int C,
+                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
+    const int lane = threadIdx.x;
+    const uint32_t nrec = ce - cs;
+    tile_fill(w.tile, min(kPartPx, npix), C, bg);
+    if (nrec == 0) {  // empty chunk: the same background tile is streamed for every part
+        wave_phase();
+        for (int part = 0; part * kPartPx < npix; ++part)
+            tile_store(w.tile, min(kPartPx, npix - part * kPartPx) * C, dst + (size_t)part * kPartPx * C);
+        return;
+    }
+    w.evbuf[lane] = r0;
+    // segment heads = runs of equal pixel id among the sorted records
+    int nseg = 0;
+    {
+        int carry = INT32_MIN;
+        for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            const bool valid = j < nrec;
+            int key = INT32_MIN;
+            if (j0 == 0) key = r0.x; else if (valid) key = sorted[cs + j].x;
+            if (!valid) key = INT32_MIN;
+            int prev = __shfl_up(key, 1, 64);
+            if (lane == 0) prev = carry;
+            const bool head = valid && key != prev;
+            const uint64_t hm = __ballot(head);
+            if (head) {
+                const int idx = nseg + __popcll(hm & ((1ull << lane) - 1ull));
+                if (idx < kMaxSegs) w.segs[idx] = make_uint2((uint32_t)(key - key0), j);
+            }
+            nseg += __popcll(hm);
+            carry = __shfl(key, 63, 64);
+        }
+        if (nseg > kMaxSegs) nseg = kMaxSegs;  // cannot happen: at most 2*kChunkPx distinct pixels are ever listed
+        if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
+    }
+    wave_phase();
+    const Rec *evbuf = w.evbuf;
+    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kEvStage ? evbuf[j] : sorted[cs + j]; };
+
+    if (nseg <= kWave) {
+        // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
+        OutT vals[CMAX];
+        int px = -1;
+        if (lane < nseg) {
+            const uint2 sg = w.segs[lane];
+            px = (int)sg.x;
+            if (px >= 0 && px < npix) reduce(sg.y, w.segs[lane + 1].y, get, vals); else px = -1;
+        }
+        for (int part = 0; part * kPartPx < npix; ++part) {
+            const int np = min(kPartPx, npix - part * kPartPx);
+            if (part) { wave_phase(); tile_fill(w.tile, np, C, bg); wave_phase(); }
+            const int q = px - part * kPartPx;
+            if (px >= 0 && q >= 0 && q < kPartPx) {
+                OutT *mine = w.tile + (size_t)q * C;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
+            }
+            wave_phase();
+            tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
+        }
+    } else {
+        // dense chunk: one pass per part tile, each segment reduced in the pass of its own part
+        for (int part = 0; part * kPartPx < npix; ++part) {
+            const int np = min(kPartPx, npix - part * kPartPx);
+            if (part) { wave_phase(); tile_fill(w.tile, np, C, bg); wave_phase(); }
+            for (int k = lane; k < nseg; k += kWave) {
+                const uint2 sg = w.segs[k];
+                const int q = (int)sg.x - part * kPartPx;
+                if (q < 0 || q >= np) continue;
+                OutT vals[CMAX];
+                reduce(sg.y, w.segs[k + 1].y, get, vals);
+                OutT *mine = w.tile + (size_t)q * C;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
+            }
+            wave_phase();
+            tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -155,7 +233,6 @@ struct MdesParams {
 // StaticDesc<T> reads a constexpr table, so after unrolling every per-channel branch folds away
 // and unused accumulators disappear (ERGO-12: 2 variance, 3 max, 1 mean-of-timestamps, ...).
 struct RuntimeDesc {
-    static constexpr bool kStatic = false;
     static constexpr int kMaxC = EVREP_MAX_CHANNELS;
     __device__ static inline int C(const MdesParams &P) { return P.C; }
     __device__ static inline int win(const MdesParams &P, int c) { return P.win[c]; }
@@ -177,7 +254,6 @@ struct Ergo12Table {
 
 template <typename T>
 struct StaticDesc {
-    static constexpr bool kStatic = true;
     static constexpr int kMaxC = T::kC;
     __device__ static inline int C(const MdesParams &) { return T::kC; }
     __device__ static inline int win(const MdesParams &, int c) { return T::kWin[c]; }
@@ -186,86 +262,10 @@ struct StaticDesc {
 };
 
 constexpr int kWantAny = 2;
-constexpr int kEvCap = 128;  // records of a chunk staged in LDS; denser chunks read the rest from HBM/L2
 
 __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG; }
-__device__ inline bool is_ts_func(int f) { return f == EVREP_F_TIMESTAMP || f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_TIMESTAMP_NEG; }
 
-// One segment of an MDES chunk reduced in time order: fills vals[c] for every channel.
-template <typename OutT, typename D, typename GetRec>
-__device__ inline void mdes_reduce_segment(const MdesParams &P, int C, uint32_t jb, uint32_t je, GetRec get, int32_t tmin,
-                                           double interval, const int (&lo)[D::kMaxC], const int (&hi)[D::kMaxC],
-                                           const int (&want)[D::kMaxC], const bool (&active)[D::kMaxC], double scale,
-                                           OutT (&vals)[D::kMaxC]) {
-    double s[D::kMaxC], s2[D::kMaxC];
-    int cnt[D::kMaxC];
-#pragma unroll
-    for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
-    for (uint32_t j = jb; j < je; ++j) {
-        const Rec e = get(j);
-        const int rank = e.y, p = e.w;
-        const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
-        const double pv = (double)p;
-#pragma unroll
-        for (int c = 0; c < D::kMaxC; ++c) {
-            if (c < C && active[c]) {
-                const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
-                const int f = D::func(P, c), a = D::agg(P, c);
-                const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
-                if (hit) {
-                    if (a == EVREP_A_MAX) {
-                        if (cnt[c] == 0 || v > s[c]) s[c] = v;
-                    } else if (is_count_func(f)) {
-                        // src = ones: sum, sum of squares and count coincide (exact small integers)
-                    } else {
-                        s[c] = s[c] + v;
-                        if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
-                    }
-                    ++cnt[c];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < D::kMaxC; ++c) {
-        double r = 0.0;
-        if (c < C && active[c]) {
-            const int f = D::func(P, c), a = D::agg(P, c);
-            const double n = (double)cnt[c];
-            const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
-            if (is_count_func(f) && a != EVREP_A_MAX) {
-                // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
-                r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
-            } else if (a == EVREP_A_SUM) r = s[c];
-            else if (a == EVREP_A_MEAN) r = s[c] / d;
-            else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
-            else {
-                const double mean = s[c] / d, mean2 = s2[c] / d;
-                const double mm = mean * mean;
-                r = mean2 - mm;
-            }
-        }
-        vals[c] = (OutT)(r * scale);
-    }
-}
-
-// The chunk is emitted as two half tiles of kHalfPx pixels through ONE half-size LDS tile: the
-// segments are reduced once, lanes whose pixel lies in the second half keep their C values in
-// registers while the first half tile is streamed out, then the tile is refilled.  LDS per wave
-// drops from 16.5 KB to ~9.5 KB (9 -> 16 resident waves per CU) while a wave still moves 12 KB, so
-// almost twice the store bytes are in flight per CU; the first half's stores drain while the second
-// half is staged.  Chunks with more than 64 non-empty pixels (dense data) take the two-pass branch.
-// grid (nchunk, H, B), 64 threads; dynamic LDS = mdes_lds_bytes(C, sizeof(OutT)).
-#ifndef EVREP_MDES_PARTS
-#define EVREP_MDES_PARTS 2
-#endif
-constexpr int kParts = EVREP_MDES_PARTS;
-constexpr int kHalfPx = kChunkPx / kParts;  // pixels per part tile
-constexpr int kMdesEvCap = 64;
-__host__ __device__ inline size_t mdes_lds_bytes(int C, size_t elem) {
-    return align16((size_t)kHalfPx * C * elem) + (size_t)(kChunkPx + 1) * sizeof(uint2) + (size_t)kMdesEvCap * sizeof(Rec) + 16;
-}
-
+// grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
 template <typename OutT, typename D>
 __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
                                                const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
@@ -273,53 +273,16 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
-    OutT *tile = reinterpret_cast<OutT *>(smem);
-    uint2 *segs = reinterpret_cast<uint2 *>(smem + align16((size_t)kHalfPx * C * sizeof(OutT)));
-    Rec *evbuf = reinterpret_cast<Rec *>(smem + align16((size_t)kHalfPx * C * sizeof(OutT)) + (kChunkPx + 1) * sizeof(uint2));
+    WaveLds<OutT> w(smem, C);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
-    const int npix0 = min(kHalfPx, g.npix);
 
-    // issue every independent global load first: the chunk's records (one coalesced 16 B/lane
-    // load for the first 64), the window's statistics and extent
-    const uint32_t nrec = g.ce - g.cs;
+    // every independent global load first: the chunk's records, the window's statistics and extent
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if (lane < (int)nrec) r0 = sorted[g.cs + lane];
+    if (lane < (int)(g.ce - g.cs)) r0 = sorted[g.cs + lane];
     const int64_t n_win = off[g.b + 1] - off[g.b];
     const WindowMeta m = meta[g.b];
-
-    tile_fill_zero(tile, npix0 * C);
-    if (nrec == 0) {  // empty chunk: pure zero fill (the same zero tile is streamed for every part)
-        wave_phase();
-        for (int part = 0; part * kHalfPx < g.npix; ++part)
-            tile_store(tile, min(kHalfPx, g.npix - part * kHalfPx) * C, dst + (size_t)part * kHalfPx * C);
-        return;
-    }
-    evbuf[lane] = r0;
-
-    // segment heads (runs of equal pixel id); records beyond the LDS stage are read from HBM/L2
-    const int key0 = g.row * W + g.c0;
-    int nseg = 0;
-    {
-        int carry = INT32_MIN;
-        for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            const bool valid = j < nrec;
-            int key = INT32_MIN;
-            if (j0 == 0) key = r0.x; else if (valid) key = sorted[g.cs + j].x;
-            if (!valid) key = INT32_MIN;
-            int prev = __shfl_up(key, 1, 64);
-            if (lane == 0) prev = carry;
-            const bool head = valid && key != prev;
-            const uint64_t hm = __ballot(head);
-            if (head) segs[nseg + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(key - key0), j);
-            nseg += __popcll(hm);
-            carry = __shfl(key, 63, 64);
-        }
-        if (lane == 0) segs[nseg] = make_uint2(0u, nrec);
-    }
-    wave_phase();
 
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
@@ -333,66 +296,78 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
     for (int c = 0; c < D::kMaxC; ++c) {
         lo[c] = 0; hi[c] = 0; want[c] = kWantAny; active[c] = false;
         if (c < C) {
-            const int w = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
-            bool ok = w >= 0 && w <= 6 && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
+            const int wi = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
+            bool ok = wi >= 0 && wi <= 6 && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
             int l = 0, h = 0;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) if (w == i) { l = mw.lo[i]; h = mw.hi[i]; }
+            for (int i = 0; i < 7; ++i) if (wi == i) { l = mw.lo[i]; h = mw.hi[i]; }
             int wn = kWantAny, field = 0;
             if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { wn = 1; field = 1; }
             if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
                 // rows with p == -1; if the window has none, rows with p == 0 (operations.py:59-61,78-80)
-                const bool has_neg = ok && ((m.neg_flags >> (w & 7)) & 1u);
+                const bool has_neg = ok && ((m.neg_flags >> (wi & 7)) & 1u);
                 wn = has_neg ? -1 : 0;
                 field = has_neg ? 2 : 3;
             }
             // an out-of-range index inside the selected rows raises in torch_scatter -> zero channel
-            if (ok && ((m.oob_flags >> (7 * field + (w & 7))) & 1u)) ok = false;
+            if (ok && ((m.oob_flags >> (7 * field + (wi & 7))) & 1u)) ok = false;
             lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
         }
     }
-    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kMdesEvCap ? evbuf[j] : sorted[g.cs + j]; };
 
-    if (nseg <= kWave) {
-        // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
-        OutT vals[D::kMaxC];
-        int px = -1;
-        if (lane < nseg) {
-            const uint2 sg = segs[lane];
-            px = (int)sg.x;
-            mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[lane + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
-        }
-        for (int part = 0; part * kHalfPx < g.npix; ++part) {
-            const int np = min(kHalfPx, g.npix - part * kHalfPx);
-            if (part) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
-            const int q = px - part * kHalfPx;
-            if (px >= 0 && q >= 0 && q < kHalfPx) {
-                OutT *mine = tile + (size_t)q * C;
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[D::kMaxC]) {
+        double s[D::kMaxC], s2[D::kMaxC];
+        int cnt[D::kMaxC];
 #pragma unroll
-                for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
-            }
-            wave_phase();
-            tile_store(tile, np * C, dst + (size_t)part * kHalfPx * C);
-        }
-    } else {
-        // dense chunk: one pass per part tile, each segment reduced in the pass of its own part
-        for (int part = 0; part * kHalfPx < g.npix; ++part) {
-            const int np = min(kHalfPx, g.npix - part * kHalfPx);
-            if (part) { wave_phase(); tile_fill_zero(tile, np * C); wave_phase(); }
-            for (int k = lane; k < nseg; k += kWave) {
-                const uint2 sg = segs[k];
-                const int q = (int)sg.x - part * kHalfPx;
-                if (q < 0 || q >= kHalfPx) continue;
-                OutT vals[D::kMaxC];
-                mdes_reduce_segment<OutT, D>(P, C, sg.y, segs[k + 1].y, get, tmin, interval, lo, hi, want, active, scale, vals);
-                OutT *mine = tile + (size_t)q * C;
+        for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
+        for (uint32_t j = jb; j < je; ++j) {
+            const Rec e = get(j);
+            const int rank = e.y, p = e.w;
+            const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
+            const double pv = (double)p;
 #pragma unroll
-                for (int c = 0; c < D::kMaxC; ++c) if (c < C) mine[c] = vals[c];
+            for (int c = 0; c < D::kMaxC; ++c) {
+                if (c < C && active[c]) {
+                    const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
+                    const int f = D::func(P, c), a = D::agg(P, c);
+                    const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
+                    if (hit) {
+                        if (a == EVREP_A_MAX) {
+                            if (cnt[c] == 0 || v > s[c]) s[c] = v;
+                        } else if (is_count_func(f)) {
+                            // src = ones: sum, sum of squares and count coincide (exact small integers)
+                        } else {
+                            s[c] = s[c] + v;
+                            if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
+                        }
+                        ++cnt[c];
+                    }
+                }
             }
-            wave_phase();
-            tile_store(tile, np * C, dst + (size_t)part * kHalfPx * C);
         }
-    }
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) {
+            double r = 0.0;
+            if (c < C && active[c]) {
+                const int f = D::func(P, c), a = D::agg(P, c);
+                const double n = (double)cnt[c];
+                const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
+                if (is_count_func(f) && a != EVREP_A_MAX) {
+                    // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
+                    r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
+                } else if (a == EVREP_A_SUM) r = s[c];
+                else if (a == EVREP_A_MEAN) r = s[c] / d;
+                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+                else {
+                    const double mean = s[c] / d, mean2 = s2[c] / d;
+                    const double mm = mean * mean;
+                    r = mean2 - mm;
+                }
+            }
+            vals[c] = (OutT)(r * scale);
+        }
+    };
+    emit_chunk<OutT, D::kMaxC>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -402,17 +377,11 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, int S,
                                                       int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveTile<float> wt(smem, S);
+    WaveLds<float> w(smem, S);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
-    tile_fill_zero(wt.tile, g.npix * S);
-    if (g.ce == g.cs) {
-        wave_phase();
-        tile_store(wt.tile, g.npix * S, dst);
-        return;
-    }
-    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    wave_phase();
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
     int offk[EVREP_MAX_CHANNELS];
@@ -421,20 +390,15 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
 #pragma unroll
         for (int k = 0; k < EVREP_MAX_CHANNELS; ++k) { offk[k] = o; cur /= 2; o += cur; }
     }
-    for (int k = threadIdx.x; k < nseg; k += kWave) {
-        const uint2 sg = wt.segs[k];
-        const uint32_t je = wt.segs[k + 1].y;
-        const Rec e = sorted[je - 1];  // ndarray.put is last-write-wins (event_stack.py:125)
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+        const Rec e = get(je - 1);  // ndarray.put is last-write-wins (event_stack.py:125)
         int p = e.w;
         if (premap) p = (p + 1) >> 1;                        // (p + 1) // 2   (gen1_transforms.py:34)
         const float v = (float)(int8_t)(2 * p - 1) * scale;  // 2*p - 1 as int8 (event_stack.py:18)
-        float *mine = wt.tile + (size_t)sg.x * S;
 #pragma unroll
-        for (int l = 0; l < EVREP_MAX_CHANNELS; ++l)
-            if (l < S) mine[l] = (e.y >= offk[l]) ? v : 0.0f;
-    }
-    wave_phase();
-    tile_store(wt.tile, g.npix * S, dst);
+        for (int l = 0; l < EVREP_MAX_CHANNELS; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
+    };
+    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -482,7 +446,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
         cuts[b].idx[s] = idx;
         cuts[b].tcut[s] = tc;
     }
-    wave_phase();
+    __syncthreads();
     if (s == 0) {
         bool alive = n > 0;
         for (int k = 0; k < kMaxSlices; ++k) {
@@ -506,39 +470,39 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
                                                        double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
-    WaveTile<OutT> wt(smem, C);
+    WaveLds<OutT> w(smem, C);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const TsCuts cu = cuts[g.b];
     const double init = -(tau * 3.0 + 1.0);  // timestamp_memory -= tau*3 + 1 (time_surface.py:29)
-    if (threadIdx.x < C) {
+    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) {
         const int s = threadIdx.x >> 1;
         double v = 0.0;
-        // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau)
-        if (cu.live[s]) { const double d = init - (double)cu.tcut[s]; v = exp(d / tau) * scale; }
-        wt.bg[threadIdx.x] = (OutT)v;
+        // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau); slices the scan never reaches are
+        if ((int)threadIdx.x < C && cu.live[s]) { const double d = init - (double)cu.tcut[s]; v = exp(d / tau) * scale; }
+        w.bg[threadIdx.x] = (OutT)v;
     }
     wave_phase();
-    tile_fill_pattern(wt.tile, g.npix, C, wt.bg);
-    int nseg = 0;
-    if (g.ce > g.cs) nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    wave_phase();
-    for (int k = threadIdx.x; k < nseg; k += kWave) {
-        const uint2 sg = wt.segs[k];
-        const uint32_t je = wt.segs[k + 1].y;
-        OutT *mine = wt.tile + (size_t)sg.x * C;
+    const OutT *bg = w.bg;
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[EVREP_MAX_CHANNELS]) {
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = bg[c];
         double mem0 = init, mem1 = init;
         bool touched0 = false, touched1 = false;
         int s = 0;
-        for (uint32_t j = sg.y; j <= je; ++j) {
+        for (uint32_t j = jb; j <= je; ++j) {
             int rank = INT32_MAX, t = 0, p = 0;
-            if (j < je) { const Rec e = sorted[j]; rank = e.y; t = e.z; p = e.w; }
+            if (j < je) { const Rec e = get(j); rank = e.y; t = e.z; p = e.w; }
             // slices cut strictly before this event see the memory as it stands
             while (s < S && cu.idx[s] < rank) {
                 if (cu.live[s]) {
                     const double tc = (double)cu.tcut[s];
-                    if (touched0) mine[2 * s] = (OutT)(exp((mem0 - tc) / tau) * scale);
-                    if (touched1) mine[2 * s + 1] = (OutT)(exp((mem1 - tc) / tau) * scale);
+                    const OutT v0 = (OutT)(exp((mem0 - tc) / tau) * scale), v1 = (OutT)(exp((mem1 - tc) / tau) * scale);
+#pragma unroll
+                    for (int q = 0; q < kMaxSlices; ++q)
+                        if (q == s) { if (touched0) vals[2 * q] = v0; if (touched1) vals[2 * q + 1] = v1; }
                 }
                 ++s;
             }
@@ -547,9 +511,8 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
                 if (p & 1) { mem1 = (double)t; touched1 = true; } else { mem0 = (double)t; touched0 = true; }
             }
         }
-    }
-    wave_phase();
-    tile_store(wt.tile, g.npix * C, dst);
+    };
+    emit_chunk<OutT, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -566,8 +529,9 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * K;
-    WaveTile<float> wt(smem, C);
-    const int b = blockIdx.z, orow = blockIdx.y, oc0 = blockIdx.x * kChunkPx;
+    WaveLds<float> w(smem, C);
+    const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    const int b = (u / nchunk) / H, orow = (u / nchunk) % H, oc0 = (u % nchunk) * kChunkPx;
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
     if (n_win <= 0) return;
@@ -577,33 +541,32 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
     if (orow >= Hf || oc0 >= Wf) return;
     const int npix = min(kChunkPx, Wf - oc0);
-    const int row = orow + y0;                      // sensor row feeding this output row
+    const int row = orow + y0;  // sensor row feeding this output row
     const int T = sample_times ? sample_times[b] : ev[beg + n_win - 1].z;
-    // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
-    const double log_min = log(151.0);
-    const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
-    for (int e = threadIdx.x; e < npix * C; e += kWave) wt.tile[e] = bgv;
     // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle two sensor chunks
-    int nseg = 0;
-    const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;  // sensor column range
+    uint32_t cs = 0, ce = 0;
+    const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
     if (row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
         const uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-        const uint32_t cs = co[ch_lo], ce = co[ch_hi + 1];
-        if (ce > cs) nseg = list_segments(sorted, cs, ce, row * W + sc_lo, wt.segs);
+        cs = co[ch_lo];
+        ce = co[ch_hi + 1];
     }
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(ce - cs)) r0 = sorted[cs + threadIdx.x];
+    // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
+    const double log_min = log(151.0);
+    const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
+    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) w.bg[threadIdx.x] = bgv;
     wave_phase();
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
-    for (int k = threadIdx.x; k < nseg; k += kWave) {
-        const uint2 sg = wt.segs[k];
-        if (sg.x >= (uint32_t)npix) continue;  // a pixel of the neighbouring output chunk
-        const uint32_t je = wt.segs[k + 1].y;
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
         int fp[kMaxToreK], fn[kMaxToreK];
         int np_ = 0, nn_ = 0;
 #pragma unroll
         for (int q = 0; q < kMaxToreK; ++q) { fp[q] = 0; fn[q] = 0; }
-        for (uint32_t j = sg.y; j < je; ++j) {
-            const Rec e = sorted[j];
+        for (uint32_t j = jb; j < je; ++j) {
+            const Rec e = get(j);
             if (!(e.z < T)) continue;  // ts < currentSampleTime (tore.py:17): events at T are dropped
             if (e.w > 0) {
 #pragma unroll
@@ -615,27 +578,30 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
                 fn[0] = e.z; ++nn_;
             }
         }
-        float *mine = wt.tile + (size_t)sg.x * C;
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = bgv;
 #pragma unroll
         for (int q = 0; q < kMaxToreK; ++q) {
-            if (q < K) {
-                if (q < np_) {
-                    float v = (float)(double)((int64_t)T - (int64_t)fp[q]);
-                    v = fminf(v, 500e6f);
-                    const float r = (float)((double)logf(v + 1.0f) - log_min);
-                    mine[q] = fmaxf(r, 0.0f) * scale;
-                }
-                if (q < nn_) {
-                    float v = (float)(double)((int64_t)T - (int64_t)fn[q]);
-                    v = fminf(v, 500e6f);
-                    const float r = (float)((double)logf(v + 1.0f) - log_min);
-                    mine[K + q] = fmaxf(r, 0.0f) * scale;
-                }
+            float vp = bgv, vn = bgv;
+            if (q < np_) {
+                float v = (float)(double)((int64_t)T - (int64_t)fp[q]);
+                v = fminf(v, 500e6f);
+                vp = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+            }
+            if (q < nn_) {
+                float v = (float)(double)((int64_t)T - (int64_t)fn[q]);
+                v = fminf(v, 500e6f);
+                vn = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+            }
+            // channel layout: positives [0, K), negatives [K, 2K)
+#pragma unroll
+            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+                if (q < K && c == q) vals[c] = vp;
+                if (q < K && c == K + q) vals[c] = vn;
             }
         }
-    }
-    wave_phase();
-    tile_store(wt.tile, npix * C, dst);
+    };
+    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, cs, ce, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -647,29 +613,22 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
                                                 int H, int W, int nchunk, int bins, int mode, double scale,
                                                 double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveTile<double> wt(smem, bins);
+    WaveLds<double> w(smem, bins);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
-    tile_fill_zero(wt.tile, g.npix * bins);
-    if (g.ce == g.cs) {
-        wave_phase();
-        tile_store(wt.tile, g.npix * bins, dst);
-        return;
-    }
-    const int nseg = list_segments(sorted, g.cs, g.ce, g.row * W + g.c0, wt.segs);
-    wave_phase();
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const int64_t beg = off[g.b];
     const int64_t n_win = off[g.b + 1] - beg;
-    const double t0 = (double)ev[beg].z;
-    const double den = (double)ev[beg + n_win - 1].z - t0;
-    for (int k = threadIdx.x; k < nseg; k += kWave) {
-        const uint2 sg = wt.segs[k];
-        const uint32_t je = wt.segs[k + 1].y;
-        double *mine = wt.tile + (size_t)sg.x * bins;
+    double t0 = 0.0, den = 1.0;
+    if (n_win > 0) { t0 = (double)ev[beg].z; den = (double)ev[beg + n_win - 1].z - t0; }
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[EVREP_MAX_CHANNELS]) {
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
         // two np.add.at passes: lower bin for every event, then upper bin for every event
         for (int pass = 0; pass < 2; ++pass) {
-            for (uint32_t j = sg.y; j < je; ++j) {
-                const Rec e = sorted[j];
+            for (uint32_t j = jb; j < je; ++j) {
+                const Rec e = get(j);
                 double p = (double)e.w;
                 double bpos;
                 if (mode == 0) {
@@ -684,19 +643,21 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
                 const int bi = (int)bpos;
                 const int blim = bi + pass;
                 if (blim < bins) {
-                    double w;
-                    if (mode == 0) w = 1.0 - fabs((double)blim - bpos);
-                    else { const double dts = bpos - (double)bi; w = pass ? dts : 1.0 - dts; }
-                    const double wp = w * p;
-                    mine[blim] = mine[blim] + wp;
+                    double wgt;
+                    if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
+                    else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
+                    const double wp = wgt * p;
+#pragma unroll
+                    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c == blim) vals[c] = vals[c] + wp;
                 }
             }
         }
-        if (scale != 1.0)
-            for (int q = 0; q < bins; ++q) mine[q] = mine[q] * scale;
-    }
-    wave_phase();
-    tile_store(wt.tile, g.npix * bins, dst);
+        if (scale != 1.0) {
+#pragma unroll
+            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
+        }
+    };
+    emit_chunk<double, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, r0, reduce);
 }
 
 }  // namespace evrep

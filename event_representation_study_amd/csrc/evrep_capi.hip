@@ -121,7 +121,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<BUILDER_GRID, kWave, mdes_lds_bytes(C, sizeof(T)), stream>>>(                                            \
+    k_mdes<T, DESC><<<BUILDER_GRID, kWave, chunk_lds_bytes(C, sizeof(T)), stream>>>(                                           \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
         plan->nchunk, scale, static_cast<T *>(out))
     if (out_dtype == EVREP_F64) {
@@ -147,7 +147,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_event_stack<<<BUILDER_GRID, kWave, builder_lds_bytes(stack_size, 4), stream>>>(
+    k_event_stack<<<BUILDER_GRID, kWave, chunk_lds_bytes(stack_size, 4), stream>>>(
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, stack_size, premap,
         scale, out);
     LAUNCH_CHECK("k_event_stack");
@@ -166,11 +166,11 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, cuts);
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
-        k_time_surface<double><<<BUILDER_GRID, kWave, builder_lds_bytes(2 * slices, 8), stream>>>(
+        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8), stream>>>(
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
-        k_time_surface<float><<<BUILDER_GRID, kWave, builder_lds_bytes(2 * slices, 4), stream>>>(
+        k_time_surface<float><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 4), stream>>>(
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
             premap, scale, static_cast<float *>(out));
     }
@@ -184,7 +184,7 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
     if (rc) return rc;
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_tore<<<BUILDER_GRID, kWave, builder_lds_bytes(2 * k, 4), stream>>>(
+    k_tore<<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * k, 4), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
         CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, k, frame_mode, scale, out);
     LAUNCH_CHECK("k_tore");
@@ -197,7 +197,7 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     if (rc) return rc;
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 1 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_voxel<<<BUILDER_GRID, kWave, builder_lds_bytes(bins, 8), stream>>>(
+    k_voxel<<<BUILDER_GRID, kWave, chunk_lds_bytes(bins, 8), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
         plan->W, plan->nchunk, bins, mode, scale, out);
     LAUNCH_CHECK("k_voxel");
