@@ -283,6 +283,166 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
     }
 }
 
+// Fused form of k_row_scan + k_row_scatter for sensors whose per-row tables fit one workgroup's LDS
+// (fused_scatter_lds_bytes() <= 64 KB; 640x480 and 1280x720 do): every block derives its own
+// destinations from the raw (block,row) histogram table -- a few dozen coalesced, independent loads
+// per thread instead of a separate 1-block-per-window scan kernel and its launch boundary -- places
+// its records stably into an LDS stage in OUTPUT order, and writes the stage out so that consecutive
+// lanes write consecutive records of a row (64-byte runs instead of scattered 16-byte stores).
+// Block 0 of every window also publishes the row offsets and the reduced window statistics.
+// grid (8 * ceil(B/8) * nblk), 256 threads, requires chunk <= kStageRecs.
+constexpr int kStageRecs = 2048;
+__host__ __device__ inline size_t fused_scatter_lds_bytes(int H) {
+    return (size_t)(kWaves + 3) * H * sizeof(uint32_t) + (size_t)kStageRecs * sizeof(Rec);
+}
+
+__global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+                                                               int B, int H, int W, int chunk, int nblk,
+                                                               const uint32_t *__restrict__ table,
+                                                               const BlockStats *__restrict__ stats,
+                                                               uint32_t *__restrict__ row_off, WindowMeta *__restrict__ meta,
+                                                               Rec *__restrict__ sorted1) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Rec *stage = reinterpret_cast<Rec *>(smem_raw);                          // [kStageRecs]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(stage + kStageRecs);        // [kWaves][H] per-wave counts -> local bases
+    uint32_t *rowtot = cnt + kWaves * H;                                     // [H] window row totals -> row starts
+    uint32_t *lbase = rowtot + H;                                            // [H] this block's row counts -> local starts
+    uint32_t *delta = lbase + H;                                             // [H] global minus local position
+    __shared__ BlockStats wstats[kWaves];
+    __shared__ uint32_t tmp[8];
+    int b, blk;
+    if (!decode_window_block(B, nblk, b, blk)) return;
+    const int64_t beg = off[b];
+    const int64_t n = off[b + 1] - beg;
+    const int64_t lo = (int64_t)blk * chunk;
+    if (lo >= n && !(blk == 0)) return;
+    const int nb = (int)((n + chunk - 1) / chunk);
+    if (n <= 0) {  // empty window: block 0 still publishes its (empty) rows and status
+        uint32_t *ro = row_off + (size_t)b * (H + 1);
+        for (int r = threadIdx.x; r <= H; r += kThreads) ro[r] = (uint32_t)beg;
+        if (threadIdx.x == 0) {
+            WindowMeta m;
+            m.tmin = INT32_MAX; m.tmax = INT32_MIN; m.xmin = INT32_MAX; m.xmax = INT32_MIN; m.ymin = INT32_MAX; m.ymax = INT32_MIN;
+            m.neg_flags = 0; m.oob_flags = 0; m.status = EVREP_ST_EMPTY; m.n_valid = 0;
+            for (int i = 0; i < 6; ++i) m.pad[i] = 0;
+            meta[b] = m;
+        }
+        return;
+    }
+    const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
+    const int64_t nloc = hi - lo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wlo = lo + nloc * wave / kWaves, whi = lo + nloc * (wave + 1) / kWaves;
+    const int64_t HW = (int64_t)H * W;
+    for (int i = threadIdx.x; i < kWaves * H; i += kThreads) cnt[i] = 0;
+    __syncthreads();
+    // the wave's events stay in registers from counting to placement (chunk <= 2048: <= 8 per lane)
+    uint32_t *mycnt = cnt + wave * H;
+    int4 e[kRegBatch];
+#pragma unroll
+    for (int i = 0; i < kRegBatch; ++i) {
+        const int64_t r = wlo + i * kWave + lane;
+        e[i] = make_int4(-1, -1, 0, 0);
+        if (r < whi) e[i] = ev[beg + r];
+    }
+#pragma unroll
+    for (int i = 0; i < kRegBatch; ++i) {
+        const int64_t r = wlo + i * kWave + lane;
+        const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+        if (r < whi && key >= 0 && key < HW) atomicAdd(&mycnt[(uint32_t)key / (uint32_t)W], 1u);
+    }
+    // window statistics (published by block 0)
+    if (blk == 0) {
+        BlockStats st;
+        stats_identity(st);
+        for (int k = threadIdx.x; k < nb; k += kThreads) stats_merge(st, stats[(size_t)b * nblk + k]);
+        stats_wave_reduce(st);
+        if (lane == 0) wstats[wave] = st;
+    }
+    __syncthreads();
+    // per row: this window's total, the part that lies in earlier blocks, this block's own count
+    for (int r = threadIdx.x; r < H; r += kThreads) {
+        uint32_t tot = 0, before = 0;
+        for (int b0 = 0; b0 < nb; b0 += kRegBatch) {
+            uint32_t v[kRegBatch];
+#pragma unroll
+            for (int i = 0; i < kRegBatch; ++i) v[i] = (b0 + i < nb) ? table[((size_t)b * nblk + b0 + i) * H + r] : 0u;
+#pragma unroll
+            for (int i = 0; i < kRegBatch; ++i) { tot += v[i]; if (b0 + i < blk) before += v[i]; }
+        }
+        rowtot[r] = tot;
+        delta[r] = before;  // (parked here until the scans are done)
+        uint32_t own = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) own += cnt[w * H + r];
+        lbase[r] = own;
+    }
+    __syncthreads();
+    // two exclusive scans over the rows: window totals -> row starts, own counts -> local starts
+    const int per = (H + kThreads - 1) / kThreads;
+    const int r0 = threadIdx.x * per;
+    uint32_t loc_t = 0, loc_o = 0;
+    for (int k = 0; k < per; ++k) if (r0 + k < H) { loc_t += rowtot[r0 + k]; loc_o += lbase[r0 + k]; }
+    uint32_t total_t, total_o;
+    uint32_t run_t = block_exclusive_scan(loc_t, tmp, &total_t);
+    uint32_t run_o = block_exclusive_scan(loc_o, tmp, &total_o);
+    for (int k = 0; k < per; ++k)
+        if (r0 + k < H) {
+            const uint32_t t = rowtot[r0 + k]; rowtot[r0 + k] = run_t; run_t += t;
+            const uint32_t o = lbase[r0 + k];  lbase[r0 + k] = run_o;  run_o += o;
+        }
+    __syncthreads();
+    for (int r = threadIdx.x; r < H; r += kThreads) {
+        const uint32_t gstart = (uint32_t)beg + rowtot[r] + delta[r];
+        uint32_t base = lbase[r];
+        delta[r] = gstart - base;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const uint32_t t = cnt[w * H + r]; cnt[w * H + r] = base; base += t; }
+        if (blk == 0) row_off[(size_t)b * (H + 1) + r] = (uint32_t)beg + rowtot[r];
+    }
+    if (blk == 0 && threadIdx.x == 0) {
+        row_off[(size_t)b * (H + 1) + H] = (uint32_t)beg + total_t;
+        BlockStats t = wstats[0];
+        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        WindowMeta m;
+        m.tmin = t.tmin; m.tmax = t.tmax; m.xmin = t.xmin; m.xmax = t.xmax; m.ymin = t.ymin; m.ymax = t.ymax;
+        m.neg_flags = t.neg_flags; m.oob_flags = t.oob_flags; m.status = t.status; m.n_valid = t.n_valid;
+        if (t.tmin == t.tmax) m.status |= EVREP_ST_FLAT_TIME;
+        for (int i = 0; i < 6; ++i) m.pad[i] = 0;
+        meta[b] = m;
+    }
+    __syncthreads();
+    // stable placement into the stage, in output order
+    const int nbits = bits_for(H);
+    volatile uint32_t *vcnt = mycnt;
+#pragma unroll
+    for (int i = 0; i < kRegBatch; ++i) {
+        const int64_t rr0 = wlo + i * kWave;
+        if (rr0 >= whi) break;  // uniform
+        const int64_t r = rr0 + lane;
+        const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+        const bool valid = r < whi && key >= 0 && key < HW;
+        const uint32_t row = valid ? (uint32_t)key / (uint32_t)W : 0u;
+        uint32_t rk; bool last;
+        wave_match(row, nbits, valid, lane, rk, last);
+        uint32_t pos = 0;
+        if (valid) {
+            pos = vcnt[row] + rk;
+            stage[pos] = make_int4((int)key, (int)r, e[i].z, e[i].w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && last) vcnt[row] = pos + 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // write-out: consecutive lanes hold consecutive records of a row
+    for (uint32_t t = threadIdx.x; t < total_o; t += kThreads) {
+        const Rec rec = stage[t];
+        const uint32_t row = (uint32_t)rec.x / (uint32_t)W;
+        sorted1[delta[row] + t] = rec;
+    }
+}
+
 // grid (H, B), 64 threads, dynamic LDS = W * 4 bytes.  Stable placement by column inside one row,
 // by ONE wave: afterwards sorted2 is ordered by (window, pixel id, rank).  Rows of up to 256 records
 // (the common case) keep their records in registers between counting and placement; longer rows

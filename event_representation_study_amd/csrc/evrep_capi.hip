@@ -1,5 +1,6 @@
 // evrep_capi.hip -- the extern "C" surface declared in include/evrep.h: argument checks, workspace
 // carving and kernel launches.  No allocation, no global state besides the last HIP error string.
+#include <stdlib.h>
 #include <string.h>
 
 #include "evrep_common.h"
@@ -93,10 +94,17 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
     k_row_hist<<<xgrid, kThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
-    k_row_scan<<<B, kThreads, (size_t)H * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
-    LAUNCH_CHECK("k_row_scan");
-    k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
-    LAUNCH_CHECK("k_row_scatter");
+    if (chunk <= kStageRecs && fused_scatter_lds_bytes(H) <= 65536 && !getenv("EVREP_NO_FUSED_SCATTER")) {
+        // scan fused into the scatter (one kernel and one launch boundary fewer)
+        k_row_scatter_fused<<<xgrid, kThreads, fused_scatter_lds_bytes(H), stream>>>(ev, offsets, B, H, W, chunk, nblk, table,
+                                                                                     stats, row_off, meta, s1);
+        LAUNCH_CHECK("k_row_scatter_fused");
+    } else {
+        k_row_scan<<<B, kThreads, (size_t)H * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
+        LAUNCH_CHECK("k_row_scan");
+        k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
+        LAUNCH_CHECK("k_row_scatter");
+    }
     k_col_sort<<<dim3(H, B), kWave, (size_t)W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2, WS(uint32_t, off_chunkoff));
     LAUNCH_CHECK("k_col_sort");
     return EVREP_OK;
