@@ -250,6 +250,7 @@ size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m) {
     const int64_t L = n > m ? n : m;
     const int64_t T = pad_tile(L) / kTile;
     size_t o = up256(sizeof(GwdStats));
+    o += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
     o += up256((size_t)kGwdMaxD * pad_tile(n) * sizeof(float));
     o += up256((size_t)kGwdMaxD * pad_tile(m) * sizeof(float));
     o += up256((size_t)(T * (T + 1) / 2) * sizeof(double));
@@ -268,11 +269,14 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     if ((int64_t)T * (T + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
     char *p = static_cast<char *>(scratch);
     GwdStats *st = reinterpret_cast<GwdStats *>(p); p += up256(sizeof(GwdStats));
+    double *stat_partial = reinterpret_cast<double *>(p); p += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
     float *Ys = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * npad * sizeof(float));
     float *Yt = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * mpad * sizeof(float));
     double *partial = reinterpret_cast<double *>(p);
-    k_gwd_stats<<<2, kThreads, 0, stream>>>(Xs, n, ds, Xt, m, dt, st);
+    k_gwd_stats<<<dim3(kStatBlocks, 2), kThreads, 0, stream>>>(Xs, n, ds, Xt, m, dt, stat_partial);
     LAUNCH_CHECK("k_gwd_stats");
+    k_gwd_stats_finish<<<1, 64, 0, stream>>>(stat_partial, n, ds, m, dt, st);
+    LAUNCH_CHECK("k_gwd_stats_finish");
     k_gwd_prep<<<(unsigned)((npad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xs, n, ds, npad, st, 0, h, Ys);
     LAUNCH_CHECK("k_gwd_prep(s)");
     k_gwd_prep<<<(unsigned)((mpad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xt, m, dt, mpad, st, 1, h, Yt);

@@ -21,39 +21,68 @@ struct GwdStats {
     double var_s, var_t;  // mean ||a - abar||^2  (= sigma^2)
 };
 
-// grid (2): block 0 -> Xs, block 1 -> Xt.  Two-pass mean / centred second moment in float64.
+constexpr int kStatBlocks = 64;  // partial-sum blocks per cloud
+
+// grid (kStatBlocks, 2): block (j, c) sums x and x^2 per dimension over its slice of cloud c
+// (float64, one pass; the clouds hold O(1e4) points of magnitude <= 255, so sum(x^2)/N - mean^2
+// keeps ~1e-11 relative accuracy, far inside the 1e-5 budget).  partial: [2][kStatBlocks][2*kGwdMaxD].
 __global__ __launch_bounds__(kThreads) void k_gwd_stats(const double *__restrict__ Xs, int64_t n, int ds,
                                                        const double *__restrict__ Xt, int64_t m, int dt,
-                                                       GwdStats *__restrict__ st) {
-    __shared__ double red[kThreads];
-    __shared__ double mean[kGwdMaxD];
-    const bool second = blockIdx.x == 1;
+                                                       double *__restrict__ partial) {
+    __shared__ double red[kWaves][2 * kGwdMaxD];
+    const bool second = blockIdx.y == 1;
     const double *X = second ? Xt : Xs;
     const int64_t N = second ? m : n;
     const int d = second ? dt : ds;
-    for (int k = 0; k < d; ++k) {
-        double s = 0.0;
-        for (int64_t i = threadIdx.x; i < N; i += kThreads) s += X[i * d + k];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = kThreads / 2; w > 0; w >>= 1) {
-            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-            __syncthreads();
+    const int64_t per = (N + kStatBlocks - 1) / kStatBlocks;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = (i0 + per < N) ? i0 + per : N;
+    // flat walk over the slice's elements: consecutive lanes read consecutive doubles (coalesced);
+    // a lane's elements e = i0*d + tid + k*256 visit dimension (e % d)
+    double s[kGwdMaxD], q[kGwdMaxD];
+#pragma unroll
+    for (int k = 0; k < kGwdMaxD; ++k) { s[k] = 0.0; q[k] = 0.0; }
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kThreads) {
+        const double *row = X + i * d;
+#pragma unroll
+        for (int k = 0; k < kGwdMaxD; ++k)
+            if (k < d) { const double v = row[k]; s[k] += v; q[k] += v * v; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kGwdMaxD; ++k) {
+        if (k < d) {
+            double a = s[k], c = q[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+            if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = c; }
         }
-        if (threadIdx.x == 0) mean[k] = red[0] / (double)N;
-        __syncthreads();
     }
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += kThreads)
-        for (int k = 0; k < d; ++k) { const double u = X[i * d + k] - mean[k]; s += u * u; }
-    red[threadIdx.x] = s;
     __syncthreads();
-    for (int w = kThreads / 2; w > 0; w >>= 1) {
-        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
+    if (threadIdx.x < 2 * d) {
+        double a = 0.0;
+        for (int w = 0; w < kWaves; ++w) a += red[w][threadIdx.x];
+        partial[((size_t)blockIdx.y * kStatBlocks + blockIdx.x) * (2 * kGwdMaxD) + threadIdx.x] = a;
     }
-    if (threadIdx.x < d) (second ? st->mean_t : st->mean_s)[threadIdx.x] = mean[threadIdx.x];
-    if (threadIdx.x == 0) (second ? st->var_t : st->var_s) = red[0] / (double)N;
+}
+
+// grid (1), 64 threads: lanes 0..31 finish cloud s, lanes 32..63 cloud t.
+__global__ void k_gwd_stats_finish(const double *__restrict__ partial, int64_t n, int ds, int64_t m, int dt,
+                                   GwdStats *__restrict__ st) {
+    const int cloud = threadIdx.x >> 5, k = threadIdx.x & 31;
+    const int d = cloud ? dt : ds;
+    const double N = (double)(cloud ? m : n);
+    double sx = 0.0, sq = 0.0;
+    if (k < d)
+        for (int j = 0; j < kStatBlocks; ++j) {
+            const double *p = partial + ((size_t)cloud * kStatBlocks + j) * (2 * kGwdMaxD);
+            sx += p[2 * k]; sq += p[2 * k + 1];
+        }
+    const double mean = sx / N;
+    double var = (k < d) ? sq / N - mean * mean : 0.0;  // this dimension's share of mean ||a - abar||^2
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);  // within each 32-lane half
+    if (k < d) (cloud ? st->mean_t : st->mean_s)[k] = mean;
+    if (k == 0) (cloud ? st->var_t : st->var_s) = var;
 }
 
 // Centre, scale by sqrt(log2(e) / (2 h^2 sigma^2)) so that K = exp2(-||a'_i - a'_j||^2), and lay

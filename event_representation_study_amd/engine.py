@@ -271,8 +271,10 @@ class BinBuildPipeline:
         return self._flush()
 
 
-def gwd_padded_l1(Xs, Xt, h=0.7):
-    """OTMI(Xs, Xt, h).solve()[1] on the GPU: Xs (n, ds), Xt (m, dt) array-likes -> 0-dim float64 cuda tensor."""
+def gwd_padded_l1(Xs, Xt, h=0.7, out=None):
+    """OTMI(Xs, Xt, h).solve()[1] on the GPU: Xs (n, ds), Xt (m, dt) array-likes -> 0-dim float64 cuda tensor.
+    `out`: optional one-element float64 cuda tensor (e.g. ``costs[i:i+1]``) the kernel writes into directly --
+    no host synchronisation, so a list of solves queues back to back."""
     _require_gpu()
     lib = _lib.load()
     dev = Xs.device if isinstance(Xs, torch.Tensor) and Xs.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -282,7 +284,12 @@ def gwd_padded_l1(Xs, Xt, h=0.7):
         raise ValueError("Xs and Xt must be non-empty 2-D point clouds")
     n, m = int(a.shape[0]), int(b.shape[0])
     scratch = torch.empty(int(lib.evrep_gwd_scratch_bytes(n, m)), dtype=torch.uint8, device=dev)
-    cost = torch.empty((), dtype=torch.float64, device=dev)
+    if out is not None:
+        if out.dtype != torch.float64 or out.numel() != 1 or not out.is_cuda:
+            raise ValueError("out must be a one-element float64 CUDA tensor")
+        cost = out
+    else:
+        cost = torch.empty((), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         check(lib.evrep_gwd_padded_l1(_ptr(a), n, int(a.shape[1]), _ptr(b), m, int(b.shape[1]), float(h),
                                       _ptr(scratch), _ptr(cost), _stream_ptr()), "evrep_gwd_padded_l1")
