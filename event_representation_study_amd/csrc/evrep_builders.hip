@@ -662,6 +662,9 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
 // --------------------------------------------------------------------------------------------
 // A2: compute_repr (representation_search/gromov_wasserstein.py:72-82), t normalised as :96.
 // mode 1: tonic.transforms.ToVoxelGrid as consumed at gen1_transforms.py:22-25 (parity unpinned).
+// mode 2: ev-licious events_to_voxel_grid, integer-pixel path (ev-licious/src/evlicious/tools/utils.py:
+//         52-108): the bilinear weight is taken from the INTEGER bin (:74), so the lower bin receives p
+//         and the upper bin an exact zero -- a signed event count per (time bin, y, x).
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                 const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
@@ -681,12 +684,16 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
 #pragma unroll
         for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
         // two np.add.at passes: lower bin for every event, then upper bin for every event
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < (mode == 2 ? 1 : 2); ++pass) {
             for (uint32_t j = jb; j < je; ++j) {
                 const Rec e = get(j);
                 double p = (double)e.w;
                 double bpos;
-                if (mode == 0) {
+                if (mode == 2) {
+                    // t_norm = (num_bins - 1) * (t - t0) / deltaT: int64 product, one float64 division
+                    const int64_t num = (int64_t)(bins - 1) * ((int64_t)e.z - (int64_t)t0);
+                    bpos = (double)num / (den == 0.0 ? 1.0 : den);
+                } else if (mode == 0) {
                     const double tn = ((double)e.z - t0) / den;
                     bpos = (double)(bins - 1) * tn;
                 } else {
@@ -699,7 +706,8 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
                 const int blim = bi + pass;
                 if (blim < bins) {
                     double wgt;
-                    if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
+                    if (mode == 2) wgt = 1.0;
+                    else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
                     else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
                     const double wp = wgt * p;
 #pragma unroll

@@ -203,7 +203,7 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
                 int32_t mode, double scale, double *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
-    if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 1 || !out) return EVREP_EINVAL;
+    if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     k_voxel<<<BUILDER_GRID, kWave, chunk_lds_bytes(bins, 8), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,

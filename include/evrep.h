@@ -122,7 +122,9 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
 
 /* compute_repr (representation_search/gromov_wasserstein.py:72-82) with t normalised as :96;
  * mode 0.  mode 1 = tonic.transforms.ToVoxelGrid as gen1_transforms.py:22-25 consumes it
- * (restated from tonic's published algorithm; parity unpinned).  out DEVICE (B,H,W,bins) float64. */
+ * (restated from tonic's published algorithm; parity unpinned).  mode 2 = ev-licious
+ * events_to_voxel_grid, integer-pixel path (ev-licious/src/evlicious/tools/utils.py:52-108), before
+ * its optional normalisation.  out DEVICE (B,H,W,bins) float64. */
 int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                 int32_t bins, int32_t mode, double scale, double *out, void *stream);
 

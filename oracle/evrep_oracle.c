@@ -339,6 +339,34 @@ int oracle_voxel(const int32_t *ev, int64_t n, int H, int W, int bins, double *o
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * F3: ev-licious events_to_voxel_grid, numpy variant, integer pixels, no normalisation
+ * (ev-licious/src/evlicious/tools/utils.py:52-76,100-108).  t_norm = (bins-1)*(t-t0)/deltaT in
+ * float64; both tlim in {int(t_norm), int(t_norm)+1} are drawn with weight (1 - |tlim - int(t_norm)|)*p,
+ * i.e. p and 0, accumulated with np.add.at into a float32 grid.  out is (bins, H, W) float32.
+ * ------------------------------------------------------------------------------------------- */
+int oracle_evl_voxel(const int32_t *ev, int64_t n, int H, int W, int bins, float *out) {
+    int64_t hw = (int64_t)H * W;
+    memset(out, 0, sizeof(float) * hw * bins);
+    if (n < 2) return ORACLE_OK;
+    int64_t t0 = ev[2], t1 = ev[4 * (n - 1) + 2];
+    double deltaT = (double)(t1 - t0);
+    if (t1 - t0 == 0) deltaT = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t i = 0; i < n; ++i) {
+            double tn = (double)((int64_t)(bins - 1) * ((int64_t)ev[4 * i + 2] - t0)) / deltaT;
+            int32_t ti = (int32_t)tn;
+            int32_t tlim = ti + pass;
+            if (!(tlim >= 0 && tlim < bins)) continue;
+            int32_t wgt = (1 - abs(tlim - ti)) * ev[4 * i + 3];
+            int x = ev[4 * i], y = ev[4 * i + 1];
+            if (!(x >= 0 && y >= 0 && x < W && y < H)) continue; /* _draw_xy_to_voxel_grid_int masks these */
+            out[(int64_t)tlim * hw + (int64_t)y * W + x] += (float)wgt;
+        }
+    }
+    return ORACLE_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * A9: OTMI.__init__/loss/solve (compute_otmi.py:61-93) in the closed form SURVEY.md section 8 A9
  * derives for POT's max_iter=0 path: C = mean over the L x L zero-padded grid of |Ks - Kt|,
  * L = max(n, m), Ks = exp(-(Cs/(h*sig_s))^2 / 2), sig = sqrt(mean(C^2)/2), C = pairwise L2.

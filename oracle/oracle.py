@@ -135,6 +135,14 @@ def voxel(ev, H, W, bins=5):
     return out
 
 
+def evl_voxel(ev, H, W, bins):
+    """ev-licious events_to_voxel_grid(events, bins, normalize=False): (bins, H, W) float32."""
+    ev = _ev(ev)
+    out = np.empty((bins, H, W), dtype=np.float32)
+    _chk(lib().oracle_evl_voxel(_p(ev), ctypes.c_int64(ev.shape[0]), H, W, bins, _p(out)))
+    return out
+
+
 def gwd(Xs, Xt, h=0.7):
     """OTMI(Xs, Xt, h).solve()[1] in closed form (PARITY UNPINNED for POT's part)."""
     Xs = np.ascontiguousarray(Xs, dtype=np.float64)

@@ -316,6 +316,35 @@ def main():
     manifest["cases"].append(dict(name="gwd", keys=sorted(g)))
     print("wrote gwd", {k: float(v) for k, v in g.items() if k.endswith("cost")})
 
+    # ---- F3: ev-licious events_to_voxel_grid (numpy variant), loaded from its file with stand-ins ----
+    import importlib.util
+    evl = types.ModuleType("evlicious")
+    evl.Events = object                       # utils.py only uses the name in annotations
+    sys.modules["evlicious"] = evl
+    spec = importlib.util.spec_from_file_location(
+        "evl_utils", os.path.join(REF, "ev-licious", "src", "evlicious", "tools", "utils.py"))
+    evl_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(evl_utils)
+
+    class _Events:                            # the fields Events carries (io/utils/events.py:8-20), p in {-1,+1}
+        def __len__(self):
+            return len(self.x)
+
+    v = {}
+    for tag, W, H, N, seed in (("a", 80, 60, 6000, 601), ("b", 304, 240, 20000, 602)):
+        ev = make_events(N, W, H, seed=seed)
+        e = _Events()
+        e.x, e.y = ev[:, 0].astype(np.uint16), ev[:, 1].astype(np.uint16)
+        e.t, e.p = ev[:, 2].astype(np.int64), ev[:, 3].astype(np.int8)
+        e.width, e.height = W, H
+        v[tag + "_events"], v[tag + "_W"], v[tag + "_H"] = ev, W, H
+        v[tag + "_raw5"] = evl_utils.events_to_voxel_grid(e, 5, normalize=False)
+        v[tag + "_norm5"] = evl_utils.events_to_voxel_grid(e, 5, normalize=True)
+        v[tag + "_raw12"] = evl_utils.events_to_voxel_grid(e, 12, normalize=False)
+    np.savez_compressed(os.path.join(HERE, "evlicious_voxel.npz"), **v)
+    manifest["cases"].append(dict(name="evlicious_voxel", keys=sorted(v)))
+    print("wrote evlicious_voxel")
+
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=str)
 

@@ -124,3 +124,19 @@ def test_gwd_fullsize_properties(eng, oracle):
     sub = float(eng.gwd_padded_l1(Xs[:1500], Xt[:1700]).item())
     ref = oracle.gwd(Xs[:1500], Xt[:1700])
     assert abs(sub - ref) <= 1e-5 * ref
+
+
+def test_bin_build_pipeline_matches_serial(eng):
+    """bin(k+1) overlapped with build(k) on a second stream gives the same tensors as the serial path."""
+    H, W, N, B = 120, 160, 6000, 4
+    batches = [eng.EventBatch.from_numpy([make_events(N, W, H, seed=50 * j + i) for i in range(B)], H, W) for j in range(2)]
+    serial = [b.rebin().optimized().clone() for b in batches]
+    outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda") for _ in range(2)]
+    pipe = eng.BinBuildPipeline("cuda:0")
+    for k in range(6):
+        j = k % 2
+        pipe.submit(batches[j], lambda b, j=j: b.optimized(out=outs[j]))
+    pipe.drain()
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert torch.equal(outs[j], serial[j])

@@ -189,3 +189,24 @@ def test_api_aliases():
     rng = np.random.default_rng(1)
     a, b = rng.random((200, 4)), rng.random((150, 6))
     assert abs(api.gwd_point_clouds(a, b) - oracle.gwd(a, b)) <= 1e-5 * oracle.gwd(a, b)
+
+
+def test_evlicious_voxel_grid():
+    """ev-licious events_to_voxel_grid (numpy variant, integer pixels)."""
+    from event_representation_study_amd.evlicious_tools import events_to_voxel_grid
+    g = load_golden("evlicious_voxel")
+
+    class Events:
+        pass
+
+    for tag in "ab":
+        ev = g[tag + "_events"]
+        e = Events()
+        e.x, e.y, e.t, e.p = ev[:, 0].astype(np.uint16), ev[:, 1].astype(np.uint16), ev[:, 2].astype(np.int64), ev[:, 3].astype(np.int8)
+        e.width, e.height = int(g[tag + "_W"]), int(g[tag + "_H"])
+        for bins in (5, 12):
+            got = events_to_voxel_grid(e, bins, normalize=False)
+            assert_bit_equal(got, g["%s_raw%d" % (tag, bins)], "%s raw %d" % (tag, bins))
+        got = events_to_voxel_grid(e, 5, normalize=True)
+        np.testing.assert_allclose(got, g[tag + "_norm5"], rtol=1e-5, atol=1e-6)   # float32 mean / std
+        assert np.array_equal(got == 0, g[tag + "_norm5"] == 0)
