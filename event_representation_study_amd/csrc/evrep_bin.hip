@@ -14,6 +14,12 @@
 
 namespace evrep {
 
+#ifndef EVREP_BIN_THREADS
+#define EVREP_BIN_THREADS 256
+#endif
+constexpr int kBinThreads = EVREP_BIN_THREADS;  // workgroup size of the row-partition kernels
+constexpr int kBinWaves = kBinThreads / kWave;
+
 // Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, gfx9 family), result in every
 // lane via readlane(63).  No LDS traffic, no lgkmcnt waits -- ten of these run per block in k_row_hist.
 template <typename Op>
@@ -74,30 +80,30 @@ __device__ inline bool decode_window_block(int B, int nblk, int &b, int &blk) {
 }
 
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = H * 4 bytes.
-__global__ __launch_bounds__(kThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                       int B, int H, int W, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, BlockStats *__restrict__ stats) {
     extern __shared__ uint32_t hist[];
-    __shared__ BlockStats wstats[kWaves];
+    __shared__ BlockStats wstats[kBinWaves];
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
     const int64_t lo = (int64_t)blk * chunk;
     if (lo >= n) return;  // k_row_scan only reads the blocks a window really has
-    for (int i = threadIdx.x; i < H; i += kThreads) hist[i] = 0;
+    for (int i = threadIdx.x; i < H; i += kBinThreads) hist[i] = 0;
     __syncthreads();
     const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
     const MdesWindows mw = mdes_windows(n);
     const int64_t HW = (int64_t)H * W;
     BlockStats st;
     stats_identity(st);
-    for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)kRegBatch * kThreads) {
+    for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)kRegBatch * kBinThreads) {
         int4 e[kRegBatch];
         int tprev[kRegBatch];
 #pragma unroll
         for (int i = 0; i < kRegBatch; ++i) {  // all loads of the batch in flight together
-            const int64_t r = r0 + (int64_t)i * kThreads + threadIdx.x;
+            const int64_t r = r0 + (int64_t)i * kBinThreads + threadIdx.x;
             e[i] = make_int4(0, 0, INT32_MAX, 0);
             tprev[i] = INT32_MIN;
             if (r < hi) {
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void k_row_hist(const int4 *__restrict__ 
         }
 #pragma unroll
         for (int i = 0; i < kRegBatch; ++i) {
-            const int64_t r = r0 + (int64_t)i * kThreads + threadIdx.x;
+            const int64_t r = r0 + (int64_t)i * kBinThreads + threadIdx.x;
             if (r < hi) {
                 const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
                 const uint32_t memb = mdes_membership(mw, (int32_t)r);
@@ -138,22 +144,22 @@ __global__ __launch_bounds__(kThreads) void k_row_hist(const int4 *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         BlockStats t = wstats[0];
-        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        for (int w = 1; w < kBinWaves; ++w) stats_merge(t, wstats[w]);
         stats[(size_t)b * nblk + blk] = t;
     }
     uint32_t *dst = table + ((size_t)b * nblk + blk) * H;
-    for (int i = threadIdx.x; i < H; i += kThreads) dst[i] = hist[i];
+    for (int i = threadIdx.x; i < H; i += kBinThreads) dst[i] = hist[i];
 }
 
 // grid (B), 256 threads, dynamic LDS = (H + 8) * 4 bytes.
 // table[b][blk][row] -> exclusive prefix over blk; row_off[b][row] = global start of the row;
 // meta[b] = reduction of the window's block statistics.
-__global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
+__global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, uint32_t *__restrict__ row_off,
                                                       const BlockStats *__restrict__ stats, WindowMeta *__restrict__ meta) {
     extern __shared__ uint32_t rowtot[];
-    __shared__ BlockStats wstats[kWaves];
-    __shared__ uint32_t tmp[8];
+    __shared__ BlockStats wstats[kBinWaves];
+    __shared__ uint32_t tmp[kBinWaves];
     const int b = blockIdx.x;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
@@ -161,11 +167,11 @@ __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict
     // window statistics
     BlockStats st;
     stats_identity(st);
-    for (int blk = threadIdx.x; blk < nb; blk += kThreads) stats_merge(st, stats[(size_t)b * nblk + blk]);
+    for (int blk = threadIdx.x; blk < nb; blk += kBinThreads) stats_merge(st, stats[(size_t)b * nblk + blk]);
     stats_wave_reduce(st);
     if ((threadIdx.x & 63) == 0) wstats[threadIdx.x >> 6] = st;
     // exclusive prefix over the window's blocks, row by row (batched so the loads overlap)
-    for (int r = threadIdx.x; r < H; r += kThreads) {
+    for (int r = threadIdx.x; r < H; r += kBinThreads) {
         uint32_t run = 0;
         for (int b0 = 0; b0 < nb; b0 += kRegBatch) {
             uint32_t v[kRegBatch];
@@ -179,21 +185,21 @@ __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict
         rowtot[r] = run;
     }
     __syncthreads();
-    const int per = (H + kThreads - 1) / kThreads;
+    const int per = (H + kBinThreads - 1) / kBinThreads;
     const int r0 = threadIdx.x * per;
     uint32_t local = 0;
     for (int k = 0; k < per; ++k) if (r0 + k < H) local += rowtot[r0 + k];
     uint32_t total;
-    uint32_t run = block_exclusive_scan(local, tmp, &total);
+    uint32_t run = block_exclusive_scan<kBinWaves>(local, tmp, &total);
     for (int k = 0; k < per; ++k)
         if (r0 + k < H) { const uint32_t t = rowtot[r0 + k]; rowtot[r0 + k] = run; run += t; }
     __syncthreads();
     uint32_t *ro = row_off + (size_t)b * (H + 1);
-    for (int r = threadIdx.x; r < H; r += kThreads) ro[r] = (uint32_t)beg + rowtot[r];
+    for (int r = threadIdx.x; r < H; r += kBinThreads) ro[r] = (uint32_t)beg + rowtot[r];
     if (threadIdx.x == 0) {
         ro[H] = (uint32_t)beg + total;
         BlockStats t = wstats[0];
-        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        for (int w = 1; w < kBinWaves; ++w) stats_merge(t, wstats[w]);
         WindowMeta m;
         m.tmin = t.tmin; m.tmax = t.tmax; m.xmin = t.xmin; m.xmax = t.xmax; m.ymin = t.ymin; m.ymax = t.ymax;
         m.neg_flags = t.neg_flags; m.oob_flags = t.oob_flags; m.status = t.status; m.n_valid = t.n_valid;
@@ -207,11 +213,11 @@ __global__ __launch_bounds__(kThreads) void k_row_scan(const int64_t *__restrict
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = 4 * H * 4 bytes.  Stable placement by sensor row.
 // Each wave owns a contiguous quarter of the block's events and keeps them in registers between
 // the counting and the placement phase (one HBM read of the events for both).
-__global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kBinThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                          int B, int H, int W, int chunk, int nblk,
                                                          const uint32_t *__restrict__ table,
                                                          const uint32_t *__restrict__ row_off, Rec *__restrict__ sorted1) {
-    extern __shared__ uint32_t cnt[];  // [kWaves][H]
+    extern __shared__ uint32_t cnt[];  // [kBinWaves][H]
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
@@ -221,11 +227,11 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
     const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
     const int64_t nloc = hi - lo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wlo = lo + nloc * wave / kWaves, whi = lo + nloc * (wave + 1) / kWaves;
+    const int64_t wlo = lo + nloc * wave / kBinWaves, whi = lo + nloc * (wave + 1) / kBinWaves;
     const int64_t HW = (int64_t)H * W;
     constexpr int kSuper = kRegBatch * kWave;  // 512 events per register-resident super batch
     const int nsuper = (int)((whi - wlo + kSuper - 1) / kSuper);
-    for (int i = threadIdx.x; i < kWaves * H; i += kThreads) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kBinWaves * H; i += kBinThreads) cnt[i] = 0;
     __syncthreads();
     uint32_t *mycnt = cnt + wave * H;
     int4 e[kRegBatch];
@@ -244,10 +250,10 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
         }
     }
     __syncthreads();
-    for (int row = threadIdx.x; row < H; row += kThreads) {
+    for (int row = threadIdx.x; row < H; row += kBinThreads) {
         uint32_t base = row_off[(size_t)b * (H + 1) + row] + table[((size_t)b * nblk + blk) * H + row];
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) { const uint32_t t = cnt[w * H + row]; cnt[w * H + row] = base; base += t; }
+        for (int w = 0; w < kBinWaves; ++w) { const uint32_t t = cnt[w * H + row]; cnt[w * H + row] = base; base += t; }
     }
     __syncthreads();
     const int nbits = bits_for(H);
@@ -293,10 +299,10 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter(const int4 *__restrict
 // grid (8 * ceil(B/8) * nblk), 256 threads, requires chunk <= kStageRecs.
 constexpr int kStageRecs = 2048;
 __host__ __device__ inline size_t fused_scatter_lds_bytes(int H) {
-    return (size_t)(kWaves + 3) * H * sizeof(uint32_t) + (size_t)kStageRecs * sizeof(Rec);
+    return (size_t)(kBinWaves + 3) * H * sizeof(uint32_t) + (size_t)kStageRecs * sizeof(Rec);
 }
 
-__global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                                int B, int H, int W, int chunk, int nblk,
                                                                const uint32_t *__restrict__ table,
                                                                const BlockStats *__restrict__ stats,
@@ -304,12 +310,12 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
                                                                Rec *__restrict__ sorted1) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Rec *stage = reinterpret_cast<Rec *>(smem_raw);                          // [kStageRecs]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(stage + kStageRecs);        // [kWaves][H] per-wave counts -> local bases
-    uint32_t *rowtot = cnt + kWaves * H;                                     // [H] window row totals -> row starts
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(stage + kStageRecs);        // [kBinWaves][H] per-wave counts -> local bases
+    uint32_t *rowtot = cnt + kBinWaves * H;                                     // [H] window row totals -> row starts
     uint32_t *lbase = rowtot + H;                                            // [H] this block's row counts -> local starts
     uint32_t *delta = lbase + H;                                             // [H] global minus local position
-    __shared__ BlockStats wstats[kWaves];
-    __shared__ uint32_t tmp[8];
+    __shared__ BlockStats wstats[kBinWaves];
+    __shared__ uint32_t tmp[kBinWaves];
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
     const int nb = (int)((n + chunk - 1) / chunk);
     if (n <= 0) {  // empty window: block 0 still publishes its (empty) rows and status
         uint32_t *ro = row_off + (size_t)b * (H + 1);
-        for (int r = threadIdx.x; r <= H; r += kThreads) ro[r] = (uint32_t)beg;
+        for (int r = threadIdx.x; r <= H; r += kBinThreads) ro[r] = (uint32_t)beg;
         if (threadIdx.x == 0) {
             WindowMeta m;
             m.tmin = INT32_MAX; m.tmax = INT32_MIN; m.xmin = INT32_MAX; m.xmax = INT32_MIN; m.ymin = INT32_MAX; m.ymax = INT32_MIN;
@@ -332,9 +338,9 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
     const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
     const int64_t nloc = hi - lo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wlo = lo + nloc * wave / kWaves, whi = lo + nloc * (wave + 1) / kWaves;
+    const int64_t wlo = lo + nloc * wave / kBinWaves, whi = lo + nloc * (wave + 1) / kBinWaves;
     const int64_t HW = (int64_t)H * W;
-    for (int i = threadIdx.x; i < kWaves * H; i += kThreads) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kBinWaves * H; i += kBinThreads) cnt[i] = 0;
     __syncthreads();
     // the wave's events stay in registers from counting to placement (chunk <= 2048: <= 8 per lane)
     uint32_t *mycnt = cnt + wave * H;
@@ -355,13 +361,13 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
     if (blk == 0) {
         BlockStats st;
         stats_identity(st);
-        for (int k = threadIdx.x; k < nb; k += kThreads) stats_merge(st, stats[(size_t)b * nblk + k]);
+        for (int k = threadIdx.x; k < nb; k += kBinThreads) stats_merge(st, stats[(size_t)b * nblk + k]);
         stats_wave_reduce(st);
         if (lane == 0) wstats[wave] = st;
     }
     __syncthreads();
     // per row: this window's total, the part that lies in earlier blocks, this block's own count
-    for (int r = threadIdx.x; r < H; r += kThreads) {
+    for (int r = threadIdx.x; r < H; r += kBinThreads) {
         uint32_t tot = 0, before = 0;
         for (int b0 = 0; b0 < nb; b0 += kRegBatch) {
             uint32_t v[kRegBatch];
@@ -374,36 +380,36 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
         delta[r] = before;  // (parked here until the scans are done)
         uint32_t own = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) own += cnt[w * H + r];
+        for (int w = 0; w < kBinWaves; ++w) own += cnt[w * H + r];
         lbase[r] = own;
     }
     __syncthreads();
     // two exclusive scans over the rows: window totals -> row starts, own counts -> local starts
-    const int per = (H + kThreads - 1) / kThreads;
+    const int per = (H + kBinThreads - 1) / kBinThreads;
     const int r0 = threadIdx.x * per;
     uint32_t loc_t = 0, loc_o = 0;
     for (int k = 0; k < per; ++k) if (r0 + k < H) { loc_t += rowtot[r0 + k]; loc_o += lbase[r0 + k]; }
     uint32_t total_t, total_o;
-    uint32_t run_t = block_exclusive_scan(loc_t, tmp, &total_t);
-    uint32_t run_o = block_exclusive_scan(loc_o, tmp, &total_o);
+    uint32_t run_t = block_exclusive_scan<kBinWaves>(loc_t, tmp, &total_t);
+    uint32_t run_o = block_exclusive_scan<kBinWaves>(loc_o, tmp, &total_o);
     for (int k = 0; k < per; ++k)
         if (r0 + k < H) {
             const uint32_t t = rowtot[r0 + k]; rowtot[r0 + k] = run_t; run_t += t;
             const uint32_t o = lbase[r0 + k];  lbase[r0 + k] = run_o;  run_o += o;
         }
     __syncthreads();
-    for (int r = threadIdx.x; r < H; r += kThreads) {
+    for (int r = threadIdx.x; r < H; r += kBinThreads) {
         const uint32_t gstart = (uint32_t)beg + rowtot[r] + delta[r];
         uint32_t base = lbase[r];
         delta[r] = gstart - base;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) { const uint32_t t = cnt[w * H + r]; cnt[w * H + r] = base; base += t; }
+        for (int w = 0; w < kBinWaves; ++w) { const uint32_t t = cnt[w * H + r]; cnt[w * H + r] = base; base += t; }
         if (blk == 0) row_off[(size_t)b * (H + 1) + r] = (uint32_t)beg + rowtot[r];
     }
     if (blk == 0 && threadIdx.x == 0) {
         row_off[(size_t)b * (H + 1) + H] = (uint32_t)beg + total_t;
         BlockStats t = wstats[0];
-        for (int w = 1; w < kWaves; ++w) stats_merge(t, wstats[w]);
+        for (int w = 1; w < kBinWaves; ++w) stats_merge(t, wstats[w]);
         WindowMeta m;
         m.tmin = t.tmin; m.tmax = t.tmax; m.xmin = t.xmin; m.xmax = t.xmax; m.ymin = t.ymin; m.ymax = t.ymax;
         m.neg_flags = t.neg_flags; m.oob_flags = t.oob_flags; m.status = t.status; m.n_valid = t.n_valid;
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void k_row_scatter_fused(const int4 *__re
     }
     __syncthreads();
     // write-out: consecutive lanes hold consecutive records of a row
-    for (uint32_t t = threadIdx.x; t < total_o; t += kThreads) {
+    for (uint32_t t = threadIdx.x; t < total_o; t += kBinThreads) {
         const Rec rec = stage[t];
         const uint32_t row = (uint32_t)rec.x / (uint32_t)W;
         sorted1[delta[row] + t] = rec;

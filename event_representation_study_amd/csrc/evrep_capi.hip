@@ -92,17 +92,17 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     Rec *s2 = WS(Rec, off_sorted2);
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
-    k_row_hist<<<xgrid, kThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
+    k_row_hist<<<xgrid, kBinThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
     if (chunk <= kStageRecs && fused_scatter_lds_bytes(H) <= 65536 && !getenv("EVREP_NO_FUSED_SCATTER")) {
         // scan fused into the scatter (one kernel and one launch boundary fewer)
-        k_row_scatter_fused<<<xgrid, kThreads, fused_scatter_lds_bytes(H), stream>>>(ev, offsets, B, H, W, chunk, nblk, table,
+        k_row_scatter_fused<<<xgrid, kBinThreads, fused_scatter_lds_bytes(H), stream>>>(ev, offsets, B, H, W, chunk, nblk, table,
                                                                                      stats, row_off, meta, s1);
         LAUNCH_CHECK("k_row_scatter_fused");
     } else {
-        k_row_scan<<<B, kThreads, (size_t)H * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
+        k_row_scan<<<B, kBinThreads, (size_t)H * 4, stream>>>(offsets, H, chunk, nblk, table, row_off, stats, meta);
         LAUNCH_CHECK("k_row_scan");
-        k_row_scatter<<<xgrid, kThreads, (size_t)kWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
+        k_row_scatter<<<xgrid, kBinThreads, (size_t)kBinWaves * H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, row_off, s1);
         LAUNCH_CHECK("k_row_scatter");
     }
     k_col_sort<<<dim3(H, B), kWave, (size_t)W * 4, stream>>>(s1, row_off, H, W, plan->nchunk, s2, WS(uint32_t, off_chunkoff));

@@ -76,8 +76,9 @@ __device__ inline int bits_for(int n) {  // bits needed to represent values in [
     return b;
 }
 
-// Exclusive scan of one uint32 per thread across a 256-thread workgroup. tmp: >= 8 uint32 of LDS.
+// Exclusive scan of one uint32 per thread across a workgroup of NW waves. tmp: >= NW uint32 of LDS.
 // Returns the exclusive prefix; *total receives the workgroup sum.  Contains __syncthreads().
+template <int NW = kWaves>
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -90,7 +91,7 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
+    for (int w = 0; w < NW; ++w) {
         uint32_t t = tmp[w];
         if (w < wave) base += t;
         tot += t;
