@@ -39,6 +39,9 @@ constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kMaxSegs = 2 * kChunkPx;      // TORE's shifted frame can straddle two sensor chunks
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
+// float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
+// wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
+// average record count per chunk, see builder_span() in evrep_capi.hip.
 
 // LDS carve of one builder wave.
 template <typename OutT>
@@ -129,18 +132,20 @@ struct ChunkGeom {
     uint32_t cs, ce;
 };
 
-// grid (nchunk, H, B): unit -> (window, sensor row, 128-pixel chunk) and its record range.
-__device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk) {
+// grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks) and
+// its record range.  span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
+__device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk, int span = 1) {
     ChunkGeom g;
+    const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
-    const int chunk = u % nchunk;
-    g.row = (u / nchunk) % H;
-    g.b = (u / nchunk) / H;
+    const int chunk = (u % nunit) * span;
+    g.row = (u / nunit) % H;
+    g.b = (u / nunit) / H;
     g.c0 = chunk * kChunkPx;
-    g.npix = min(kChunkPx, W - g.c0);
+    g.npix = min(span * kChunkPx, W - g.c0);
     const uint32_t *co = chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
     g.cs = co[chunk];
-    g.ce = co[chunk + 1];
+    g.ce = co[min(chunk + span, nchunk)];
     return g;
 }
 
@@ -281,12 +286,12 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 template <typename OutT, typename D>
 __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
                                                const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
-                                               MdesParams P, int H, int W, int nchunk, double scale,
+                                               MdesParams P, int H, int W, int nchunk, int span, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
     WaveLds<OutT> w(smem, C);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
 
@@ -386,11 +391,11 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
-                                                      const int64_t *__restrict__ off, int H, int W, int nchunk, int S,
-                                                      int premap, float scale, float *__restrict__ out) {
+                                                      const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
+                                                      int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<float> w(smem, S);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
@@ -504,12 +509,12 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 
 template <typename OutT>
 __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
-                                                       const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int S,
-                                                       double tau, int premap, double scale, OutT *__restrict__ out) {
+                                                       const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int span,
+                                                       int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
     WaveLds<OutT> w(smem, C);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];

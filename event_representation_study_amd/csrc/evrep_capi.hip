@@ -112,6 +112,15 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
 
 #define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
 
+// 128-pixel chunks one builder wave takes: 2 for float32 outputs on sparse windows (<= 30 records per
+// chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel fast path), else 1.
+static int builder_span(const evrep_plan *plan, size_t elem) {
+    if (elem != 4 || plan->nchunk < 2) return 1;
+    const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    return per_chunk <= 30.0 ? 2 : 1;
+}
+#define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
+
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
                const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
                void *out, void *stream_) {
@@ -128,10 +137,11 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     bool ergo = C == Ergo12Table::kC;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
+    const int span = builder_span(plan, out_dtype == EVREP_F64 ? 8 : 4);
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<BUILDER_GRID, kWave, chunk_lds_bytes(C, sizeof(T)), stream>>>(                                           \
+    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T)), stream>>>(                              \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
-        plan->nchunk, scale, static_cast<T *>(out))
+        plan->nchunk, span, scale, static_cast<T *>(out))
     if (out_dtype == EVREP_F64) {
         if (ergo) MDES_LAUNCH(double, StaticDesc<Ergo12Table>); else MDES_LAUNCH(double, RuntimeDesc);
     } else {
@@ -155,9 +165,10 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_event_stack<<<BUILDER_GRID, kWave, chunk_lds_bytes(stack_size, 4), stream>>>(
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, stack_size, premap,
-        scale, out);
+    const int span = builder_span(plan, 4);
+    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4), stream>>>(
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
+        premap, scale, out);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
 }
@@ -175,11 +186,12 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
         k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
-        k_time_surface<float><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 4), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, slices, tau,
+        const int span = builder_span(plan, 4);
+        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4), stream>>>(
+            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
             premap, scale, static_cast<float *>(out));
     }
     LAUNCH_CHECK("k_time_surface");
