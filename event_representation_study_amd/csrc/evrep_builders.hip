@@ -37,7 +37,7 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #endif
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
-constexpr int kMaxSegs = 2 * kChunkPx;      // TORE's shifted frame can straddle two sensor chunks
+constexpr int kMaxSegs = 3 * kChunkPx;      // a 2-chunk unit of TORE's shifted frame can straddle three sensor chunks
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
@@ -580,18 +580,19 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
 // --------------------------------------------------------------------------------------------
 constexpr int kMaxToreK = 8;
 
-// grid (ceil(W/128), H, B) over OUTPUT chunks / rows, 64 threads.
+// grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
 __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
                                                const WindowMeta *__restrict__ meta, const int32_t *__restrict__ sample_times,
-                                               int H, int W, int nchunk, int K, int frame_mode, float scale,
+                                               int H, int W, int nchunk, int span, int K, int frame_mode, float scale,
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * K;
     WaveLds<float> w(smem, C);
+    const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
-    const int b = (u / nchunk) / H, orow = (u / nchunk) % H, oc0 = (u % nchunk) * kChunkPx;
+    const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
     if (n_win <= 0) return;
@@ -600,10 +601,10 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     if (frame_mode == 0 || frame_mode == 1) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
     if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
     if (orow >= Hf || oc0 >= Wf) return;
-    const int npix = min(kChunkPx, Wf - oc0);
+    const int npix = min(span * kChunkPx, Wf - oc0);
     const int row = orow + y0;  // sensor row feeding this output row
     const int T = sample_times ? sample_times[b] : ev[beg + n_win - 1].z;
-    // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle two sensor chunks
+    // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
     uint32_t cs = 0, ce = 0;
     const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
     if (row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
@@ -673,11 +674,11 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                 const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
-                                                int H, int W, int nchunk, int bins, int mode, double scale,
+                                                int H, int W, int nchunk, int span, int bins, int mode, double scale,
                                                 double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<double> w(smem, bins);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];

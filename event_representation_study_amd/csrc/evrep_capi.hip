@@ -112,10 +112,10 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
 
 #define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
 
-// 128-pixel chunks one builder wave takes: 2 for float32 outputs on sparse windows (<= 30 records per
+// 128-pixel chunks one builder wave takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on sparse windows (<= 30 records per
 // chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel fast path), else 1.
-static int builder_span(const evrep_plan *plan, size_t elem) {
-    if (elem != 4 || plan->nchunk < 2) return 1;
+static int builder_span(const evrep_plan *plan, size_t pixel_bytes) {
+    if (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) return 1;  // a 128-pixel chunk is already >= 8 KB
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
     return per_chunk <= 30.0 ? 2 : 1;
 }
@@ -137,7 +137,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     bool ergo = C == Ergo12Table::kC;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
-    const int span = builder_span(plan, out_dtype == EVREP_F64 ? 8 : 4);
+    const int span = builder_span(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
 #define MDES_LAUNCH(T, DESC)                                                                                          \
     k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T)), stream>>>(                              \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
@@ -165,7 +165,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, 4);
+    const int span = builder_span(plan, (size_t)stack_size * 4);
     k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4), stream>>>(
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
         premap, scale, out);
@@ -189,7 +189,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
-        const int span = builder_span(plan, 4);
+        const int span = builder_span(plan, (size_t)2 * slices * 4);
         k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4), stream>>>(
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
             premap, scale, static_cast<float *>(out));
@@ -204,9 +204,10 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
     if (rc) return rc;
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_tore<<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * k, 4), stream>>>(
+    const int span = builder_span(plan, (size_t)2 * k * 4);
+    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
-        CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, k, frame_mode, scale, out);
+        CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, span, k, frame_mode, scale, out);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
 }
@@ -217,9 +218,10 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     if (rc) return rc;
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    k_voxel<<<BUILDER_GRID, kWave, chunk_lds_bytes(bins, 8), stream>>>(
+    const int span = builder_span(plan, (size_t)bins * 8);
+    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
-        plan->W, plan->nchunk, bins, mode, scale, out);
+        plan->W, plan->nchunk, span, bins, mode, scale, out);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }
