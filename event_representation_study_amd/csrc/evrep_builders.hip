@@ -159,7 +159,9 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
                                   OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
     const int lane = threadIdx.x;
     const uint32_t nrec = ce - cs;
-    tile_fill(w.tile, min(kPartPx, npix), C, bg);
+    // a zero tile is filled at once (it overlaps the record load); a background that had to be
+    // loaded is filled after the segment heads are listed, when it has arrived behind the records
+    if (!bg || nrec == 0) tile_fill(w.tile, min(kPartPx, npix), C, bg);
     if (nrec == 0) {  // empty chunk: the same background tile is streamed for every part
         wave_phase();
         for (int part = 0; part * kPartPx < npix; ++part)
@@ -191,6 +193,7 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
         if (nseg > kMaxSegs) nseg = kMaxSegs;  // cannot happen: at most 2*kChunkPx distinct pixels are ever listed
         if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
     }
+    if (bg) tile_fill(w.tile, min(kPartPx, npix), C, bg);
     wave_phase();
     const Rec *evbuf = w.evbuf;
     auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kEvStage ? evbuf[j] : sorted[cs + j]; };
@@ -453,13 +456,14 @@ struct TsCuts {
     int32_t tcut[kMaxSlices];  // t[idx[s]]
     int32_t live[kMaxSlices];  // 1 iff the sequential scan reaches this slice (strictly increasing idx)
     int32_t pad[8];
+    double bg[2 * kMaxSlices];  // value of an untouched (pixel, polarity) entry of slice s, already scaled
 };
-static_assert(sizeof(TsCuts) == 128, "TsCuts");
+static_assert(sizeof(TsCuts) == 256, "TsCuts");
 
 // grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
 // int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
 __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
-                          const int32_t *__restrict__ indices, TsCuts *__restrict__ cuts) {
+                          const int32_t *__restrict__ indices, double tau, double scale, TsCuts *__restrict__ cuts) {
     const int b = blockIdx.x, s = threadIdx.x;
     __shared__ int sidx[kMaxSlices];
     const int64_t beg = off[b];
@@ -503,6 +507,12 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
                 cuts[b].idx[k] = 0;
                 cuts[b].tcut[k] = 0;
             }
+            // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau)  (time_surface.py:26-29,68-72);
+            // slices the scan never reaches stay exactly 0
+            double v = 0.0;
+            if (k < S && alive) v = exp_neg_range((-(tau * 3.0 + 1.0) - (double)cuts[b].tcut[k]) * (1.0 / tau)) * scale;
+            cuts[b].bg[2 * k] = v;
+            cuts[b].bg[2 * k + 1] = v;
         }
     }
 }
@@ -523,14 +533,11 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
     struct { int idx[kMaxSlices], tcut[kMaxSlices], live[kMaxSlices]; } cu;
 #pragma unroll
     for (int q = 0; q < kMaxSlices; ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
-    const double init = -(tau * 3.0 + 1.0);  // timestamp_memory -= tau*3 + 1 (time_surface.py:29)
-    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) {
-        const int s = threadIdx.x >> 1;
-        double v = 0.0;
-        // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau); slices the scan never reaches are
-        if ((int)threadIdx.x < C && cp->live[s]) { const double d = init - (double)cp->tcut[s]; v = exp_neg_range(d / tau) * scale; }
-        w.bg[threadIdx.x] = (OutT)v;
-    }
+    // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
+    // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
+    const double inv_tau = 1.0 / tau;
+    // the background of every slice was computed once per window by k_ts_cuts
+    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
     wave_phase();
     const OutT *bg = w.bg;
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[EVREP_MAX_CHANNELS]) {
@@ -560,11 +567,11 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
             if (q < S && cu.live[q]) {
                 const double tc = (double)cu.tcut[q];
                 if (__any(snap0[q] != INT32_MIN)) {
-                    const double e0 = exp_neg_range(((double)snap0[q] - tc) / tau) * scale;
+                    const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
                     if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
                 }
                 if (__any(snap1[q] != INT32_MIN)) {
-                    const double e1 = exp_neg_range(((double)snap1[q] - tc) / tau) * scale;
+                    const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
                     if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
                 }
             }

@@ -182,7 +182,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TsCuts *cuts = WS(TsCuts, off_cuts);
-    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, cuts);
+    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
         k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8), stream>>>(
