@@ -1,0 +1,114 @@
+"""-m gpu: randomized geometry / density sweep of every builder against the oracle, aimed at the
+internal boundaries of the HIP path (64-record LDS stage, 64-segment fast path, 256-record column-sort
+batches, 2048-event partition blocks, part tiles, two-chunk units, ragged batches)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+from event_representation_study_amd.synthetic import make_events
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_all(eng, oracle, wins, H, W, tag):
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    opt = eb.optimized().cpu().numpy()
+    opt32 = eb.optimized(dtype=__import__("torch").float32).cpu().numpy()
+    es = eb.event_stack().cpu().numpy()
+    ts = eb.time_surface().cpu().numpy()
+    tore_full = eb.tore(6, frame_mode=2).cpu().numpy()
+    vox = eb.voxel(5).cpu().numpy()
+    for b, ev in enumerate(wins):
+        if ev.shape[0] == 0:
+            continue
+        ref = oracle.ergo12(ev, H, W)
+        assert_bit_equal(opt[b], ref, "%s ergo12 w%d" % (tag, b))
+        assert_bit_equal(opt32[b], ref.astype(np.float32), "%s ergo12 f32 w%d" % (tag, b))
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "%s event_stack w%d" % (tag, b))
+        if ev.shape[0] >= 2 and ev[-1, 2] != ev[0, 2]:
+            np.testing.assert_allclose(ts[b], oracle.time_surface(ev, H, W), rtol=1e-12, err_msg="%s ts w%d" % (tag, b))
+            assert_bit_equal(vox[b], oracle.voxel(ev, H, W, 5), "%s voxel w%d" % (tag, b))
+        # full-frame TORE (frame_mode 2) against the oracle's 1-based entry point
+        want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
+        np.testing.assert_allclose(tore_full[b], want, rtol=1e-6, atol=1e-6, err_msg="%s tore w%d" % (tag, b))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometry_and_density(seed, oracle):
+    from event_representation_study_amd import engine as eng
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 300, 640]))
+    H = int(rng.integers(1, 40))
+    B = int(rng.integers(1, 6))
+    dens = float(rng.choice([0.02, 0.16, 0.5, 1.0, 4.0]))          # events per pixel
+    wins = []
+    for b in range(B):
+        n = max(1, int(dens * W * H * rng.uniform(0.5, 1.5)))
+        if rng.random() < 0.15:
+            n = int(rng.choice([1, 2, 3, 63, 64, 65, 2047, 2048, 2049]))
+        wins.append(make_events(n, W, H, seed=7 * seed + b, polarity="pm1" if rng.random() < 0.5 else "01",
+                                span_us=int(rng.choice([3, 1000, 50000]))))
+    _check_all(eng, oracle, wins, H, W, "seed%d %dx%d" % (seed, W, H))
+
+
+@pytest.mark.parametrize("per_chunk", [63, 64, 65, 127, 128, 129])
+def test_records_per_chunk_boundaries(per_chunk, oracle):
+    """Exactly `per_chunk` records in one 128-pixel chunk: the LDS stage (64) and one-lane-per-pixel (64 segments) edges."""
+    from event_representation_study_amd import engine as eng
+    H, W = 3, 256
+    rng = np.random.default_rng(per_chunk)
+    n = per_chunk
+    ev = np.zeros((n, 4), np.int32)
+    ev[:, 0] = rng.permutation(128)[:n] if n <= 128 else np.concatenate([np.arange(128), rng.integers(0, 128, n - 128)])
+    ev[:, 1] = 1
+    ev[:, 2] = np.arange(n) * 3
+    ev[:, 3] = rng.choice([-1, 1], n)
+    _check_all(eng, oracle, [ev], H, W, "chunk%d" % per_chunk)
+
+
+@pytest.mark.parametrize("per_row", [255, 256, 257, 511, 513, 1500])
+def test_records_per_row_boundaries(per_row, oracle):
+    """Row lengths around the column sort's 256-record register batches."""
+    from event_representation_study_amd import engine as eng
+    H, W = 4, 96
+    rng = np.random.default_rng(per_row)
+    n = per_row + 40
+    ev = np.zeros((n, 4), np.int32)
+    ev[:, 0] = rng.integers(0, W, n)
+    ev[:, 1] = 2
+    ev[rng.choice(n, 40, replace=False), 1] = rng.integers(0, H, 40)
+    ev[:, 2] = np.sort(rng.integers(0, 5000, n))
+    ev[:, 3] = rng.choice([-1, 1], n)
+    _check_all(eng, oracle, [ev], H, W, "row%d" % per_row)
+
+
+def test_window_sizes_around_partition_blocks(oracle):
+    """Windows of 2047..4097 events: the 2048-event partition blocks and their wave quarters."""
+    from event_representation_study_amd import engine as eng
+    H, W = 30, 40
+    wins = [make_events(n, W, H, seed=n) for n in (2047, 2048, 2049, 4095, 4096, 4097, 511, 513)]
+    _check_all(eng, oracle, wins, H, W, "blocks")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_tore_frame_modes(seed, oracle):
+    """frame_mode 0 (bounding box, the dispatcher) and 1 (full frame, origin-shifted: n_imagenet's call) with
+    events confined to a sub-rectangle, so the shift straddles chunk boundaries."""
+    from event_representation_study_amd import engine as eng
+    rng = np.random.default_rng(seed)
+    H, W = 50, 700
+    x0, y0 = int(rng.integers(1, 300)), int(rng.integers(1, 20))
+    wbb, hbb = int(rng.integers(130, 390)), int(rng.integers(5, 25))
+    n = 6000
+    ev = make_events(n, wbb, hbb, seed=seed + 50)
+    ev[:, 0] += x0
+    ev[:, 1] += y0
+    eb = eng.EventBatch.from_numpy(ev, H, W)
+    got0 = eb.tore(6, frame_mode=0)[0].cpu().numpy()
+    np.testing.assert_allclose(got0, oracle.tore_bbox(ev, 6), rtol=1e-6, atol=1e-6)
+    got1 = eb.tore(6, frame_mode=1)[0].cpu().numpy()
+    x = ev[:, 0] - ev[:, 0].min() + 1
+    y = ev[:, 1] - ev[:, 1].min() + 1
+    want1 = oracle.tore(x, y, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
+    np.testing.assert_allclose(got1, want1, rtol=1e-6, atol=1e-6)
