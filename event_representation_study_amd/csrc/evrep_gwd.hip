@@ -103,43 +103,27 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict_
     }
 }
 
+// Squared distances of an 8 x 4 block of (row point, column point) pairs, coordinates in LDS
+// (dimension-major).  D > 0: compile-time dimension count; D == 0: runtime `d`.
 template <int D>
-__device__ inline void tile_accumulate(const float *__restrict__ A, const float *__restrict__ Bm, int lds_stride,
-                                       int ti, int tj, float (&acc)[8][8]) {
-    // A: LDS [D][kTile] row points, Bm: LDS [D][kTile] column points; thread owns rows ti*8.., cols tj*8..
+__device__ inline void block_sqdist(const float *__restrict__ A, const float *__restrict__ Bm, int d, int r0, int c0,
+                                    float (&acc)[8][4]) {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
-    for (int k = 0; k < D; ++k) {
-        float a[8], b[8];
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+    const int nd = D > 0 ? D : d;
+#pragma unroll 2
+    for (int k = 0; k < nd; ++k) {
+        float a[8], b[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = A[k * lds_stride + ti * 8 + r];
+        for (int r = 0; r < 8; ++r) a[r] = A[k * kTile + r0 + r];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = Bm[k * lds_stride + tj * 8 + c];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { const float u = a[r] - b[c]; acc[r][c] = fmaf(u, u, acc[r][c]); }
-    }
-}
-
-__device__ inline void tile_accumulate_rt(const float *__restrict__ A, const float *__restrict__ Bm, int lds_stride,
-                                          int D, int ti, int tj, float (&acc)[8][8]) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;
-    for (int k = 0; k < D; ++k) {
-        float a[8], b[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = A[k * lds_stride + ti * 8 + r];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = Bm[k * lds_stride + tj * 8 + c];
+        for (int c = 0; c < 4; ++c) b[c] = Bm[k * kTile + c0 + c];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { const float u = a[r] - b[c]; acc[r][c] = fmaf(u, u, acc[r][c]); }
+            for (int c = 0; c < 4; ++c) { const float u = a[r] - b[c]; acc[r][c] = fmaf(u, u, acc[r][c]); }
     }
 }
 
@@ -169,35 +153,36 @@ __global__ __launch_bounds__(kThreads) void k_gwd_tiles(const float *__restrict_
             Bt[e] = Yt[(int64_t)k * mpad + j0 + i];
         }
     __syncthreads();
+    // each thread owns 8 rows x 8 columns of the tile, evaluated as two 8 x 4 halves so that only
+    // 64 accumulators are live at a time (more waves per SIMD hide the exp2 / LDS latencies)
     const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-    float ks[8][8], kt[8][8];
-    if (has_s) {
-        if (ds == 4) tile_accumulate<4>(As, Bs, kTile, ti, tj, ks);
-        else tile_accumulate_rt(As, Bs, kTile, ds, ti, tj, ks);
-    }
-    if (has_t) {
-        if (dt == 14) tile_accumulate<14>(At, Bt, kTile, ti, tj, kt);
-        else tile_accumulate_rt(At, Bt, kTile, dt, ti, tj, kt);
-    }
     float sum = 0.0f;
     const int64_t lim = n < m ? n : m;
-    if (j0 + kTile <= lim) {  // interior tile: every entry exists in both kernels
+    const bool interior = j0 + kTile <= lim;  // every entry exists in both kernels
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int r0 = ti * 8, c0 = tj * 8 + half * 4;
+        float ks[8][4], kt[8][4];
+        if (has_s) { if (ds == 4) block_sqdist<4>(As, Bs, ds, r0, c0, ks); else block_sqdist<0>(As, Bs, ds, r0, c0, ks); }
+        if (has_t) { if (dt == 14) block_sqdist<14>(At, Bt, dt, r0, c0, kt); else block_sqdist<0>(At, Bt, dt, r0, c0, kt); }
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                sum += fabsf(__builtin_amdgcn_exp2f(-ks[r][c]) - __builtin_amdgcn_exp2f(-kt[r][c]));
-    } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
-        const int64_t gi0 = i0 + ti * 8, gj0 = j0 + tj * 8;
+                for (int c = 0; c < 4; ++c)
+                    sum += fabsf(__builtin_amdgcn_exp2f(-ks[r][c]) - __builtin_amdgcn_exp2f(-kt[r][c]));
+        } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
+            const int64_t gi0 = i0 + r0, gj0 = j0 + c0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int64_t gi = gi0 + r, gj = gj0 + c;
-                const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(-ks[r][c]) : 0.0f;
-                const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(-kt[r][c]) : 0.0f;
-                sum += fabsf(a - bb);
-            }
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t gi = gi0 + r, gj = gj0 + c;
+                    const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(-ks[r][c]) : 0.0f;
+                    const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(-kt[r][c]) : 0.0f;
+                    sum += fabsf(a - bb);
+                }
+        }
     }
     __shared__ double red[kThreads];
     red[threadIdx.x] = (double)sum;
