@@ -37,7 +37,6 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #endif
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
-constexpr int kMaxSegs = 3 * kChunkPx;      // a 2-chunk unit of TORE's shifted frame can straddle three sensor chunks
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
@@ -50,18 +49,20 @@ struct WaveLds {
     OutT *bg;     // EVREP_MAX_CHANNELS background values (the empty-pixel value of every channel)
     uint2 *segs;  // (pixel offset inside the chunk, first record index); entry nseg = sentinel
     Rec *evbuf;   // the chunk's first kEvStage records
-    __device__ WaveLds(unsigned char *smem, int C) {
+    int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
+    __device__ WaveLds(unsigned char *smem, int C, int segcap_) : segcap(segcap_) {
         size_t o = 0;
         tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)kPartPx * C * sizeof(OutT));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
-        segs = reinterpret_cast<uint2 *>(smem + o); o += align16((size_t)(kMaxSegs + 1) * sizeof(uint2));
-        evbuf = reinterpret_cast<Rec *>(smem + o);
+        evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)kEvStage * sizeof(Rec);
+        segs = reinterpret_cast<uint2 *>(smem + o);
     }
 };
 
-__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem) {
+// segcap = pixels one unit can touch: span * kChunkPx (+ kChunkPx for TORE's shifted frame)
+__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap) {
     return align16((size_t)kPartPx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
-           align16((size_t)(kMaxSegs + 1) * sizeof(uint2)) + (size_t)kEvStage * sizeof(Rec);
+           (size_t)kEvStage * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
 }
 
 // Ordering point between LDS phases of a ONE-WAVE workgroup.  LDS operations of a wave execute in
@@ -185,12 +186,12 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
             const uint64_t hm = __ballot(head);
             if (head) {
                 const int idx = nseg + __popcll(hm & ((1ull << lane) - 1ull));
-                if (idx < kMaxSegs) w.segs[idx] = make_uint2((uint32_t)(key - key0), j);
+                if (idx < w.segcap) w.segs[idx] = make_uint2((uint32_t)(key - key0), j);
             }
             nseg += __popcll(hm);
             carry = __shfl(key, 63, 64);
         }
-        if (nseg > kMaxSegs) nseg = kMaxSegs;  // cannot happen: at most 2*kChunkPx distinct pixels are ever listed
+        if (nseg > w.segcap) nseg = w.segcap;  // cannot happen: a unit never holds more distinct pixels
         if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
     }
     if (bg) tile_fill(w.tile, min(kPartPx, npix), C, bg);
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
-    WaveLds<OutT> w(smem, C);
+    WaveLds<OutT> w(smem, C, span * kChunkPx);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<float> w(smem, S);
+    WaveLds<float> w(smem, S, span * kChunkPx);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
-    WaveLds<OutT> w(smem, C);
+    WaveLds<OutT> w(smem, C, span * kChunkPx);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * K;
-    WaveLds<float> w(smem, C);
+    WaveLds<float> w(smem, C, (span + 1) * kChunkPx);
     const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
     const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
                                                 int H, int W, int nchunk, int span, int bins, int mode, double scale,
                                                 double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<double> w(smem, bins);
+    WaveLds<double> w(smem, bins, span * kChunkPx);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
     Rec r0 = make_int4(INT32_MIN, 0, 0, 0);

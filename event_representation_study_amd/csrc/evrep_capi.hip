@@ -139,7 +139,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
     const int span = builder_span(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T)), stream>>>(                              \
+    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx), stream>>>(                              \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
         plan->nchunk, span, scale, static_cast<T *>(out))
     if (out_dtype == EVREP_F64) {
@@ -166,7 +166,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)stack_size * 4);
-    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4), stream>>>(
+    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx), stream>>>(
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
         premap, scale, out);
     LAUNCH_CHECK("k_event_stack");
@@ -185,12 +185,12 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
-        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8), stream>>>(
+        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8, kChunkPx), stream>>>(
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
         const int span = builder_span(plan, (size_t)2 * slices * 4);
-        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4), stream>>>(
+        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4, span * kChunkPx), stream>>>(
             CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
             premap, scale, static_cast<float *>(out));
     }
@@ -205,7 +205,7 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)2 * k * 4);
-    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4), stream>>>(
+    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
         CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, span, k, frame_mode, scale, out);
     LAUNCH_CHECK("k_tore");
@@ -219,7 +219,7 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)bins * 8);
-    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8), stream>>>(
+    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
         plan->W, plan->nchunk, span, bins, mode, scale, out);
     LAUNCH_CHECK("k_voxel");
