@@ -1,0 +1,116 @@
+"""The caller side of the GWD score: representation -> keep-ratio resize ->
+letterbox(114) -> ``otmi(events, rep)`` -> C_p, as ``Gen1H5GWD.__getitem__`` + ``measure_otmi`` do
+(representations/representation_search/gen1_compute.py:30-104, ev-YOLOv6/yolov6/data/gen1_2yolo.py:230-265,
+ev-YOLOv6/yolov6/data/data_augment.py:31-85).
+
+The reference resizes with OpenCV (``cv2.resize`` INTER_AREA per channel when shrinking, INTER_LINEAR
+otherwise).  OpenCV is absent here, so the two interpolations are RESTATED from OpenCV's published
+algorithm (resize.cpp: ``computeResizeAreaTab`` / ``resizeArea_`` and the half-pixel-centre bilinear
+table) as separable weight matrices applied on the GPU in float64 -- PARITY UNPINNED against cv2 itself
+(different accumulation order; expected agreement ~1e-15 relative).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import distributed
+from .representations.representation_search.compute_otmi import otmi
+
+
+def area_weights(src, dst):
+    """(dst, src) float64 matrix of OpenCV's INTER_AREA weights for shrinking ``src`` samples to ``dst``."""
+    scale = src / dst                                   # 1 / inv_scale, inv_scale = dsize / ssize
+    Wm = np.zeros((dst, src), dtype=np.float64)
+    for d in range(dst):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, src - f1)
+        s1 = math.ceil(f1)
+        s2 = min(math.floor(f2), src - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            Wm[d, s1 - 1] += (s1 - f1) / cell
+        for sx in range(s1, s2):
+            Wm[d, sx] += 1.0 / cell
+        if f2 - s2 > 1e-3:
+            Wm[d, s2] += min(min(f2 - s2, 1.0), cell) / cell
+    return Wm
+
+
+def linear_weights(src, dst):
+    """(dst, src) float64 matrix of OpenCV's INTER_LINEAR weights (half-pixel centres, edge clamp)."""
+    scale = src / dst
+    Wm = np.zeros((dst, src), dtype=np.float64)
+    for d in range(dst):
+        fx = (d + 0.5) * scale - 0.5
+        sx = math.floor(fx)
+        fx -= sx
+        if sx < 0:
+            sx, fx = 0, 0.0
+        if sx >= src - 1:
+            sx, fx = src - 1, 0.0
+        Wm[d, sx] += 1.0 - fx
+        if fx:
+            Wm[d, sx + 1] += fx
+    return Wm
+
+
+def resize(im, new_w, new_h, interpolation="area"):
+    """im: (H, W, C) tensor/array -> (new_h, new_w, C) float64 cuda tensor; every channel on its own, like
+    the reference's per-channel cv2.resize."""
+    t = torch.as_tensor(im).to("cuda", torch.float64)
+    H, W = int(t.shape[0]), int(t.shape[1])
+    fn = area_weights if interpolation == "area" else linear_weights
+    wy = torch.from_numpy(fn(H, new_h)).to(t.device)
+    wx = torch.from_numpy(fn(W, new_w)).to(t.device)
+    # out[y, x, c] = sum_{i,j} wy[y,i] * wx[x,j] * im[i,j,c]
+    return torch.einsum("yi,ijc,xj->yxc", wy, t, wx)
+
+
+def resize_image(im, img_size, augment=False):
+    """Gen1H5.resize_image (gen1_2yolo.py:230-265): keep-ratio resize so the long side is ``img_size``."""
+    h0, w0 = int(im.shape[0]), int(im.shape[1])
+    r = img_size / max(h0, w0)
+    if r == 1:
+        return torch.as_tensor(im).to("cuda", torch.float64)
+    interp = "area" if (r < 1 and not augment) else "linear"
+    return resize(im, int(w0 * r), int(h0 * r), interp)
+
+
+def letterbox(im, new_shape, color=114.0, scaleup=False):
+    """letterbox(..., auto=False) of data_augment.py:31-85: pad (and, if needed, bilinearly resize) to a
+    ``new_shape`` square with ``color``."""
+    h, w = int(im.shape[0]), int(im.shape[1])
+    r = min(new_shape / h, new_shape / w)
+    if not scaleup:
+        r = min(r, 1.0)
+    nw, nh = int(round(w * r)), int(round(h * r))
+    dw, dh = (new_shape - nw) / 2, (new_shape - nh) / 2
+    if (w, h) != (nw, nh):
+        im = resize(im, nw, nh, "linear")
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    t = torch.as_tensor(im).to("cuda", torch.float64)
+    out = torch.full((nh + top + bottom, nw + left + right, t.shape[2]), float(color), dtype=torch.float64, device=t.device)
+    out[top:top + nh, left:left + nw] = t
+    return out
+
+
+def rep_for_gwd(rep, img_size):
+    """Representation (H, W, C) -> the letterboxed (img_size, img_size, C) array ``otmi`` is given."""
+    return letterbox(resize_image(rep, img_size), img_size)
+
+
+def measure_cp(windows, build_rep, height, width, img_size=240):
+    """C_p of one representation over a list of raw (n, 4) int windows: per window
+    ``otmi(events, letterboxed rep)`` (mean of 3 quadrant solves), then the mean over windows
+    (gen1_compute.py:91-104).  Windows are dealt to the ranks of the current process group and the
+    per-window scalars are assembled with ONE all_gather."""
+    def score(ev):
+        rep = build_rep(ev)                                        # (H, W, C) tensor on the GPU
+        lb = rep_for_gwd(rep, img_size).cpu().numpy()
+        return float(otmi(torch.from_numpy(np.asarray(ev)), lb, height, width, img_size))
+
+    scores = distributed.sharded_scores(score, list(windows))
+    return float(scores.mean().item()), scores

@@ -210,3 +210,42 @@ def test_evlicious_voxel_grid():
         got = events_to_voxel_grid(e, 5, normalize=True)
         np.testing.assert_allclose(got, g[tag + "_norm5"], rtol=1e-5, atol=1e-6)   # float32 mean / std
         assert np.array_equal(got == 0, g[tag + "_norm5"] == 0)
+
+
+def test_gwd_caller_pipeline_f1():
+    """keep-ratio area resize + letterbox(114) + otmi -> C_p (resize restated from
+    OpenCV's published algorithm; parity unpinned: cv2 is absent)."""
+    import torch
+    from event_representation_study_amd import gwd_pipeline as gp
+    from event_representation_study_amd.engine import EventBatch
+    from event_representation_study_amd.representations.representation_search.compute_otmi import otmi
+    # 1. INTER_AREA weights = exact box integration of the piecewise-constant source
+    rng = np.random.default_rng(0)
+    for src, dst in ((304, 240), (240, 189), (33, 10)):
+        img = rng.random((src, 3))
+        scale = src / dst
+        want = np.zeros((dst, 3))
+        for d in range(dst):
+            lo, hi = d * scale, min((d + 1) * scale, src)
+            acc = np.zeros(3)
+            for sx in range(int(np.floor(lo)), int(np.ceil(hi))):
+                acc += img[sx] * (min(hi, sx + 1) - max(lo, sx))
+            want[d] = acc / (hi - lo)
+        got = gp.area_weights(src, dst) @ img
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=2e-3 * 0)   # identical up to the 1e-3 edge rule
+    # 2. shapes and padding of the Gen1 case: 240x304 -> 189x240 -> 240x240 with 25 / 26 rows of 114
+    H, W = 240, 304
+    ev = make_events(12000, W, H, seed=8)
+    rep = EventBatch.from_numpy(ev, H, W).optimized(scale=255.0)[0]
+    small = gp.resize_image(rep, 240)
+    assert tuple(small.shape) == (189, 240, 12)
+    np.testing.assert_allclose(float(small.sum()) / (189 * 240), float(rep.sum()) / (H * W), rtol=2e-3)  # area-preserving
+    lb = gp.rep_for_gwd(rep, 240)
+    assert tuple(lb.shape) == (240, 240, 12)
+    assert torch.all(lb[:25] == 114) and torch.all(lb[-26:] == 114) and torch.equal(lb[25:214], small)
+    # 3. C_p = mean over windows of otmi(events, letterboxed rep)
+    wins = [make_events(6000, W, H, seed=20 + i) for i in range(2)]
+    build = lambda e: EventBatch.from_numpy(e, H, W).optimized(scale=255.0)[0]
+    cp, scores = gp.measure_cp(wins, build, H, W, 240)
+    manual = [otmi(torch.from_numpy(w), gp.rep_for_gwd(build(w), 240).cpu().numpy(), H, W, 240) for w in wins]
+    assert abs(cp - float(np.mean(manual))) < 1e-12 and 0.0 < cp < 1.0
