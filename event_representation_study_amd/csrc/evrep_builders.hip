@@ -253,8 +253,9 @@ struct MdesParams {
 // Descriptor sources: RuntimeDesc reads the caller's triples from the kernel arguments;
 // StaticDesc<T> reads a constexpr table, so after unrolling every per-channel branch folds away
 // and unused accumulators disappear (ERGO-12: 2 variance, 3 max, 1 mean-of-timestamps, ...).
-struct RuntimeDesc {
-    static constexpr int kMaxC = EVREP_MAX_CHANNELS;
+template <int N>
+struct RuntimeDesc {  // N = compile-time capacity (4, 8, 12, 16): register arrays are sized by it
+    static constexpr int kMaxC = N;
     __device__ static inline int C(const MdesParams &P) { return P.C; }
     __device__ static inline int win(const MdesParams &P, int c) { return P.win[c]; }
     __device__ static inline int func(const MdesParams &P, int c) { return P.func[c]; }

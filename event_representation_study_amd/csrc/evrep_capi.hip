@@ -142,11 +142,19 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx), stream>>>(                              \
         CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
         plan->nchunk, span, scale, static_cast<T *>(out))
+#define MDES_RUNTIME(T)                                     \
+    do {                                                    \
+        if (C <= 4) MDES_LAUNCH(T, RuntimeDesc<4>);         \
+        else if (C <= 8) MDES_LAUNCH(T, RuntimeDesc<8>);    \
+        else if (C <= 12) MDES_LAUNCH(T, RuntimeDesc<12>);  \
+        else MDES_LAUNCH(T, RuntimeDesc<16>);               \
+    } while (0)
     if (out_dtype == EVREP_F64) {
-        if (ergo) MDES_LAUNCH(double, StaticDesc<Ergo12Table>); else MDES_LAUNCH(double, RuntimeDesc);
+        if (ergo) MDES_LAUNCH(double, StaticDesc<Ergo12Table>); else MDES_RUNTIME(double);
     } else {
-        if (ergo) MDES_LAUNCH(float, StaticDesc<Ergo12Table>); else MDES_LAUNCH(float, RuntimeDesc);
+        if (ergo) MDES_LAUNCH(float, StaticDesc<Ergo12Table>); else MDES_RUNTIME(float);
     }
+#undef MDES_RUNTIME
 #undef MDES_LAUNCH
     LAUNCH_CHECK("k_mdes");
     return EVREP_OK;
