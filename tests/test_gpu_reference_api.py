@@ -249,3 +249,22 @@ def test_gwd_caller_pipeline_f1():
     cp, scores = gp.measure_cp(wins, build, H, W, 240)
     manual = [otmi(torch.from_numpy(w), gp.rep_for_gwd(build(w), 240).cpu().numpy(), H, W, 240) for w in wins]
     assert abs(cp - float(np.mean(manual))) < 1e-12 and 0.0 < cp < 1.0
+
+
+def test_precompute_pipeline_f2(tmp_path):
+    """SURVEY 8 row F2 / BASELINE config 5: windows -> representation -> forced (S,S) resize -> float32 file per sample."""
+    import torch
+    from event_representation_study_amd import gwd_pipeline as gp
+    from event_representation_study_amd.engine import EventBatch
+    from event_representation_study_amd.precompute import RepPrecomputer
+    H, W, S = 90, 160, 80
+    wins = [make_events(3000, W, H, seed=70 + i) for i in range(5)]
+    pc = RepPrecomputer(H, W, S, "optimized", writers=2)
+    n, nbytes, el = pc.run([wins[:3], wins[3:]], str(tmp_path))
+    assert n == 5 and nbytes == 5 * S * S * 12 * 4
+    for i, ev in enumerate(wins):
+        got = np.load(str(tmp_path / ("%d.npy" % i)))
+        assert got.shape == (S, S, 12) and got.dtype == np.float32
+        rep = EventBatch.from_numpy(ev, H, W).optimized(scale=255.0)[0]
+        want = gp.resize(rep, S, S, "area").to(torch.float32).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
