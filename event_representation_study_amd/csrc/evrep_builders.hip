@@ -155,11 +155,10 @@ __device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, i
 // pixels without records keep the background.  `r0` = record `lane` of the chunk, loaded by the
 // caller before its own independent loads.  Pixel offsets outside [0, npix) (TORE's straddle)
 // are ignored.
-template <typename OutT, int CMAX, typename Reduce>
-__device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, int npix, int C,
-                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
+template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename Reduce>
+__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key0, int npix, int C,
+                                 OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
-    const uint32_t nrec = ce - cs;
     // a zero tile is filled at once (it overlaps the record load); a background that had to be
     // loaded is filled after the segment heads are listed, when it has arrived behind the records
     if (!bg || nrec == 0) tile_fill(w.tile, min(kPartPx, npix), C, bg);
@@ -169,7 +168,6 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
             tile_store(w.tile, min(kPartPx, npix - part * kPartPx) * C, dst + (size_t)part * kPartPx * C);
         return;
     }
-    w.evbuf[lane] = r0;
     // segment heads = runs of equal pixel id among the sorted records
     int nseg = 0;
     {
@@ -178,8 +176,7 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
             const uint32_t j = j0 + lane;
             const bool valid = j < nrec;
             int key = INT32_MIN;
-            if (j0 == 0) key = r0.x; else if (valid) key = sorted[cs + j].x;
-            if (!valid) key = INT32_MIN;
+            if (valid) key = key_at(j);
             int prev = __shfl_up(key, 1, 64);
             if (lane == 0) prev = carry;
             const bool head = valid && key != prev;
@@ -196,8 +193,6 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
     }
     if (bg) tile_fill(w.tile, min(kPartPx, npix), C, bg);
     wave_phase();
-    const Rec *evbuf = w.evbuf;
-    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kEvStage ? evbuf[j] : sorted[cs + j]; };
 
     if (nseg <= kWave) {
         // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
@@ -239,6 +234,19 @@ __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, u
             tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
         }
     }
+}
+
+// emit_core over a chunk of the column-sorted stream: `r0` = record `lane` of the chunk, loaded by the
+// caller before its own independent loads; the first kEvStage records are staged in LDS.
+template <typename OutT, int CMAX, typename Reduce>
+__device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, int npix, int C,
+                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
+    const uint32_t nrec = ce - cs;
+    if (nrec) w.evbuf[threadIdx.x] = r0;
+    const Rec *evbuf = w.evbuf;
+    auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : sorted[cs + j].x; };
+    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kEvStage ? evbuf[j] : sorted[cs + j]; };
+    emit_core<OutT, CMAX>(nrec, key_at, get, key0, npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
