@@ -746,4 +746,80 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
     emit_chunk<double, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, r0, reduce);
 }
 
+// --------------------------------------------------------------------------------------------
+// F4: n_imagenet's per-polarity accumulators (n_imagenet/real_cnn_model/data/imagenet.py:169-511,841-871)
+// --------------------------------------------------------------------------------------------
+struct PolStatParams {
+    int32_t C;
+    int32_t pol[EVREP_MAX_CHANNELS], stat[EVREP_MAX_CHANNELS];
+    double tau;
+};
+
+// grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
+__global__ __launch_bounds__(kWave) void k_polstats(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+                                                   const int64_t *__restrict__ off, const double *__restrict__ tnorm,
+                                                   PolStatParams P, int H, int W, int nchunk, int span,
+                                                   float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = P.C;
+    WaveLds<float> w(smem, C, span * kChunkPx);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    const int lane = threadIdx.x;
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if (lane < (int)(g.ce - g.cs)) r0 = sorted[g.cs + lane];
+    const double *tw = tnorm + off[g.b];
+    // empty pixels: 0, except EXP channels = exp(-(1 - 0)/tau)  (imagenet.py:463,466)
+    bool any_bg = false;
+#pragma unroll
+    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
+    if (any_bg) {
+        if (lane < EVREP_MAX_CHANNELS) {
+            float v = 0.0f;
+            if (lane < C && P.stat[lane] == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - 0.0) / P.tau);
+            w.bg[lane] = v;
+        }
+        wave_phase();
+    }
+    const float *bg = any_bg ? w.bg : nullptr;
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+        int n_any = 0, n_pos = 0, n_neg = 0;
+        double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
+        for (uint32_t j = jb; j < je; ++j) {
+            const Rec e = get(j);
+            const double tn = tw[e.y];
+            if (n_any == 0 || tn > mx_any) mx_any = tn;
+            if (n_any == 0 || tn < mn_any) mn_any = tn;
+            ++n_any;
+            if (e.w > 0) {
+                if (n_pos == 0 || tn > mx_pos) mx_pos = tn;
+                if (n_pos == 0 || tn < mn_pos) mn_pos = tn;
+                ++n_pos;
+            } else if (e.w < 0) {
+                if (n_neg == 0 || tn > mx_neg) mx_neg = tn;
+                if (n_neg == 0 || tn < mn_neg) mn_neg = tn;
+                ++n_neg;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+            float v = 0.0f;
+            if (c < C) {
+                const int k = P.pol[c], st = P.stat[c];
+                const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
+                const double mx = k == EVREP_PS_POS ? mx_pos : (k == EVREP_PS_NEG ? mx_neg : mx_any);
+                const double mn = k == EVREP_PS_POS ? mn_pos : (k == EVREP_PS_NEG ? mn_neg : mn_any);
+                if (st == EVREP_PS_COUNT) v = (float)n;
+                else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
+                else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
+                else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
+                else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
+                else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+            }
+            vals[c] = v;
+        }
+    };
+    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, r0, reduce);
+}
+
 }  // namespace evrep

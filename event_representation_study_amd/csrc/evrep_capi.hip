@@ -234,6 +234,31 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     return EVREP_OK;
 }
 
+int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                   const double *tnorm, int32_t C, const int32_t *pol, const int32_t *stat, double tau, float *out,
+                   void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (C <= 0 || C > EVREP_MAX_CHANNELS || !pol || !stat || !out) return EVREP_EINVAL;
+    if (plan->total_events > 0 && !tnorm) return EVREP_EINVAL;
+    PolStatParams P;
+    memset(&P, 0, sizeof(P));
+    P.C = C;
+    P.tau = tau;
+    for (int c = 0; c < C; ++c) {
+        if (pol[c] < EVREP_PS_ANY || pol[c] > EVREP_PS_NEG || stat[c] < EVREP_PS_COUNT || stat[c] > EVREP_PS_SIGNED) return EVREP_EINVAL;
+        if (stat[c] == EVREP_PS_EXP && !(tau > 0.0)) return EVREP_EINVAL;
+        P.pol[c] = pol[c];
+        P.stat[c] = stat[c];
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int span = builder_span(plan, (size_t)C * 4);
+    k_polstats<<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx), stream>>>(
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, span, out);
+    LAUNCH_CHECK("k_polstats");
+    return EVREP_OK;
+}
+
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream_) {
     if (!plan || !workspace || !status) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);

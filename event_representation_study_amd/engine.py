@@ -215,6 +215,24 @@ class EventBatch:
                   "evrep_voxel")
         return out
 
+    def polstats(self, tnorm, pol, stat, tau=0.3, out=None):
+        """n_imagenet's per-polarity accumulators (imagenet.py:169-511): channel c = stat[c] over the events of
+        polarity class pol[c] at each pixel.  tnorm: float64 device tensor, one normalised time per event."""
+        self.bin()
+        pol = np.ascontiguousarray(pol, dtype=np.int32)
+        stat = np.ascontiguousarray(stat, dtype=np.int32)
+        if pol.shape != stat.shape or pol.ndim != 1:
+            raise ValueError("pol and stat must be 1-D and of equal length")
+        if tnorm.dtype != torch.float64 or tnorm.device != self.device or tnorm.numel() != self.total \
+                or not tnorm.is_contiguous():
+            raise ValueError("tnorm must be a contiguous float64 tensor with one entry per event on %s" % self.device)
+        out = self._out(out, len(pol), torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_polstats(*self._args(), _ptr(tnorm), len(pol), pol.ctypes.data_as(ctypes.c_void_p),
+                                          stat.ctypes.data_as(ctypes.c_void_p), float(tau), _ptr(out), _stream_ptr()),
+                  "evrep_polstats")
+        return out
+
 
 class BinBuildPipeline:
     """Throughput path for a STREAM of batches: the binning pass of batch k+1 runs on a side HIP stream

@@ -1,0 +1,157 @@
+"""Row F4: n_imagenet's per-polarity accumulators on the binned stream.
+
+Host-side mirror of the `reshape_then_*` accumulator family of
+n_imagenet/real_cnn_model/data/imagenet.py (same names, same `(event_tensor, augment=None, **kwargs)`
+signature, same (C, H, W) float32 result, same empty-input behaviour):
+
+    reshape_then_acc            :169-210   [pos count / max, pos latest time, neg count / max, neg latest time]
+    reshape_then_acc_time       :213-247   [pos earliest, pos latest, neg earliest, neg latest]
+    reshape_then_acc_count      :250-293   [pos count, pos latest, neg count, neg latest]
+    reshape_then_acc_count_pol  :296-321   [pos count, neg count]
+    reshape_then_acc_count_only :324-343   [count]
+    reshape_then_acc_all        :346-394   [pos count, neg count, pos latest, neg latest, pos earliest, neg earliest]
+    reshape_then_flat           :397-413   [any event]
+    reshape_then_flat_pol       :416-438   [any pos event, any neg event]
+    reshape_then_acc_exp        :441-472   exp(-(1 - latest)/0.3) per polarity, over the whole frame
+    reshape_then_acc_time_pol   :475-510   [pos latest, neg latest]
+    reshape_then_acc_intensity  :841-870   min-max normalised (pos count - neg count)
+
+`event_tensor` is what parse_event hands over (:128-164): a float64 (N, 4) tensor of rows
+[x, y, t_seconds, p], p in {-1, +1}, coordinates possibly fractional (they are truncated by `.long()`,
+:187).  All of them are ONE HIP builder (evrep_polstats, csrc/evrep_builders.hip k_polstats) with a
+per-channel (polarity class, statistic) descriptor; the two window-level normalisations (count / count.max(),
+min-max of the intensity) are strided float32 tensor ops on the builder's output, as in the reference.
+
+Not built: the DiST sort family (reshape_then_acc_sort / _adj_sort, :513-1000) and the EST quantisation
+layer (ev-YOLOv6/yolov6/models/learned_repr.py:143-179, a learned layer that needs autograd).
+The product path needs the HIP library and an MI355X; there is no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from .engine import EventBatch
+
+IMAGE_H = 224    # imagenet.py:17-18
+IMAGE_W = 224
+EXP_TAU = 0.3    # imagenet.py:20
+
+ANY, POS, NEG = 0, 1, 2                                  # EVREP_PS_* of include/evrep.h
+COUNT, TMAX, TMIN, FLAG, EXP, SIGNED = 0, 1, 2, 3, 4, 5
+
+# name -> (polarity class per channel, statistic per channel)
+SPECS = {
+    "acc": ([POS, POS, NEG, NEG], [COUNT, TMAX, COUNT, TMAX]),
+    "acc_time": ([POS, POS, NEG, NEG], [TMIN, TMAX, TMIN, TMAX]),
+    "acc_count": ([POS, POS, NEG, NEG], [COUNT, TMAX, COUNT, TMAX]),
+    "acc_count_pol": ([POS, NEG], [COUNT, COUNT]),
+    "acc_count_only": ([ANY], [COUNT]),
+    "acc_all": ([POS, NEG, POS, NEG, POS, NEG], [COUNT, COUNT, TMAX, TMAX, TMIN, TMIN]),
+    "flat": ([ANY], [FLAG]),
+    "flat_pol": ([POS, NEG], [FLAG, FLAG]),
+    "acc_exp": ([POS, NEG], [EXP, EXP]),
+    "acc_time_pol": ([POS, NEG], [TMAX, TMAX]),
+    "acc_intensity": ([ANY], [SIGNED]),
+}
+
+
+def _as_f64(event_tensor):
+    a = event_tensor.detach().cpu().numpy() if isinstance(event_tensor, torch.Tensor) else np.asarray(event_tensor)
+    return np.asarray(a, dtype=np.float64).reshape(-1, 4)
+
+
+def _window(ev, H, W):
+    """(N,4) float64 -> int32 rows [x.long(), y.long(), 0, sign(p)] and the normalised float64 times
+    (t - t[0]) / (t[-1] - t[0])  (imagenet.py:178-181,198-199)."""
+    xi, yi = ev[:, 0].astype(np.int64), ev[:, 1].astype(np.int64)   # .long() truncates toward zero
+    if len(ev) and (xi.min() < 0 or yi.min() < 0 or xi.max() >= W or yi.max() >= H):
+        # the reference fails here as well (bincount grows past H*W and the reshape raises, :187-189)
+        raise RuntimeError("event coordinates outside the %dx%d frame" % (W, H))
+    rows = np.zeros((len(ev), 4), dtype=np.int32)
+    rows[:, 0], rows[:, 1] = xi, yi
+    rows[:, 3] = (ev[:, 3] > 0).astype(np.int32) - (ev[:, 3] < 0).astype(np.int32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tn = (ev[:, 2] - ev[0, 2]) / (ev[-1, 2] - ev[0, 2]) if len(ev) else np.zeros(0)
+    return rows, tn
+
+
+def accumulate_batch(name, event_tensors, height=IMAGE_H, width=IMAGE_W, device="cuda:0"):
+    """Batched form: a list of (N_b, 4) float64 event tensors -> (B, C, H, W) float32 CUDA tensor (a
+    channel-first VIEW of the builder's (B, H, W, C) output, like the reference's permute(2, 0, 1))."""
+    pol, stat = SPECS[name]
+    wins = [_as_f64(e) for e in event_tensors]
+    for w in wins:
+        if len(w) == 0:
+            raise IndexError("empty event tensor")   # event_tensor[0, 2], imagenet.py:178
+    packed = [_window(w, height, width) for w in wins]
+    batch = EventBatch.from_numpy([r for r, _ in packed], height, width, device=device)
+    tnorm = torch.from_numpy(np.concatenate([t for _, t in packed]) if packed else np.zeros(0)).to(batch.device)
+    out = batch.polstats(tnorm, pol, stat, tau=EXP_TAU)            # (B, H, W, C) float32
+    if name == "acc":          # pos_count / pos_count.max().float()  (:190-191,196-197): float32 / float32
+        for c in (0, 2):
+            out[..., c] /= out[..., c].amax(dim=(1, 2), keepdim=True)
+    elif name == "acc_intensity":   # (i - i.min()) / (i.max() - i.min())  (:867)
+        lo = out.amin(dim=(1, 2, 3), keepdim=True)
+        hi = out.amax(dim=(1, 2, 3), keepdim=True)
+        out = (out - lo) / (hi - lo)
+    return out.permute(0, 3, 1, 2)
+
+
+def _single(name, event_tensor, augment, kwargs):
+    if augment is not None:
+        event_tensor = augment(event_tensor)
+    H = kwargs.get("height", IMAGE_H)
+    W = kwargs.get("width", IMAGE_W)
+    ev = _as_f64(event_tensor)
+    if len(ev) == 0:
+        if name in ("acc_count", "acc_time_pol"):   # ten synthetic events at the origin (:258-261,483-486)
+            ev = np.zeros((10, 4))
+            ev[:, 2] = (np.arange(10, dtype=np.float32) / np.float32(10.0)).astype(np.float64)
+            ev[:, 3] = 1
+        elif name == "acc_all":                     # :353-354 (IMAGE_H x IMAGE_W whatever height/width say)
+            return torch.zeros([6, IMAGE_H, IMAGE_W])
+    res = accumulate_batch(name, [ev], H, W, device=kwargs.get("device", "cuda:0"))[0]
+    return res if kwargs.get("keep_on_device", False) else res.cpu()
+
+
+def reshape_then_acc(event_tensor, augment=None, **kwargs):
+    return _single("acc", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_time(event_tensor, augment=None, **kwargs):
+    return _single("acc_time", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_count(event_tensor, augment=None, **kwargs):
+    return _single("acc_count", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_count_pol(event_tensor, augment=None, **kwargs):
+    return _single("acc_count_pol", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_count_only(event_tensor, augment=None, **kwargs):
+    return _single("acc_count_only", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_all(event_tensor, augment=None, **kwargs):
+    return _single("acc_all", event_tensor, augment, kwargs)
+
+
+def reshape_then_flat(event_tensor, augment=None, **kwargs):
+    return _single("flat", event_tensor, augment, kwargs)
+
+
+def reshape_then_flat_pol(event_tensor, augment=None, **kwargs):
+    return _single("flat_pol", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_exp(event_tensor, augment=None, **kwargs):
+    return _single("acc_exp", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_time_pol(event_tensor, augment=None, **kwargs):
+    return _single("acc_time_pol", event_tensor, augment, kwargs)
+
+
+def reshape_then_acc_intensity(event_tensor, augment=None, **kwargs):
+    return _single("acc_intensity", event_tensor, augment, kwargs)

@@ -128,6 +128,30 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
 int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                 int32_t bins, int32_t mode, double scale, double *out, void *stream);
 
+/* n_imagenet's per-polarity accumulators (n_imagenet/real_cnn_model/data/imagenet.py:169-511,841-871:
+ * reshape_then_acc, _acc_time, _acc_count, _acc_count_pol, _acc_count_only, _acc_all, _flat, _flat_pol,
+ * _acc_exp, _acc_time_pol, _acc_intensity) as ONE builder: channel c = stat[c] of the events of polarity
+ * class pol[c] at each pixel.  pol: EVREP_PS_ANY (every event), EVREP_PS_POS (p > 0), EVREP_PS_NEG (p < 0).
+ * stat: COUNT = torch.bincount (:187-189); TMAX / TMIN = torch_scatter.scatter_max / scatter_min of the
+ * normalised time, 0 where empty (:203-206,236-239); FLAG = 1 where any event (:405-406); EXP =
+ * exp(-(1 - TMAX)/tau) over the WHOLE frame, empty pixels included (:461-465); SIGNED = count(p>0) -
+ * count(p<0) (:866).  tnorm DEVICE double [total_events] = (t - t[0]) / (t[-1] - t[0]) per window in
+ * float64 (:180-181,198-199), indexed like `events`; the events' own t column is not used.
+ * The window-level normalisations (count / count.max() :190-191, min-max of the intensity :867) are
+ * the caller's.  out DEVICE (B,H,W,C) float32, C <= 16. */
+#define EVREP_PS_ANY 0
+#define EVREP_PS_POS 1
+#define EVREP_PS_NEG 2
+#define EVREP_PS_COUNT 0
+#define EVREP_PS_TMAX 1
+#define EVREP_PS_TMIN 2
+#define EVREP_PS_FLAG 3
+#define EVREP_PS_EXP 4
+#define EVREP_PS_SIGNED 5
+int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                   const double *tnorm, int32_t C, const int32_t *pol, const int32_t *stat, double tau, float *out,
+                   void *stream);
+
 /* Synchronous read-backs (they synchronise `stream`). status: HOST uint32 [B];
  * bbox: HOST int32 [B,4] = xmin, ymin, xmax, ymax of each window's in-frame events. */
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream);

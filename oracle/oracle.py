@@ -198,3 +198,84 @@ def otmi_point_clouds(events, rep, height, width, rep_size):
 
 def otmi(events, rep, height, width, rep_size, h=0.7):
     return float(np.mean([gwd(a, b, h) for a, b in otmi_point_clouds(events, rep, height, width, rep_size)]))
+
+
+# ---------------------------------------------------------------------------------------------
+# F4: n_imagenet's per-polarity accumulators, numpy restatement
+# (n_imagenet/real_cnn_model/data/imagenet.py; event_tensor = float64 (N,4) rows [x, y, t_seconds, p])
+# ---------------------------------------------------------------------------------------------
+NIMAGENET_EXP_TAU = 0.3  # imagenet.py:20
+
+
+def _ni_split(ev, W):
+    """pos / neg rows (:176-177), pixel index = x.long() + y.long()*W (:187,200), normalised time (:198-199)."""
+    ev = np.asarray(ev, dtype=np.float64)
+    pos, neg = ev[ev[:, 3] > 0], ev[ev[:, 3] < 0]
+    idx = lambda a: a[:, 0].astype(np.int64) + a[:, 1].astype(np.int64) * W  # noqa: E731  (.long() truncates)
+    start = ev[0, 2]
+    length = ev[-1, 2] - ev[0, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tp, tn = (pos[:, 2] - start) / length, (neg[:, 2] - start) / length
+    return ev, idx(pos), idx(neg), tp, tn
+
+
+def _ni_count(idx, H, W):
+    return np.bincount(idx, minlength=H * W).reshape(H, W)  # torch.bincount (:187-189)
+
+
+def _ni_scatter(src, idx, H, W, op):
+    """torch_scatter.scatter_max / scatter_min with dim_size and no `out`: empty entries are 0."""
+    o = np.full(H * W, -np.inf if op == "max" else np.inf)
+    (np.maximum if op == "max" else np.minimum).at(o, idx, src)
+    o[np.isinf(o)] = 0.0
+    return o.reshape(H, W)
+
+
+def nimagenet_acc(name, ev, H, W):
+    """name in: acc, acc_time, acc_count, acc_count_pol, acc_count_only, acc_all, flat, flat_pol, acc_exp,
+    acc_time_pol, acc_intensity -> (C, H, W) float32, as reshape_then_<name> (imagenet.py:169-511,841-871)."""
+    ev = np.asarray(ev, dtype=np.float64)
+    if len(ev) == 0:
+        if name in ("acc_count", "acc_time_pol"):  # :258-261,483-486: ten synthetic events at the origin
+            ev = np.zeros((10, 4))
+            ev[:, 2] = (np.arange(10, dtype=np.float32) / np.float32(10.0)).astype(np.float64)
+            ev[:, 3] = 1
+        elif name == "acc_all":
+            return np.zeros((6, 224, 224), np.float32)  # :353-354 (IMAGE_H, IMAGE_W, whatever H, W are)
+        else:
+            raise IndexError("empty event tensor")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if name in ("flat", "acc_count_only"):
+            idx = ev[:, 0].astype(np.int64) + ev[:, 1].astype(np.int64) * W
+            c = _ni_count(idx, H, W)
+            out = [(c > 0).astype(np.float64)] if name == "flat" else [c]  # :403-406 / :334-336
+            return np.stack(out).astype(np.float32)
+        ev, ip, ineg, tp, tn = _ni_split(ev, W)
+        pc, nc = _ni_count(ip, H, W), _ni_count(ineg, H, W)
+        if name == "acc":  # :169-210
+            pcn = pc.astype(np.float32) / np.float32(pc.max())  # int64 tensor / 0-dim float32 tensor -> float32
+            ncn = nc.astype(np.float32) / np.float32(nc.max())
+            ch = [pcn, _ni_scatter(tp, ip, H, W, "max"), ncn, _ni_scatter(tn, ineg, H, W, "max")]
+        elif name == "acc_time":  # :213-247
+            ch = [_ni_scatter(tp, ip, H, W, "min"), _ni_scatter(tp, ip, H, W, "max"),
+                  _ni_scatter(tn, ineg, H, W, "min"), _ni_scatter(tn, ineg, H, W, "max")]
+        elif name == "acc_count":  # :250-293
+            ch = [pc, _ni_scatter(tp, ip, H, W, "max"), nc, _ni_scatter(tn, ineg, H, W, "max")]
+        elif name == "acc_count_pol":  # :296-321
+            ch = [pc, nc]
+        elif name == "acc_all":  # :346-394
+            ch = [pc, nc, _ni_scatter(tp, ip, H, W, "max"), _ni_scatter(tn, ineg, H, W, "max"),
+                  _ni_scatter(tp, ip, H, W, "min"), _ni_scatter(tn, ineg, H, W, "min")]
+        elif name == "flat_pol":  # :416-438
+            ch = [(pc > 0).astype(np.float64), (nc > 0).astype(np.float64)]
+        elif name == "acc_exp":  # :441-472
+            ch = [np.exp(-(1 - _ni_scatter(tp, ip, H, W, "max")) / NIMAGENET_EXP_TAU),
+                  np.exp(-(1 - _ni_scatter(tn, ineg, H, W, "max")) / NIMAGENET_EXP_TAU)]
+        elif name == "acc_time_pol":  # :475-510
+            ch = [_ni_scatter(tp, ip, H, W, "max"), _ni_scatter(tn, ineg, H, W, "max")]
+        elif name == "acc_intensity":  # :841-870, float32 throughout
+            it = pc.astype(np.float32) - nc.astype(np.float32)
+            ch = [(it - it.min()) / (it.max() - it.min())]
+        else:
+            raise ValueError(name)
+        return np.stack([np.asarray(c) for c in ch]).astype(np.float32)

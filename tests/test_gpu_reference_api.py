@@ -1,5 +1,7 @@
 """-m gpu: the reference's own Python names, re-hosted on the HIP path, against
 the golden vectors produced by the reference itself."""
+import os
+
 import numpy as np
 import pytest
 
@@ -268,3 +270,61 @@ def test_precompute_pipeline_f2(tmp_path):
         rep = EventBatch.from_numpy(ev, H, W).optimized(scale=255.0)[0]
         want = gp.resize(rep, S, S, "area").to(torch.float32).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ F4: n_imagenet accumulators
+NI_NAMES = ["acc", "acc_time", "acc_count", "acc_count_pol", "acc_count_only", "acc_all", "flat", "flat_pol",
+            "acc_exp", "acc_time_pol", "acc_intensity"]
+
+
+def _ni_golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "nimagenet_acc.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "pos", "c224"])
+def test_nimagenet_acc_against_reference_goldens(tag):
+    """reshape_then_* (HIP k_polstats) against outputs of the reference's own functions: bit-exact for
+    counts / flags / min-max times / normalised counts (NaN where the reference has NaN), 1e-5 for acc_exp."""
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    g = _ni_golden()
+    ev, H, W = g[tag + "_events"], int(g[tag + "_H"]), int(g[tag + "_W"])
+    for name in NI_NAMES:
+        key = "%s_%s" % (tag, name)
+        if key not in g.files:
+            continue
+        got = getattr(ni, "reshape_then_" + name)(torch.from_numpy(ev.copy()), height=H, width=W)
+        assert got.dtype == torch.float32 and tuple(got.shape) == g[key].shape and got.device.type == "cpu"
+        if name == "acc_exp":
+            np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=0)
+        else:
+            np.testing.assert_array_equal(got.numpy(), g[key])
+
+
+@pytest.mark.gpu
+def test_nimagenet_acc_empty_and_batch(oracle):
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    from event_representation_study_amd.synthetic import make_events
+    g = _ni_golden()
+    empty = torch.zeros((0, 4), dtype=torch.float64)
+    for name in ("acc_count", "acc_time_pol"):
+        np.testing.assert_array_equal(getattr(ni, "reshape_then_" + name)(empty, height=24, width=32).numpy(),
+                                      g["empty_" + name])
+    assert tuple(ni.reshape_then_acc_all(empty, height=24, width=32).shape) == (6, 224, 224)
+    with pytest.raises(IndexError):
+        ni.reshape_then_acc(empty, height=24, width=32)
+    with pytest.raises(RuntimeError):
+        ni.reshape_then_acc_count_pol(torch.tensor([[40.0, 3.0, 0.0, 1.0], [1.0, 2.0, 0.1, -1.0]], dtype=torch.float64),
+                                      height=24, width=32)
+    # a ragged batch against the oracle, window by window
+    wins = []
+    for i, n in enumerate([1500, 7, 40000]):
+        e = make_events(n, 160, 120, seed=900 + i).astype(np.float64)
+        e[:, 2] /= 1e6
+        wins.append(e)
+    for name in ("acc_all", "acc", "acc_intensity", "flat_pol"):
+        out = ni.accumulate_batch(name, wins, 120, 160).cpu().numpy()
+        for b, e in enumerate(wins):
+            np.testing.assert_array_equal(out[b], oracle.nimagenet_acc(name, e, 120, 160))

@@ -40,6 +40,7 @@ def main():
         wins = [make_events(N, W, H, seed=7000 + i) for i in range(B)]
         eb = EventBatch.from_numpy(wins, H, W)
         t_bin = timed(lambda: eb.rebin(), 20)
+        tnorm = torch.rand(eb.total, dtype=torch.float64, device="cuda:0")  # one normalised time per event
         builders = {
             "optimized_f64": (lambda o: eb.optimized(out=o), 12, torch.float64),
             "optimized_f32": (lambda o: eb.optimized(dtype=torch.float32, out=o), 12, torch.float32),
@@ -47,6 +48,9 @@ def main():
             "time_surface_f64": (lambda o: eb.time_surface(out=o), 12, torch.float64),
             "tore_full_frame_f32": (lambda o: eb.tore(6, frame_mode=2, out=o), 12, torch.float32),
             "voxel5_f64": (lambda o: eb.voxel(5, out=o), 5, torch.float64),
+            # F4: n_imagenet reshape_then_acc_all = 6 per-polarity statistics (count, latest, earliest)
+            "nimagenet_acc_all_f32": (lambda o: eb.polstats(tnorm, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2], out=o),
+                                      6, torch.float32),
         }
         for name, (fn, C, dt) in builders.items():
             out = torch.empty((B, H, W, C), dtype=dt, device="cuda:0")
