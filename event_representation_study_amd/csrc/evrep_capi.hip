@@ -37,6 +37,8 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     if (!plan || B <= 0 || H <= 0 || W <= 0 || H > EVREP_MAX_DIM || W > EVREP_MAX_DIM) return EVREP_EINVAL;
     if (total_events < 0 || max_events_per_window < 0 || max_events_per_window > total_events) return EVREP_EINVAL;
     if (total_events >= (int64_t)1 << 31 || (int64_t)H * W >= (int64_t)1 << 30) return EVREP_EINVAL;
+    // launch geometry: windows ride gridDim.z / .y (<= 65535) and work-unit ids are 32-bit
+    if (B > 65535 || (int64_t)B * H * ((W + kChunkPx - 1) / kChunkPx) >= (int64_t)1 << 31) return EVREP_EINVAL;
     memset(plan, 0, sizeof(*plan));
     plan->abi_version = EVREP_ABI_VERSION;
     plan->B = B; plan->H = H; plan->W = W;

@@ -24,7 +24,10 @@ def _third_party(events, transform, height, width, **kw):
 
 
 def _voxel_grid(events, transform, height, width, num_events):
-    grid = _third_party(events, transform, height, width, n_time_bins=VOXEL_BINS)   # (T, 1, H, W)
+    made = transform((width, height, 2), n_time_bins=VOXEL_BINS)
+    if hasattr(made, "build_hwt"):       # our ToVoxelGrid: (H, W, T) straight from the builder, x255 in the kernel
+        return made.build_hwt(events, scale=SCALE)
+    grid = made(events)                                                             # (T, 1, H, W)
     return np.moveaxis(grid[:, 0], 0, -1) * SCALE                                   # (H, W, T)
 
 

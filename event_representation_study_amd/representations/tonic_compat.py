@@ -16,16 +16,18 @@ class ToVoxelGrid:
         self.sensor_size = sensor_size
         self.n_time_bins = int(n_time_bins)
 
-    def __call__(self, events):
+    def build_hwt(self, events, scale=1.0):
+        """(H, W, T) float64 on the host, `scale` folded into the kernel (what the dispatcher wants)."""
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
+        if self.n_time_bins > 16:
+            raise NotImplementedError("ToVoxelGrid: n_time_bins > 16")
         batch = single_batch(events, H, W)
         raise_for_status(batch, what="ToVoxelGrid")
-        T = self.n_time_bins
-        parts = [batch.voxel(bins=T, mode=1)] if T <= 16 else None
-        if parts is None:
-            raise NotImplementedError("ToVoxelGrid: n_time_bins > 16")
-        rep = parts[0][0].cpu().numpy()                      # (H, W, T)
-        return np.ascontiguousarray(rep.transpose(2, 0, 1))[:, np.newaxis, :, :]
+        return batch.voxel(bins=self.n_time_bins, mode=1, scale=float(scale))[0].cpu().numpy()
+
+    def __call__(self, events):
+        # tonic's layout (T, 1, H, W), as a strided view of the builder's (H, W, T) result
+        return np.moveaxis(self.build_hwt(events), -1, 0)[:, np.newaxis, :, :]
 
 
 class ToImage:
@@ -40,5 +42,6 @@ class ToImage:
         batch = single_batch(events, H, W)
         raise_for_status(batch, what="ToImage")
         # counts of p == 0 ("count_neg" falls back to p == 0 when no -1 is present) and of p == 1
-        rep = batch.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"])[0].cpu().numpy()
-        return np.ascontiguousarray(rep.transpose(2, 0, 1)).astype(np.int16)
+        import torch
+        rep = batch.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"], dtype=torch.float32)[0]
+        return rep.permute(2, 0, 1).to(torch.int16).contiguous().cpu().numpy()   # counts are exact in float32

@@ -47,7 +47,9 @@ def test_plan_struct_layout_matches_header(lib):
 
 
 @pytest.mark.parametrize("args", [(0, 480, 640, 10, 10), (1, 0, 640, 10, 10), (1, 480, 5000, 10, 10),
-                                  (1, 480, 640, 10, 11), (1, 480, 640, -1, 0), (1, 480, 640, 1 << 31, 1)])
+                                  (1, 480, 640, 10, 11), (1, 480, 640, -1, 0), (1, 480, 640, 1 << 31, 1),
+                                  (65536, 8, 8, 10, 10),            # windows ride gridDim.z
+                                  (60000, 4096, 4096, 10, 10)])     # > 2^31 work units
 def test_plan_init_rejects_bad_arguments(lib, args):
     from event_representation_study_amd._lib import Plan, EVREP_EINVAL
     assert lib.evrep_plan_init(ctypes.byref(Plan()), *args) == EVREP_EINVAL
@@ -68,6 +70,12 @@ def test_null_and_misaligned_pointers_are_refused_before_any_launch(lib):
     assert lib.evrep_bin_events(ctypes.byref(p), ctypes.c_void_p(8), ctypes.c_void_p(256), ctypes.c_void_p(256),
                                 None) == EVREP_EINVAL   # events not 16-byte aligned
     assert lib.evrep_gwd_padded_l1(None, 1, 4, None, 1, 4, 0.7, None, None, None) == EVREP_EINVAL
+    i32 = (ctypes.c_int32 * 2)(0, 0)
+    assert lib.evrep_polstats(ctypes.byref(p), ctypes.c_void_p(256), ctypes.c_void_p(256), ctypes.c_void_p(256),
+                              ctypes.c_void_p(256), 17, i32, i32, 0.3, ctypes.c_void_p(256), None) == EVREP_EINVAL
+    bad = (ctypes.c_int32 * 2)(0, 9)   # unknown statistic
+    assert lib.evrep_polstats(ctypes.byref(p), ctypes.c_void_p(256), ctypes.c_void_p(256), ctypes.c_void_p(256),
+                              ctypes.c_void_p(256), 2, i32, bad, 0.3, ctypes.c_void_p(256), None) == EVREP_EINVAL
     assert lib.evrep_gwd_scratch_bytes(12500, 14400) > 14 * 14400 * 4
 
 
