@@ -80,13 +80,20 @@ def cpu_baseline(events_per_window, budget_s=12.0, threads_budget_s=6.0):
                 oracle.ergo12(wins[(k + n) % len(wins)], H, W)   # ctypes releases the GIL
                 n += 1
             return n
-        t0 = time.perf_counter()
-        deadline = t0 + threads_budget_s
-        with ThreadPoolExecutor(ncpu) as ex:
-            total = sum(ex.map(work, range(ncpu)))
-        el2 = time.perf_counter() - t0
-        res["all_cores"] = {"value": total * events_per_window / el2, "unit": "events/s", "cores": ncpu,
-                            "sample": "%d windows over %d threads, %.1f s" % (total, ncpu, el2)}
+        # every window allocates and first-touches a fresh 29.5 MB result (as the reference does), so the
+        # scaling over threads is set by the host's page-fault path; report the best of a few thread counts
+        tried = []
+        counts = sorted({min(ncpu, 8), min(ncpu, 32), ncpu})
+        for nt in counts:
+            t0 = time.perf_counter()
+            deadline = t0 + threads_budget_s / len(counts)
+            with ThreadPoolExecutor(nt) as ex:
+                total = sum(ex.map(work, range(nt)))
+            el2 = time.perf_counter() - t0
+            tried.append({"value": total * events_per_window / el2, "unit": "events/s", "cores": nt,
+                          "sample": "%d windows over %d threads, %.1f s" % (total, nt, el2)})
+        res["all_cores"] = dict(max(tried, key=lambda r: r["value"]), host_cores=ncpu,
+                                tried=[(r["cores"], round(r["value"])) for r in tried])
     return res
 
 
