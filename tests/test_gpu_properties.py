@@ -107,6 +107,23 @@ def test_odd_geometries(eng, oracle, W, H):
     np.testing.assert_allclose(tore, oracle.tore_bbox(ev, 6), rtol=1e-6, atol=1e-6)
 
 
+def test_maximum_frame(eng, oracle):
+    """EVREP_MAX_DIM x EVREP_MAX_DIM (4096 x 4096): the widest rows (32 chunks, 16 KB of column counters),
+    the tallest row table (the unfused scan/scatter pair), 1.6 GB of float64 output -- bit-exact vs the oracle;
+    one window more than the 16-bit grid limit is refused by the plan."""
+    import ctypes
+    from event_representation_study_amd import _lib
+    H = W = 4096
+    ev = make_events(300000, W, H, seed=4096)
+    eb = eng.EventBatch.from_numpy(ev, H, W)
+    got = eb.optimized()[0].cpu().numpy()
+    assert_bit_equal(got, oracle.ergo12(ev, H, W), "ergo12 4096x4096")
+    del got
+    es = eb.event_stack()[0].cpu().numpy()
+    assert_bit_equal(es, oracle.event_stack(ev, H, W), "event stack 4096x4096")
+    assert _lib.load().evrep_plan_init(ctypes.byref(_lib.Plan()), 1, H + 1, W, 10, 10) == _lib.EVREP_EINVAL
+
+
 def test_gwd_fullsize_properties(eng, oracle):
     """GWD at the reference's size (n ~ 12.5k, m = 14.4k): symmetry-free invariants + sampled check."""
     rng = np.random.default_rng(3)
