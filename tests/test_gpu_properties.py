@@ -157,3 +157,30 @@ def test_bin_build_pipeline_matches_serial(eng):
     torch.cuda.synchronize()
     for j in range(2):
         assert torch.equal(outs[j], serial[j])
+
+
+def test_step_is_graph_capturable(eng):
+    """bin + build make no synchronising call, so the whole step records into a hipGraph and replays to the
+    same tensor (what a launch-bound caller would do with many small batches)."""
+    wins = [make_events(5000, 304, 240, seed=70 + i) for i in range(4)]
+    eb = eng.EventBatch.from_numpy(wins, 240, 304)
+    out = torch.empty((4, 240, 304, 12), dtype=torch.float64, device="cuda:0")
+
+    def step():
+        eb.rebin()
+        eb.optimized(out=out)
+    step()
+    ref = out.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
