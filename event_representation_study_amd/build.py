@@ -47,5 +47,24 @@ def build(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "capi_ergo12.cpp")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "capi_ergo12")
+
+
+def build_example(force=False, verbose=True):
+    """examples/capi_ergo12: the C ABI driven from plain C++ (HIP runtime only, no torch, no Python)."""
+    build(verbose=verbose)
+    if not force and os.path.exists(EXAMPLE_BIN) and \
+            os.path.getmtime(EXAMPLE_BIN) >= max(os.path.getmtime(EXAMPLE_SRC), os.path.getmtime(LIB)):
+        return EXAMPLE_BIN
+    cmd = [hipcc(), "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), EXAMPLE_SRC, "-L", PKG, "-levrep",
+           "-Wl,-rpath,$ORIGIN/../event_representation_study_amd", "-o", EXAMPLE_BIN]
+    if verbose:
+        print("[evrep build]", " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a != "--force"])
+    build_example(force="--force" in sys.argv)
