@@ -112,3 +112,22 @@ def test_tore_frame_modes(seed, oracle):
     y = ev[:, 1] - ev[:, 1].min() + 1
     want1 = oracle.tore(x, y, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
     np.testing.assert_allclose(got1, want1, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [30000, 65536, 65537])
+def test_clustered_windows(oracle, n):
+    """Clustered windows: every event inside seven sensor rows and a third of the stream on ONE pixel (long
+    rows for the column sort, dense chunks and a 10 000+-event pixel segment for the builders), next to a
+    sparse window in the same batch -- bit-exact vs the oracle."""
+    from event_representation_study_amd import engine as eng
+    H, W = 480, 640
+    ev = make_events(n, W, H, seed=n)
+    ev[:, 1] = ev[:, 1] % 7 + 180            # rows 180..186: one band of 60 rows gets everything
+    ev[: n // 3, 0] = 321                    # and a third of the stream on one column
+    ev[: n // 3, 1] = 183
+    eb = eng.EventBatch.from_numpy([ev, make_events(777, W, H, seed=1)], H, W)
+    got = eb.optimized().cpu().numpy()
+    assert_bit_equal(got[0], oracle.ergo12(ev, H, W), "clustered ergo12 n=%d" % n)
+    assert_bit_equal(got[1], oracle.ergo12(make_events(777, W, H, seed=1), H, W), "sparse neighbour window")
+    assert_bit_equal(eb.event_stack()[0].cpu().numpy(), oracle.event_stack(ev, H, W), "clustered event stack")
+    assert_bit_equal(eb.voxel(5)[0].cpu().numpy(), oracle.voxel(ev, H, W, 5), "clustered voxel")
