@@ -13,7 +13,7 @@
 //   5. emits the chunk as kParts part tiles through the ONE part-size LDS tile: lanes whose pixel
 //      lies in a later part keep their values in registers while the earlier part is streamed
 //      out with 16-byte-per-lane coalesced stores.  Halving the tile takes the float64 12-channel
-//      builder from 9 to 16 resident waves per CU while a wave still moves 12 KB, so almost twice the
+//      builder from 9 to 19 resident waves per CU while a wave still moves 12 KB, so almost twice the
 //      store bytes are in flight per CU (202 -> 168 us for the headline kernel).
 // No block barrier exists (one wave per workgroup; wave_phase() only orders LDS phases), every
 // output element is written exactly once, and HBM traffic per window = 16 B per event (binned
