@@ -22,6 +22,13 @@ signature, same (C, H, W) float32 result, same empty-input behaviour):
 per-channel (polarity class, statistic) descriptor; the two window-level normalisations (count / count.max(),
 min-max of the intensity) are strided float32 tensor ops on the builder's output, as in the reference.
 
+The three n_imagenet wrappers of the path's own builders that run in the reference -- reshape_then_optimized
+(:1025-1039), reshape_then_event_stack (:1042-1060), reshape_then_tore (:1080-1107) -- are mirrored here too
+(float64 event tensors with integral values, as load_event produces them without `reshape`).
+reshape_then_time_surface (:1110-1137) raises IndexError in the reference itself (a float `p` field indexes
+the surface memory, time_surface.py:67) and does so here; reshape_then_voxel_grid / _to_image go through tonic
+(absent; see representations/tonic_compat.py).
+
 Not built: the DiST sort family (reshape_then_acc_sort / _adj_sort, :513-1000) and the EST quantisation
 layer (ev-YOLOv6/yolov6/models/learned_repr.py:143-179, a learned layer that needs autograd).
 The product path needs the HIP library and an MI355X; there is no CPU fallback.
@@ -155,3 +162,50 @@ def reshape_then_acc_time_pol(event_tensor, augment=None, **kwargs):
 
 def reshape_then_acc_intensity(event_tensor, augment=None, **kwargs):
     return _single("acc_intensity", event_tensor, augment, kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# n_imagenet's wrappers of the path's own builders (imagenet.py:1002-1137)
+# ---------------------------------------------------------------------------------------------
+def fix_events_training(events):
+    """(N, 4) float array -> structured array with '<f8' fields x, y, t, p (imagenet.py:1002-1006)."""
+    ev = np.ascontiguousarray(np.asarray(events, dtype=np.float64).reshape(-1, 4))
+    return ev.view([("x", "<f8"), ("y", "<f8"), ("t", "<f8"), ("p", "<f8")]).reshape(-1)
+
+
+def _prep(event_tensor, augment, kwargs):
+    if augment is not None:
+        event_tensor = augment(event_tensor)
+    return fix_events_training(_as_f64(event_tensor)), kwargs.get("height", IMAGE_H), kwargs.get("width", IMAGE_W)
+
+
+def reshape_then_optimized(event_tensor, augment=None, **kwargs):
+    from .representations.optimized_representation import get_optimized_representation
+    data, H, W = _prep(event_tensor, augment, kwargs)
+    rep = get_optimized_representation(data, data.shape[0], H, W)
+    return torch.tensor(rep.transpose(2, 0, 1)).float()
+
+
+def reshape_then_event_stack(event_tensor, augment=None, **kwargs):
+    from .representations.event_stack import EventStack
+    data, H, W = _prep(event_tensor, augment, kwargs)
+    data["p"] = (data["p"] + 1) // 2
+    transformation = EventStack(12, data.shape[0], H, W)
+    post = transformation.post_stack(transformation.pre_stack(data, data[-1]["t"]))
+    return torch.tensor(post.transpose(3, 0, 1, 2)[..., 0]).float()
+
+
+def reshape_then_tore(event_tensor, augment=None, **kwargs):
+    from .representations.tore import events2ToreFeature
+    data, H, W = _prep(event_tensor, augment, kwargs)
+    x, y, ts, pol = data["x"], data["y"], data["t"], data["p"]
+    x = x - min(x) + 1          # the reference's shift to 1-based coordinates (:1095-1096)
+    y = y - min(y) + 1
+    rep = events2ToreFeature(x, y, ts, pol, ts[-1], 6, (H, W))
+    return torch.tensor(rep.transpose(2, 0, 1)).float()
+
+
+def reshape_then_time_surface(event_tensor, augment=None, **kwargs):
+    # the reference stores int8 polarities back into a '<f8' field and then indexes memory[p, y, x] with it
+    raise IndexError("only integers, slices (`:`), ellipsis (`...`), numpy.newaxis (`None`) and integer or boolean "
+                     "arrays are valid indices")

@@ -76,6 +76,13 @@ def main():
     for name in ("acc_count", "acc_time_pol"):
         g["empty_" + name] = getattr(ref, "reshape_then_" + name)(torch.zeros((0, 4), dtype=torch.float64),
                                                                 height=24, width=32).numpy()
+    # the wrappers of the path's own builders that run in the reference (imagenet.py:1025-1107): integral fields
+    for tag, N, W, H, seed in (("w1", 3000, 64, 48, 711), ("w2", 9000, 128, 96, 712)):
+        ev = mg.make_events(N, W, H, seed=seed).astype(np.float64)
+        g[tag + "_events"], g[tag + "_H"], g[tag + "_W"] = ev, H, W
+        for name in ("optimized", "event_stack", "tore"):
+            g["%s_%s" % (tag, name)] = getattr(ref, "reshape_then_" + name)(torch.from_numpy(ev.copy()),
+                                                                          height=H, width=W).numpy()
     np.savez_compressed(os.path.join(HERE, "nimagenet_acc.npz"), **g)
     print("wrote nimagenet_acc.npz", len(g), "arrays")
 

@@ -328,3 +328,23 @@ def test_nimagenet_acc_empty_and_batch(oracle):
         out = ni.accumulate_batch(name, wins, 120, 160).cpu().numpy()
         for b, e in enumerate(wins):
             np.testing.assert_array_equal(out[b], oracle.nimagenet_acc(name, e, 120, 160))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_nimagenet_builder_wrappers(tag):
+    """reshape_then_optimized / _event_stack / _tore (imagenet.py:1025-1107) against the reference's outputs."""
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    g = _ni_golden()
+    ev, H, W = g[tag + "_events"], int(g[tag + "_H"]), int(g[tag + "_W"])
+    for name, exact in (("optimized", True), ("event_stack", True), ("tore", False)):
+        got = getattr(ni, "reshape_then_" + name)(torch.from_numpy(ev.copy()), height=H, width=W)
+        want = g["%s_%s" % (tag, name)]
+        assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
+        if exact:
+            np.testing.assert_array_equal(got.numpy(), want)
+        else:
+            np.testing.assert_allclose(got.numpy(), want, rtol=1e-6, atol=1e-6)
+    with pytest.raises(IndexError):
+        ni.reshape_then_time_surface(torch.from_numpy(ev.copy()), height=H, width=W)
