@@ -822,4 +822,70 @@ __global__ __launch_bounds__(kWave) void k_polstats(const Rec *__restrict__ sort
     emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, r0, reduce);
 }
 
+// --------------------------------------------------------------------------------------------
+// F4: EST quantisation layer, forward (ev-YOLOv6/yolov6/models/learned_repr.py:143-179)
+// --------------------------------------------------------------------------------------------
+constexpr int kEstMaxBins = EVREP_MAX_CHANNELS / 2;
+
+struct EstParams {
+    int32_t C, nseg, nbucket, pad;
+    double lo, inv_width;          // bucket = (u - lo) * inv_width
+    float shift[kEstMaxBins];      // float32(i / (C - 1)), as `t - i_bin / (C - 1)` rounds it (:167)
+};
+
+// f(u) of the value MLP through its exact piecewise-linear form: segment k covers u < seg[3k] (ascending),
+// f = seg[3k+1] * u + seg[3k+2].
+__device__ inline float est_value(float u, const double *__restrict__ seg, const uint32_t *__restrict__ bucket,
+                                  const EstParams &P) {
+    const double ud = (double)u;
+    int g = (int)((ud - P.lo) * P.inv_width);
+    g = g < 0 ? 0 : (g >= P.nbucket ? P.nbucket - 1 : g);
+    int k = (int)bucket[g];
+    while (k + 1 < P.nseg && ud >= seg[3 * k]) ++k;
+    return (float)(seg[3 * k + 1] * ud + seg[3 * k + 2]);
+}
+
+// grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's float32 t / t.max().
+__global__ __launch_bounds__(kWave) void k_est(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+                                              const int64_t *__restrict__ off, const float *__restrict__ tnorm,
+                                              const double *__restrict__ seg, const uint32_t *__restrict__ bucket,
+                                              EstParams P, int H, int W, int nchunk, int span, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C2 = 2 * P.C;
+    WaveLds<float> w(smem, C2, span * kChunkPx);
+    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
+    const float *tw = tnorm + off[g.b];
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+        float lo_half[kEstMaxBins], hi_half[kEstMaxBins];
+#pragma unroll
+        for (int i = 0; i < kEstMaxBins; ++i) { lo_half[i] = 0.0f; hi_half[i] = 0.0f; }
+        for (uint32_t j = jb; j < je; ++j) {
+            const Rec e = get(j);
+            const float tn = tw[e.y];
+#pragma unroll
+            for (int i = 0; i < kEstMaxBins; ++i) {
+                if (i < P.C) {
+                    const float u = tn - P.shift[i];
+                    const float v = tn * est_value(u, seg, bucket, P);   // values = t * value_layer(t - i/(C-1))  (:167)
+                    if (e.w > 0) hi_half[i] = hi_half[i] + v; else lo_half[i] = lo_half[i] + v;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+            float v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kEstMaxBins; ++i) {
+                if (c == i && i < P.C) v = lo_half[i];
+                if (c == P.C + i && i < P.C) v = hi_half[i];
+            }
+            vals[c] = v;
+        }
+    };
+    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, r0, reduce);
+}
+
 }  // namespace evrep

@@ -261,6 +261,27 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     return EVREP_OK;
 }
 
+int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                    const float *tnorm, int32_t C, const double *segments, int32_t nseg, const uint32_t *buckets,
+                    int32_t nbucket, double lo, double hi, float *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (C < 2 || C > kEstMaxBins || !segments || nseg < 1 || !buckets || nbucket < 1 || !(hi > lo) || !out) return EVREP_EINVAL;
+    if (plan->total_events > 0 && !tnorm) return EVREP_EINVAL;
+    EstParams P;
+    memset(&P, 0, sizeof(P));
+    P.C = C; P.nseg = nseg; P.nbucket = nbucket;
+    P.lo = lo; P.inv_width = (double)nbucket / (hi - lo);
+    for (int i = 0; i < C; ++i) P.shift[i] = (float)((double)i / (double)(C - 1));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int span = builder_span(plan, (size_t)2 * C * 4);
+    k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx), stream>>>(
+        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
+        plan->nchunk, span, out);
+    LAUNCH_CHECK("k_est");
+    return EVREP_OK;
+}
+
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream_) {
     if (!plan || !workspace || !status) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -233,6 +233,22 @@ class EventBatch:
                   "evrep_polstats")
         return out
 
+    def est_voxel(self, tnorm, C, segments, buckets, lo, hi, out=None):
+        """EST quantisation layer forward (learned_repr.py:143-179) -> (B, H, W, 2C) float32; the value MLP is
+        passed as its piecewise-linear table (est.PiecewiseLinearKernel.device_table)."""
+        self.bin()
+        if tnorm.dtype != torch.float32 or tnorm.device != self.device or tnorm.numel() != self.total \
+                or not tnorm.is_contiguous():
+            raise ValueError("tnorm must be a contiguous float32 tensor with one entry per event on %s" % self.device)
+        if segments.dtype != torch.float64 or segments.dim() != 2 or segments.shape[1] != 3 or buckets.dtype != torch.int32:
+            raise ValueError("segments must be float64 (nseg, 3), buckets int32")
+        out = self._out(out, 2 * int(C), torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_est_voxel(*self._args(), _ptr(tnorm), int(C), _ptr(segments), int(segments.shape[0]),
+                                           _ptr(buckets), int(buckets.numel()), float(lo), float(hi), _ptr(out),
+                                           _stream_ptr()), "evrep_est_voxel")
+        return out
+
 
 class BinBuildPipeline:
     """Throughput path for a STREAM of batches: the binning pass of batch k+1 runs on a side HIP stream

@@ -152,6 +152,19 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
                    const double *tnorm, int32_t C, const int32_t *pol, const int32_t *stat, double tau, float *out,
                    void *stream);
 
+/* EST quantisation layer, forward only (ev-YOLOv6/yolov6/models/learned_repr.py:143-179): channel p*C + i of a
+ * pixel = sum over its events of t_n * f(t_n - i/(C-1)), float32, events of a pixel added in time order (what
+ * vox.put_(idx, values, accumulate=True) does on the CPU, :173).  f = the layer's value MLP (:9-43), a scalar
+ * function of a scalar with LeakyReLU activations, i.e. EXACTLY piecewise linear: the caller passes it as
+ * nseg segments {u_next, a, c} (f(u) = a*u + c for u below u_next, ascending, DEVICE double [nseg][3]) plus a
+ * uniform bucket index over [lo, hi] (DEVICE uint32 [nbucket]: first segment that can contain the bucket's left
+ * edge) -- built on the host from the MLP weights (event_representation_study_amd/est.py).
+ * tnorm DEVICE float [total_events] = t / t.max() per window (:159-160), indexed like `events`; p > 0 selects
+ * the second half of the channels (the layer expects p in {0, 1}).  out DEVICE (B,H,W,2C) float32, C <= 8. */
+int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                    const float *tnorm, int32_t C, const double *segments, int32_t nseg, const uint32_t *buckets,
+                    int32_t nbucket, double lo, double hi, float *out, void *stream);
+
 /* Synchronous read-backs (they synchronise `stream`). status: HOST uint32 [B];
  * bbox: HOST int32 [B,4] = xmin, ymin, xmax, ymax of each window's in-frame events. */
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream);

@@ -279,3 +279,33 @@ def nimagenet_acc(name, ev, H, W):
         else:
             raise ValueError(name)
         return np.stack([np.asarray(c) for c in ch]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# F4: EST quantisation layer forward, numpy restatement (ev-YOLOv6/yolov6/models/learned_repr.py:143-176)
+# ---------------------------------------------------------------------------------------------
+def est_voxel(events, dim, weights, slope=0.1):
+    """events (N,5) [x,y,t,p,b] float32, weights = (w1,b1,W2,b2,w3,b3) -> (B, 2C, H, W) float32 before the
+    letterbox: t /= t.max() per batch item (:159-160); for every bin i: values = t * mlp(t - i/(C-1)) (:167),
+    accumulated at x + W*y + W*H*i + W*H*C*p + W*H*C*2*b in event order (:163-173).  The MLP runs in float32."""
+    C, H, W = dim
+    ev = np.asarray(events, dtype=np.float32)
+    w1, b1, W2, b2, w3, b3 = [np.asarray(a, dtype=np.float32) for a in weights]
+    x, y, p, b = (ev[:, k].astype(np.int64) for k in (0, 1, 3, 4))
+    t = ev[:, 2].copy()
+    nb = int(1 + ev[-1, 4])
+    for bi in range(nb):
+        m = b == bi
+        if m.any():
+            t[m] = t[m] / t[m].max()
+    vox = np.zeros(2 * C * H * W * nb, dtype=np.float32)
+    base = x + W * y + W * H * C * p + W * H * C * 2 * b
+    leaky = lambda z: np.where(z > 0, z, np.float32(slope) * z)  # noqa: E731
+    for i in range(C):
+        u = t - np.float32(i / (C - 1))
+        h1 = leaky(np.outer(u, w1.reshape(-1)) + b1.reshape(-1))
+        h2 = leaky(h1 @ W2.T + b2.reshape(-1))
+        f = h2 @ w3.reshape(-1) + np.float32(np.asarray(b3).reshape(-1)[0])
+        np.add.at(vox, base + W * H * i, (t * f).astype(np.float32))
+    vox = vox.reshape(nb, 2, C, H, W)
+    return np.concatenate([vox[:, 0], vox[:, 1]], axis=1)

@@ -348,3 +348,31 @@ def test_nimagenet_builder_wrappers(tag):
             np.testing.assert_allclose(got.numpy(), want, rtol=1e-6, atol=1e-6)
     with pytest.raises(IndexError):
         ni.reshape_then_time_surface(torch.from_numpy(ev.copy()), height=H, width=W)
+
+
+# ------------------------------------------------------------------ F4: EST quantisation layer (forward)
+@pytest.mark.gpu
+def test_est_quantization_layer_forward(oracle):
+    """est.QuantizationLayer (k_est + the exact piecewise-linear form of the value MLP) against the reference's own
+    layer run on the CPU: voxel grid before the letterbox, and the letterboxed output."""
+    import torch
+    from event_representation_study_amd import est
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "est.npz"))
+    C, H, W = (int(v) for v in g["dim"])
+    weights = est.mlp_weights({k[2:]: g[k] for k in g.files if k.startswith("w_")})
+    layer = est.QuantizationLayer((C, H, W), est.PiecewiseLinearKernel(weights), image_size=int(g["image_size"]))
+    ev = torch.from_numpy(g["events"].copy())
+    vox = layer.voxel(ev).cpu().numpy()
+    want = g["voxel"]
+    assert vox.shape == want.shape and vox.dtype == np.float32
+    scale = np.abs(want).max()
+    assert np.abs(vox - want).max() <= 1e-5 * scale, np.abs(vox - want).max() / scale
+    assert np.array_equal(vox != 0, want != 0)            # exactly the touched (pixel, polarity, bin) entries
+    assert np.abs(vox - oracle.est_voxel(g["events"], (C, H, W), weights)).max() <= 1e-5 * scale
+    out = layer(ev).cpu().numpy()
+    assert out.shape == g["output"].shape and out.dtype == np.float32
+    np.testing.assert_allclose(out, g["output"], rtol=1e-5, atol=1e-5 * scale)
+    assert torch.equal(ev, torch.from_numpy(g["events"]))  # the caller's tensor is left alone
+    with pytest.raises(ValueError):
+        bad = g["events"].copy(); bad[0, 3] = -1
+        layer.voxel(torch.from_numpy(bad))
