@@ -29,8 +29,12 @@ reshape_then_time_surface (:1110-1137) raises IndexError in the reference itself
 the surface memory, time_surface.py:67) and does so here; reshape_then_voxel_grid / _to_image go through tonic
 (absent; see representations/tonic_compat.py).
 
-Not built: the DiST sort family (reshape_then_acc_sort / _adj_sort, :513-1000) and the EST quantisation
-layer (ev-YOLOv6/yolov6/models/learned_repr.py:143-179, a learned layer that needs autograd).
+reshape_then_acc_adj_sort (DiST, :873-999) = the same builder (per-polarity count, latest and earliest time)
+followed by the reference's own image-space statements (count clipping, 5x5 pooling, temporal discount, dense
+rank of the discounted timestamps) as torch ops on the GPU.
+
+Not built: reshape_then_acc_sort (:513-838; its denoise options call a function the reference file never
+defines).  The EST quantisation layer is in est.py.
 The product path needs the HIP library and an MI355X; there is no CPU fallback.
 """
 import numpy as np
@@ -162,6 +166,51 @@ def reshape_then_acc_time_pol(event_tensor, augment=None, **kwargs):
 
 def reshape_then_acc_intensity(event_tensor, augment=None, **kwargs):
     return _single("acc_intensity", event_tensor, augment, kwargs)
+
+
+CLIP_COUNT_RATE = 0.99   # imagenet.py:23
+DISC_ALPHA = 3.0         # imagenet.py:24
+
+
+def reshape_then_acc_adj_sort(event_tensor, augment=None, **kwargs):
+    """DiST (imagenet.py:873-999): discounted, sorted timestamp image, (2, H, W) float32."""
+    F = torch.nn.functional
+    if augment is not None:
+        event_tensor = augment(event_tensor)
+    H = kwargs.get("height", IMAGE_H)
+    W = kwargs.get("width", IMAGE_W)
+    # [pos count, pos latest, pos earliest, neg count, neg latest, neg earliest] from the HIP builder
+    pol, stat = [POS, POS, POS, NEG, NEG, NEG], [COUNT, TMAX, TMIN, COUNT, TMAX, TMIN]
+    ev = _as_f64(event_tensor)
+    if len(ev) == 0:
+        raise IndexError("empty event tensor")
+    rows, tn = _window(ev, H, W)
+    batch = EventBatch.from_numpy([rows], H, W, device=kwargs.get("device", "cuda:0"))
+    prim = batch.polstats(torch.from_numpy(tn).to(batch.device), pol, stat)[0]          # (H, W, 6)
+    halves = []
+    for k in (0, 3):
+        count, out, min_out = prim[..., k].clone(), prim[..., k + 1].clone(), prim[..., k + 2].clone()
+        # clip count (:893-901)
+        unique_count = torch.unique(count, return_counts=True)[1]
+        sum_subset = torch.cumsum(unique_count, dim=0)
+        th_clip = sum_subset[sum_subset < H * W * CLIP_COUNT_RATE].shape[0]
+        count[count > th_clip] = th_clip
+        min_out[count == 0] = 1.0                                                        # (:924-925)
+        patch = 5
+        neighbor = patch ** 2 * F.avg_pool2d(count.unsqueeze(0), patch, stride=1, padding=patch // 2)
+        disc = (F.max_pool2d(out.unsqueeze(0), patch, stride=1, padding=patch // 2)
+                + F.max_pool2d(-min_out.unsqueeze(0), patch, stride=1, padding=patch // 2)) / neighbor
+        out[count > 0] = out[count > 0] - DISC_ALPHA * disc.squeeze()[count > 0]         # (:957-961)
+        out[out < 0] = 0
+        out[neighbor.squeeze() == 1.0] = 0
+        flat = out.reshape(H * W)
+        val, idx = torch.sort(flat)                                                      # (:973-990)
+        unq, cnt = torch.unique_consecutive(val, return_counts=True)
+        srt = torch.zeros_like(flat)
+        srt[idx] = torch.repeat_interleave(torch.arange(unq.shape[0], device=flat.device), cnt).float() / unq.shape[0]
+        halves.append(srt.reshape(H, W))
+    res = torch.stack(halves, dim=2).permute(2, 0, 1).float()
+    return res if kwargs.get("keep_on_device", False) else res.cpu()
 
 
 # ---------------------------------------------------------------------------------------------

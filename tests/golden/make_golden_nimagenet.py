@@ -72,6 +72,9 @@ def main():
             a = out.numpy()
             assert a.dtype == np.float32, (name, a.dtype)
             g["%s_%s" % (tag, name)] = np.ascontiguousarray(a)
+    # DiST (reshape_then_acc_adj_sort, :873-999) on the same cases
+    for tag, ev, H, W in cases[:3]:
+        g[tag + "_acc_adj_sort"] = ref.reshape_then_acc_adj_sort(torch.from_numpy(ev.copy()), height=H, width=W).numpy()
     # the empty-tensor substitutions (imagenet.py:258-261,483-486)
     for name in ("acc_count", "acc_time_pol"):
         g["empty_" + name] = getattr(ref, "reshape_then_" + name)(torch.zeros((0, 4), dtype=torch.float64),

@@ -376,3 +376,18 @@ def test_est_quantization_layer_forward(oracle):
     with pytest.raises(ValueError):
         bad = g["events"].copy(); bad[0, 3] = -1
         layer.voxel(torch.from_numpy(bad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "pos"])
+def test_nimagenet_dist_adj_sort(tag):
+    """DiST (reshape_then_acc_adj_sort): HIP per-polarity statistics + the reference's image-space statements on the GPU."""
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    g = _ni_golden()
+    ev, H, W = g[tag + "_events"], int(g[tag + "_H"]), int(g[tag + "_W"])
+    got = ni.reshape_then_acc_adj_sort(torch.from_numpy(ev.copy()), height=H, width=W).numpy()
+    want = g[tag + "_acc_adj_sort"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    # same ranks everywhere; the final `rank.float() / n_unique` differs by one float32 ulp between the CPU and GPU divisions
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, equal_nan=True)
