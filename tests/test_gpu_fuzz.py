@@ -131,3 +131,18 @@ def test_clustered_windows(oracle, n):
     assert_bit_equal(got[1], oracle.ergo12(make_events(777, W, H, seed=1), H, W), "sparse neighbour window")
     assert_bit_equal(eb.event_stack()[0].cpu().numpy(), oracle.event_stack(ev, H, W), "clustered event stack")
     assert_bit_equal(eb.voxel(5)[0].cpu().numpy(), oracle.voxel(ev, H, W, 5), "clustered voxel")
+
+
+def test_batch_of_only_empty_windows():
+    """No event at all (a NULL events pointer is legal when total_events == 0): every builder returns its
+    background and every window reports EVREP_ST_EMPTY."""
+    import torch
+    from event_representation_study_amd import _lib, engine as eng
+    H, W = 33, 130
+    eb = eng.EventBatch.from_numpy([np.zeros((0, 4), np.int32)] * 3, H, W)
+    assert all(int(s) & _lib.ST_EMPTY for s in eb.status())
+    assert float(eb.optimized().abs().sum()) == 0.0
+    assert float(eb.event_stack().abs().sum()) == 0.0
+    assert float(eb.voxel(5).abs().sum()) == 0.0
+    assert float(eb.polstats(torch.zeros(0, dtype=torch.float64, device="cuda:0"), [0, 1], [0, 1]).abs().sum()) == 0.0
+    assert tuple(eb.tore(6, frame_mode=2).shape) == (3, H, W, 12)
