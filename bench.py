@@ -110,6 +110,9 @@ def gwd_leg(rank, world, pairs, device):
     for _ in range(4):     # warm: first launch of every kernel (torch's fill included), scratch allocations
         gwd_padded_l1(Xs, Xt, out=costs[0:1])
     costs.zero_()
+    if world > 1:          # warm the collective as well (communicator set-up is not part of a solve)
+        warm = [torch.zeros_like(costs) for _ in range(world)]
+        torch.distributed.all_gather(warm, costs)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
