@@ -21,3 +21,4 @@ python tools/gwd_matrix.py > $O/gwd_matrix.log 2>&1
 python tools/est_bench.py > $O/est_bench.json 2>/dev/null
 find $O -name "*.csv" | head -30
 tail -c 600 $O/bench.json
+python tools/precompute_reps.py --samples 256 2>/dev/null | grep "^{" > $O/precompute.json
