@@ -33,8 +33,11 @@ reshape_then_acc_adj_sort (DiST, :873-999) = the same builder (per-polarity coun
 followed by the reference's own image-space statements (count clipping, 5x5 pooling, temporal discount, dense
 rank of the discounted timestamps) as torch ops on the GPU.
 
-Not built: reshape_then_acc_sort (:513-838; its denoise options call a function the reference file never
-defines).  The EST quantisation layer is in est.py.
+reshape_then_acc_sort (:513-838) is mirrored for strict=False (the "sorted timestamp image": latest time INDEX per
+pixel, from the same builder with the dense time rank as the per-event value); strict=True depends on
+torch_scatter's arg-max tie-breaking (absent package) and raises NotImplementedError, the denoise options raise
+the NameError they raise in the reference (density_filter_event_image is never defined there).
+The EST quantisation layer is in est.py.
 The product path needs the HIP library and an MI355X; there is no CPU fallback.
 """
 import numpy as np
@@ -210,6 +213,56 @@ def reshape_then_acc_adj_sort(event_tensor, augment=None, **kwargs):
         srt[idx] = torch.repeat_interleave(torch.arange(unq.shape[0], device=flat.device), cnt).float() / unq.shape[0]
         halves.append(srt.reshape(H, W))
     res = torch.stack(halves, dim=2).permute(2, 0, 1).float()
+    return res if kwargs.get("keep_on_device", False) else res.cpu()
+
+
+TIME_SCALE = 1000000     # imagenet.py:21
+
+
+def reshape_then_acc_sort(event_tensor, augment=None, **kwargs):
+    """Sorted timestamp image (imagenet.py:513-838), strict=False: per pixel (and polarity) the LATEST time index,
+    optionally with the binary event image and quantised copies; (C, H, W) float32."""
+    if augment is not None:
+        event_tensor = augment(event_tensor)
+    global_time, neglect, use_image, strict = (kwargs[k] for k in ("global_time", "neglect_polarity", "use_image", "strict"))
+    H = kwargs.get("height", IMAGE_H)
+    W = kwargs.get("width", IMAGE_W)
+    ev_t = event_tensor if isinstance(event_tensor, torch.Tensor) else torch.as_tensor(np.asarray(event_tensor))
+    time_idx = (ev_t[:, 2] * TIME_SCALE).long()
+    if global_time:   # dense rank of the microsecond timestamps (:521-525)
+        mem, cnt = torch.unique_consecutive(time_idx, return_counts=True)
+        time_idx = torch.repeat_interleave(torch.arange(mem.shape[0]), cnt)
+    ev_t[:, 2] = time_idx                      # the reference overwrites the caller's time column as well (:525,539)
+    if use_image and kwargs["denoise_image"]:
+        raise NameError("name 'density_filter_event_image' is not defined")   # what the reference raises (:556,679)
+    if strict:
+        raise NotImplementedError("strict=True needs torch_scatter's arg-max tie-breaking (package absent)")
+    if kwargs["denoise_sort"]:
+        raise NameError("name 'density_filter_event_image' is not defined")   # (:609,777)
+    ev = _as_f64(ev_t)
+    if len(ev) == 0:
+        raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0")
+    rows, _ = _window(ev, H, W)
+    batch = EventBatch.from_numpy([rows], H, W, device=kwargs.get("device", "cuda:0"))
+    tval = torch.from_numpy(np.ascontiguousarray(ev[:, 2])).to(batch.device)       # float64 time index per event
+    classes = [ANY] if neglect else [POS, NEG]
+    pol = [c for c in classes for _ in (0, 1)]
+    stat = [FLAG, TMAX] * len(classes)
+    prim = batch.polstats(tval, pol, stat)[0]                                      # (H, W, 2 * len(classes))
+    q = kwargs["quantize_sort"]
+    chans = []
+    for k in range(len(classes)):
+        image, srt = prim[..., 2 * k], prim[..., 2 * k + 1]
+        if not bool((srt > 0.0).any()):        # hot_event_sort.max() on an empty selection (:592-594,744-746)
+            raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0")
+        if q is not None:
+            if type(q) == int:
+                srt = torch.round(srt * q) / q
+            elif type(q) == list:
+                srt = torch.stack([torch.round(srt * qs) / qs for qs in q], dim=2)
+        parts = ([image.unsqueeze(-1)] if use_image else []) + [srt if srt.dim() == 3 else srt.unsqueeze(-1)]
+        chans.append(torch.cat(parts, dim=2))
+    res = torch.cat(chans, dim=2).permute(2, 0, 1).float()
     return res if kwargs.get("keep_on_device", False) else res.cpu()
 
 

@@ -75,6 +75,16 @@ def main():
     # DiST (reshape_then_acc_adj_sort, :873-999) on the same cases
     for tag, ev, H, W in cases[:3]:
         g[tag + "_acc_adj_sort"] = ref.reshape_then_acc_adj_sort(torch.from_numpy(ev.copy()), height=H, width=W).numpy()
+    # sorted timestamp image (reshape_then_acc_sort, :513-838), strict=False, a few keyword combinations
+    base = dict(strict=False, denoise_image=False, denoise_sort=False)
+    combos = {"s0": dict(global_time=True, neglect_polarity=True, use_image=True, quantize_sort=None),
+              "s1": dict(global_time=True, neglect_polarity=False, use_image=True, quantize_sort=8),
+              "s2": dict(global_time=False, neglect_polarity=False, use_image=False, quantize_sort=[4, 16]),
+              "s3": dict(global_time=False, neglect_polarity=True, use_image=False, quantize_sort=None)}
+    for tag, ev, H, W in cases[:2]:
+        for ck, kw in combos.items():
+            g["%s_acc_sort_%s" % (tag, ck)] = ref.reshape_then_acc_sort(
+                torch.from_numpy(ev.copy()), height=H, width=W, **base, **kw).numpy()
     # the empty-tensor substitutions (imagenet.py:258-261,483-486)
     for name in ("acc_count", "acc_time_pol"):
         g["empty_" + name] = getattr(ref, "reshape_then_" + name)(torch.zeros((0, 4), dtype=torch.float64),

@@ -391,3 +391,35 @@ def test_nimagenet_dist_adj_sort(tag):
     assert got.shape == want.shape and got.dtype == np.float32
     # same ranks everywhere; the final `rank.float() / n_unique` differs by one float32 ulp between the CPU and GPU divisions
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_nimagenet_acc_sort(tag):
+    """reshape_then_acc_sort, strict=False: latest time index per pixel from the HIP builder, for the keyword
+    combinations the goldens hold -- bit-exact; plus the caller-visible side effect and the reference's errors."""
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    g = _ni_golden()
+    ev, H, W = g[tag + "_events"], int(g[tag + "_H"]), int(g[tag + "_W"])
+    base = dict(strict=False, denoise_image=False, denoise_sort=False)
+    combos = {"s0": dict(global_time=True, neglect_polarity=True, use_image=True, quantize_sort=None),
+              "s1": dict(global_time=True, neglect_polarity=False, use_image=True, quantize_sort=8),
+              "s2": dict(global_time=False, neglect_polarity=False, use_image=False, quantize_sort=[4, 16]),
+              "s3": dict(global_time=False, neglect_polarity=True, use_image=False, quantize_sort=None)}
+    for ck, kw in combos.items():
+        t = torch.from_numpy(ev.copy())
+        got = ni.reshape_then_acc_sort(t, height=H, width=W, **base, **kw)
+        want = g["%s_acc_sort_%s" % (tag, ck)]
+        assert got.dtype == torch.float32 and tuple(got.shape) == want.shape, (ck, got.shape, want.shape)
+        np.testing.assert_array_equal(got.numpy(), want, err_msg=ck)
+        # the caller's time column now holds the time index, as after the reference call
+        assert float(t[:, 2].max()) >= 1.0 and bool((t[:, 2] == t[:, 2].round()).all())
+    with pytest.raises(NotImplementedError):
+        ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, global_time=True, neglect_polarity=True,
+                                 use_image=False, quantize_sort=None, strict=True, denoise_image=False, denoise_sort=False)
+    with pytest.raises(NameError):
+        ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, global_time=True, neglect_polarity=True,
+                                 use_image=False, quantize_sort=None, strict=False, denoise_image=False, denoise_sort=True)
+    with pytest.raises(KeyError):
+        ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W)
