@@ -9,9 +9,16 @@ window size, gen1_2yolo.py:41), batch of 32 windows.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch under ``python -m torch.distributed.run --nproc-per-node N``; every rank owns its own
-windows (weak scaling, no data-path collective); the only collective is the all-gather of GWD scalars.
-Rank 0 prints ONE JSON line.
+For N > 1 the driver launches it under ``python -m torch.distributed.run --nproc-per-node N``; run as a plain
+``python bench.py --gpus N`` it re-launches ITSELF that way (one rank per GPU, rendezvous on 127.0.0.1), so
+the one entry point always runs N ranks -- a world size that differs from --gpus is an error, never a silent
+1-GPU run.  Every rank owns its own windows (weak scaling, no data-path collective); the only collective is
+the all-gather of GWD scalars.  Rank 0 prints ONE JSON line.
+
+``EVREP_BENCH_DRYRUN=1`` (tests/test_bench_launcher_cpu.py) keeps the launcher, the rendezvous, the barriers,
+the MAX-over-ranks timing and the all-gather but runs them on the gloo backend with the GPU legs replaced by
+no-ops, so the N > 1 control flow is exercised on a CPU-only box; the line it prints carries "dry_run": true
+and is not a measurement.
 """
 import argparse
 import json
@@ -43,7 +50,8 @@ def parse():
     ap.add_argument("--out-dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gwd", action="store_true")
-    ap.add_argument("--gwd-pairs", type=int, default=36)
+    ap.add_argument("--gwd-pairs", type=int, default=144,
+                    help="GWD solves of the wall-time leg; 144 = the metric's 12x12 representation matrix")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -97,56 +105,98 @@ def cpu_baseline(events_per_window, budget_s=12.0, threads_budget_s=6.0):
     return res
 
 
-def gwd_leg(rank, world, pairs, device):
+def gwd_leg(rank, world, pairs, device, dry=False):
     """Wall time of `pairs` GWD solves at the reference's size (n ~ 12.5k events/quadrant, m = 14.4k
     representation points of C+2 = 14 features), sharded over ranks, scalars all-gathered."""
-    from event_representation_study_amd.engine import gwd_padded_l1
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     rng = np.random.default_rng(77)
     n, m = 12500, 14400
-    Xs = torch.from_numpy(rng.random((n, 4))).to(device)
-    Xt = torch.from_numpy(rng.random((m, 14)) * np.array([255.0] * 12 + [1.0, 1.0])).to(device)
+    if dry:
+        def solve(i, out):
+            out.fill_(float(i + 1))
+    else:
+        from event_representation_study_amd.engine import gwd_padded_l1
+        Xs = torch.from_numpy(rng.random((n, 4))).to(device)
+        Xt = torch.from_numpy(rng.random((m, 14)) * np.array([255.0] * 12 + [1.0, 1.0])).to(device)
+
+        def solve(i, out):
+            gwd_padded_l1(Xs, Xt, out=out)   # written in place: no host sync between solves
     mine = list(range(rank, pairs, world))
     costs = torch.zeros(pairs, dtype=torch.float64, device=device)
     for _ in range(4):     # warm: first launch of every kernel (torch's fill included), scratch allocations
-        gwd_padded_l1(Xs, Xt, out=costs[0:1])
+        solve(0, costs[0:1])
     costs.zero_()
     if world > 1:          # warm the collective as well (communicator set-up is not part of a solve)
         warm = [torch.zeros_like(costs) for _ in range(world)]
         torch.distributed.all_gather(warm, costs)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for i in mine:
-        gwd_padded_l1(Xs, Xt, out=costs[i:i + 1])   # written in place: no host sync between solves
+        solve(i, costs[i:i + 1])
     if world > 1:
         gathered = [torch.zeros_like(costs) for _ in range(world)]
         torch.distributed.all_gather(gathered, costs)
         costs = torch.stack(gathered).sum(0)
-    torch.cuda.synchronize()
+    sync()
     el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el = float(t.item())
     entries = pairs * (n * n + m * m)
-    return {"pairs": pairs, "n": n, "m": m, "wall_ms": el * 1e3, "kernel_entries_per_s": entries / el,
-            "first_cost": float(costs[0].item())}
+    res = {"pairs": pairs, "n": n, "m": m, "wall_ms": el * 1e3, "kernel_entries_per_s": entries / el,
+           "n_ranks": world, "solves_per_rank": [len(range(r, pairs, world)) for r in range(world)],
+           "all_solved": bool((costs != 0).all().item()), "first_cost": float(costs[0].item())}
+    return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: run N ranks of this file under
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=dict(os.environ, EVREP_BENCH_SELF_LAUNCHED="1"))
 
 
 def main():
     args = parse()
+    dry = os.environ.get("EVREP_BENCH_DRYRUN") == "1"
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus and not launched:
+            raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+    if args.gpus > 1 and not launched:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:   # never a silently smaller (or larger) run than the one asked for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if dry:
+        device = torch.device("cpu")
+        sync = lambda: None  # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
-
-    from event_representation_study_amd.engine import BinBuildPipeline, EventBatch
-    from event_representation_study_amd.synthetic import make_events
+        if dry:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
 
     B, N = args.batch, args.events
     dtype = torch.float64 if args.out_dtype == "f64" else torch.float32
@@ -154,56 +204,62 @@ def main():
     # binning pass of step k+1 overlaps the builder of step k on a second HIP stream (measured: ~5 % more
     # throughput, but the builder's own launch time is inflated by the sharing, so it is not the default)
     nbuf = 2 if args.pipeline else 1
-    batches, outs = [], []
-    for j in range(nbuf):
-        wins = [make_events(N, W, H, seed=rank * 100000 + j * B + i) for i in range(B)]  # seed = window index
-        batches.append(EventBatch.from_numpy(wins, H, W, device=device))
-        outs.append(torch.empty((B, H, W, C), dtype=dtype, device=device))
-    pipe = BinBuildPipeline(device) if args.pipeline else None
+    pipe = None
+    if dry:
+        def step(k, ev_pair=None):
+            pass
+    else:
+        from event_representation_study_amd.engine import BinBuildPipeline, EventBatch
+        from event_representation_study_amd.synthetic import make_events
+        batches, outs = [], []
+        for j in range(nbuf):
+            wins = [make_events(N, W, H, seed=rank * 100000 + j * B + i) for i in range(B)]  # seed = window index
+            batches.append(EventBatch.from_numpy(wins, H, W, device=device))
+            outs.append(torch.empty((B, H, W, C), dtype=dtype, device=device))
+        pipe = BinBuildPipeline(device) if args.pipeline else None
 
-    def build(k, ev_pair):
-        def fn(batch):
-            if ev_pair is not None:
-                ev_pair[0].record()
-            batch.optimized(scale=1.0, dtype=dtype, out=outs[k % nbuf])
-            if ev_pair is not None:
-                ev_pair[1].record()
-        return fn
+        def build(k, ev_pair):
+            def fn(batch):
+                if ev_pair is not None:
+                    ev_pair[0].record()
+                batch.optimized(scale=1.0, dtype=dtype, out=outs[k % nbuf])
+                if ev_pair is not None:
+                    ev_pair[1].record()
+            return fn
 
-    def step(k, ev_pair=None):
-        batch = batches[k % nbuf]
-        if pipe is None:
-            batch.rebin()
-            build(k, ev_pair)(batch)
-        else:
-            pipe.submit(batch, build(k, ev_pair))
+        def step(k, ev_pair=None):
+            batch = batches[k % nbuf]
+            if pipe is None:
+                batch.rebin()
+                build(k, ev_pair)(batch)
+            else:
+                pipe.submit(batch, build(k, ev_pair))
 
     for k in range(args.warmup):
         step(k)
     if pipe is not None:
         pipe.drain()
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
+    pairs = None if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                              for _ in range(args.steps)]
+    sync()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k, pairs[k])
+        step(k, None if dry else pairs[k])
     if pipe is not None:
         pipe.drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     t = torch.tensor([el], dtype=torch.float64, device=device)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    el = float(t.item())
+    el = max(float(t.item()), 1e-9)
 
-    builder_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))  # the k_mdes launch, HIP events on its stream
     elem = 8 if dtype == torch.float64 else 4
     alg_bytes = B * (16 * N + elem * H * W * C)  # read every event once, write every output once
-    achieved = alg_bytes / (builder_ms * 1e-3) / 1e9
 
     result = {
         "metric": "events/sec/GPU (OptimizedRep, Gen1 640x480) + 12-rep GWD matrix wall-time",
@@ -223,33 +279,40 @@ def main():
                                % (N, B, "" if not pipe else " (bin of step k+1 overlapped with build of step k on a second stream)"),
                    "pipeline": pipe is not None,
                    "events_per_window": N, "batch": B, "height": H, "width": W, "channels": C,
-                   "parallelism": "windows sharded over %d GPU(s), no data-path collective" % world},
+                   "parallelism": "windows sharded over %d GPU(s), one process per GPU, no data-path collective" % world},
         "windows_per_s": world * B * args.steps / el,
         "algorithmic_GBps_whole_step": world * alg_bytes * args.steps / el / 1e9,
-        "roofline": {"bound": "hbm", "kernel": "k_mdes<%s>" % ("double" if elem == 8 else "float"),
-                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "avg_launch_ms": builder_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }
-    tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):
-        try:
-            with open(tr) as f:
-                trj = json.load(f)
-            key = "k_mdes_f64" if elem == 8 else "k_mdes_f32"
-            if key in trj and trj[key].get("batch") == B and trj[key].get("events") == N:
-                result["roofline"]["traffic"] = trj[key]["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = trj[key].get("source")
-        except Exception:
-            pass
+    if dry:
+        result["dry_run"] = True      # launcher / rendezvous / collectives only: NOT a measurement
+        result["value"] = 0.0
+    else:
+        builder_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))  # the k_mdes launch, HIP events on its stream
+        achieved = alg_bytes / (builder_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": "k_mdes<%s>" % ("double" if elem == 8 else "float"),
+                              "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": builder_ms,
+                              "algorithmic_bytes_per_launch": alg_bytes}
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                with open(tr) as f:
+                    trj = json.load(f)
+                key = "k_mdes_f64" if elem == 8 else "k_mdes_f32"
+                if key in trj and trj[key].get("batch") == B and trj[key].get("events") == N:
+                    result["roofline"]["traffic"] = trj[key]["hbm_bytes_per_launch"]
+                    result["roofline"]["traffic_source"] = "replayed from profiles/traffic.json (%s); not collected in this run" \
+                        % trj[key].get("source")
+            except Exception:
+                pass
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
-        g = gwd_leg(rank, world, args.gwd_pairs, device)
-        result["gwd"] = g
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         result["cpu_baseline"] = cpu_baseline(N)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

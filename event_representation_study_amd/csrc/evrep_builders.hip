@@ -423,8 +423,10 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
         const Rec e = get(je - 1);  // ndarray.put is last-write-wins (event_stack.py:125)
         int p = e.w;
-        if (premap) p = (p + 1) >> 1;                        // (p + 1) // 2   (gen1_transforms.py:34)
-        const float v = (float)(int8_t)(2 * p - 1) * scale;  // 2*p - 1 as int8 (event_stack.py:18)
+        if (premap == 1) p = (p + 1) >> 1;                   // (p + 1) // 2   (gen1_transforms.py:34)
+        // 2*p - 1 as int8 (event_stack.py:18); premap 2: the column already holds that int8 value (the host
+        // formed it, negated for the reversed "future" half, event_stack.py:35)
+        const float v = (float)(int8_t)(premap == 2 ? p : 2 * p - 1) * scale;
 #pragma unroll
         for (int l = 0; l < EVREP_MAX_CHANNELS; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
     };
@@ -612,19 +614,22 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    if (n_win <= 0) return;
+    // an empty window has no bounding box: mode 0 has nothing to write (the dispatcher raises on it), the
+    // full-frame modes still owe the caller the empty-FIFO background in every element of the window's slice
+    const bool empty = n_win <= 0;
+    if (empty && frame_mode == 0) return;
     const WindowMeta m = meta[b];
     int x0 = 0, y0 = 0, Hf = H, Wf = W;
-    if (frame_mode == 0 || frame_mode == 1) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
+    if (!empty && (frame_mode == 0 || frame_mode == 1)) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
     if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
     if (orow >= Hf || oc0 >= Wf) return;
     const int npix = min(span * kChunkPx, Wf - oc0);
     const int row = orow + y0;  // sensor row feeding this output row
-    const int T = sample_times ? sample_times[b] : ev[beg + n_win - 1].z;
+    const int T = empty ? 0 : (sample_times ? sample_times[b] : ev[beg + n_win - 1].z);
     // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
     uint32_t cs = 0, ce = 0;
     const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
-    if (row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
+    if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
         const uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
         cs = co[ch_lo];
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
 __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                 const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, int span, int bins, int mode, double scale,
-                                                double *__restrict__ out) {
+                                                const int64_t *__restrict__ t_range, double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<double> w(smem, bins, span * kChunkPx);
     const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
@@ -703,6 +708,8 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
     const int64_t n_win = off[g.b + 1] - beg;
     double t0 = 0.0, den = 1.0;
     if (n_win > 0) { t0 = (double)ev[beg].z; den = (double)ev[beg + n_win - 1].z - t0; }
+    // explicit [t0_us, t1_us] of ev-licious' events_to_voxel_grid (utils.py:60-63), mode 2 only
+    if (t_range) { t0 = (double)t_range[2 * g.b]; den = (double)(t_range[2 * g.b + 1] - t_range[2 * g.b]); }
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[EVREP_MAX_CHANNELS]) {
 #pragma unroll
         for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
@@ -724,7 +731,9 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
                     bpos = num / den;
                     if (e.w == 0) p = -1.0;
                 }
-                if (!(bpos >= 0.0 && bpos < 1.0e9)) continue;  // flat time span (0/0): the reference yields NaN garbage
+                // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
+                // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
+                if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
                 const int bi = (int)bpos;
                 const int blim = bi + pass;
                 if (blim < bins) {

@@ -1,5 +1,6 @@
 // evrep_capi.hip -- the extern "C" surface declared in include/evrep.h: argument checks, workspace
 // carving and kernel launches.  No allocation, no global state besides the last HIP error string.
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -224,14 +225,20 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
 
 int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t bins,
                 int32_t mode, double scale, double *out, void *stream_) {
+    return evrep_voxel_range(plan, events, offsets, workspace, bins, mode, scale, nullptr, out, stream_);
+}
+
+int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      int32_t bins, int32_t mode, double scale, const int64_t *t_range, double *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
+    if (t_range && mode != 2) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)bins * 8);
     k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
-        plan->W, plan->nchunk, span, bins, mode, scale, out);
+        plan->W, plan->nchunk, span, bins, mode, scale, t_range, out);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }
@@ -282,32 +289,32 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     return EVREP_OK;
 }
 
+// Both read-backs are ONE strided copy of a field of every window's 64-byte WindowMeta (2-D copy: row = window).
+static int read_meta_field(const evrep_plan *plan, const void *workspace, size_t field_off, size_t field_bytes,
+                           void *dst, hipStream_t stream) {
+    const char *meta = static_cast<const char *>(workspace) + plan->off_meta;
+    int rc = hip_check(hipMemcpy2DAsync(dst, field_bytes, meta + field_off, sizeof(WindowMeta), field_bytes,
+                                        (size_t)plan->B, hipMemcpyDeviceToHost, stream), "hipMemcpy2DAsync(meta)");
+    if (rc) return rc;
+    return hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
+
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream_) {
     if (!plan || !workspace || !status) return EVREP_EINVAL;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int rc = hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    if (rc) return rc;
-    const WindowMeta *meta = CWS(WindowMeta, off_meta);
-    for (int b = 0; b < plan->B; ++b) {
-        WindowMeta m;
-        rc = hip_check(hipMemcpy(&m, meta + b, sizeof(m), hipMemcpyDeviceToHost), "hipMemcpy(meta)");
-        if (rc) return rc;
-        status[b] = m.status;
-    }
-    return EVREP_OK;
+    return read_meta_field(plan, workspace, offsetof(WindowMeta, status), sizeof(uint32_t), status,
+                           static_cast<hipStream_t>(stream_));
 }
 
 int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox, void *stream_) {
     if (!plan || !workspace || !bbox) return EVREP_EINVAL;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int rc = hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    static_assert(offsetof(WindowMeta, ymax) - offsetof(WindowMeta, xmin) == 12, "xmin, xmax, ymin, ymax are contiguous");
+    int rc = read_meta_field(plan, workspace, offsetof(WindowMeta, xmin), 4 * sizeof(int32_t), bbox,
+                             static_cast<hipStream_t>(stream_));
     if (rc) return rc;
-    const WindowMeta *meta = CWS(WindowMeta, off_meta);
-    for (int b = 0; b < plan->B; ++b) {
-        WindowMeta m;
-        rc = hip_check(hipMemcpy(&m, meta + b, sizeof(m), hipMemcpyDeviceToHost), "hipMemcpy(meta)");
-        if (rc) return rc;
-        bbox[4 * b + 0] = m.xmin; bbox[4 * b + 1] = m.ymin; bbox[4 * b + 2] = m.xmax; bbox[4 * b + 3] = m.ymax;
+    for (int b = 0; b < plan->B; ++b) {  // stored xmin, xmax, ymin, ymax -> reported xmin, ymin, xmax, ymax
+        const int32_t t = bbox[4 * b + 1];
+        bbox[4 * b + 1] = bbox[4 * b + 2];
+        bbox[4 * b + 2] = t;
     }
     return EVREP_OK;
 }

@@ -8,6 +8,7 @@ The per-sample functions that mirror the reference's Python names
 (``representations/*.py``) are thin wrappers over this class with B = 1.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -156,10 +157,13 @@ class EventBatch:
         return out
 
     def event_stack(self, stack_size=12, premap=True, scale=1.0, out=None):
+        """EventStack levels -> (B, H, W, stack_size) float32.  premap True/1: p -> (p + 1) // 2 first (the
+        dispatcher, gen1_transforms.py:34); False/0: p is {0, 1}, the kernel forms 2p - 1; 2: the p column
+        already holds the final int8 polarity value (EventStack.pre_stack forms it on the host)."""
         self.bin()
         out = self._out(out, stack_size, torch.float32)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_event_stack(*self._args(), int(stack_size), int(bool(premap)), float(scale),
+            check(self.lib.evrep_event_stack(*self._args(), int(stack_size), int(premap), float(scale),
                                              _ptr(out), _stream_ptr()), "evrep_event_stack")
         return out
 
@@ -207,12 +211,21 @@ class EventBatch:
             views.append(flat[: hb * wb * 2 * k].view(hb, wb, 2 * k))
         return views
 
-    def voxel(self, bins=5, mode=0, scale=1.0, out=None):
+    def voxel(self, bins=5, mode=0, scale=1.0, out=None, t_range=None):
+        """Voxel grids -> (B, H, W, bins) float64.  mode 0: compute_repr; 1: tonic ToVoxelGrid; 2: ev-licious
+        events_to_voxel_grid (t_range: optional (B, 2) int64 [t0_us, t1_us] per window, mode 2 only)."""
         self.bin()
         out = self._out(out, bins, torch.float64)
+        rptr = ctypes.c_void_p(None)
+        if t_range is not None:
+            tr = torch.as_tensor(np.asarray(t_range, dtype=np.int64)).reshape(-1)
+            if tr.numel() != 2 * self.B:
+                raise ValueError("t_range must hold (t0, t1) for each of the %d windows" % self.B)
+            tr = tr.to(self.device)
+            rptr = _ptr(tr)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_voxel(*self._args(), int(bins), int(mode), float(scale), _ptr(out), _stream_ptr()),
-                  "evrep_voxel")
+            check(self.lib.evrep_voxel_range(*self._args(), int(bins), int(mode), float(scale), rptr, _ptr(out),
+                                             _stream_ptr()), "evrep_voxel_range")
         return out
 
     def polstats(self, tnorm, pol, stat, tau=0.3, out=None):
@@ -260,6 +273,9 @@ class BinBuildPipeline:
         for batch, out in work:              # e.g. alternating between two resident batches
             pipe.submit(batch, lambda b: b.optimized(out=out))
         pipe.drain()
+
+    A batch's events may be refilled (on the caller's stream) once its build has been issued, i.e. after the
+    submit() that followed its own; they must not change while its build is still pending.
     """
 
     def __init__(self, device=None):
@@ -267,23 +283,30 @@ class BinBuildPipeline:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.bin_stream = torch.cuda.Stream(device=self.device)
         self._pending = None          # (batch, build_fn, binned_event)
-        self._built = {}              # id(batch) -> event recorded after the last build that read its workspace
+        # batch -> event recorded after the last build that read its workspace; weak keys: a recycled id() of a
+        # collected batch must not hand its event to an unrelated new batch
+        self._built = weakref.WeakKeyDictionary()
 
     def _start_bin(self, batch):
         main = torch.cuda.current_stream(self.device)
-        done = self._built.get(id(batch))
+        done = self._built.get(batch)
         with torch.cuda.stream(self.bin_stream):
+            # the caller may have (re)filled batch.events on its own stream since the last build: ALWAYS order the
+            # binning pass behind the caller's stream, and behind the last build that read this workspace
+            self.bin_stream.wait_stream(main)
             if done is not None:
-                self.bin_stream.wait_event(done)      # the workspace is free once its previous build finished
-            else:
-                self.bin_stream.wait_stream(main)     # first use: inputs were produced on the caller's stream
+                self.bin_stream.wait_event(done)
             batch.rebin()
             ev = torch.cuda.Event()
             ev.record(self.bin_stream)
         return ev
 
     def submit(self, batch, build_fn):
-        """Queue `batch`: its binning starts now on the side stream; the PREVIOUS submission is built now."""
+        """Queue `batch`: its binning starts now on the side stream; the PREVIOUS submission is built now.
+        Submitting the batch that is still pending builds it first (its workspace cannot be re-binned while a
+        build of it is outstanding)."""
+        if self._pending is not None and self._pending[0] is batch:
+            self._flush()
         ev = self._start_bin(batch)
         self._flush()
         self._pending = (batch, build_fn, ev)
@@ -298,7 +321,7 @@ class BinBuildPipeline:
         res = build_fn(batch)
         done = torch.cuda.Event()
         done.record(main)
-        self._built[id(batch)] = done
+        self._built[batch] = done
         return res
 
     def drain(self):

@@ -32,7 +32,7 @@ def _voxel_grid(events, transform, height, width, num_events):
 
 
 def _optimized(events, transform, height, width, num_events):
-    batch = single_batch(events, height, width)
+    batch = single_batch(events, height, width, truncate=True, rebase_t=True)   # MDES.stack's own casts (:26-33)
     raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
     return batch.optimized(scale=float(SCALE))[0].cpu().numpy()
 

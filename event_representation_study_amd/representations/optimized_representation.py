@@ -7,6 +7,8 @@ N_CHANNELS = 12
 def get_optimized_representation(reshaped_return_data, num_events, height, width):
     """ERGO-12: the 12 (window, function, aggregation) triples of the reference's second search,
     as an (H, W, 12) float64 array."""
-    batch = single_batch(reshaped_return_data, height, width)
+    # x, y, p -> int32, t -> int64 and t - t.min(), as MixedDensityEventStack.stack does (:26-33); n_imagenet hands
+    # all-float64 fields (imagenet.py:1002-1006)
+    batch = single_batch(reshaped_return_data, height, width, truncate=True, rebase_t=True)
     raise_for_status(batch, allow_oob=True, what="get_optimized_representation")
     return batch.optimized(scale=1.0)[0].cpu().numpy()

@@ -19,7 +19,7 @@ class MixedDensityEventStack(object):
         if self.stacking_type != "SBN":
             raise NotImplementedError("only the 'SBN' stacking the reference selects is implemented")
         windows, funcs, aggs = self.indexes_functions_aggregations
-        batch = single_batch(event_sequence, self.height, self.width)
+        batch = single_batch(event_sequence, self.height, self.width, truncate=True, rebase_t=True)   # astype + t - t.min(), :26-33
         raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
         from ... import _lib
         def window(v):      # anything that cannot index the 7-window list fails the channel (-> zeros)

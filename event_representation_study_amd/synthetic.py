@@ -48,15 +48,49 @@ def to_structured(ev):
     return out
 
 
-def from_structured(rec):
-    """Structured x,y,t,p record array -> (n,4) int32 (values must be integral)."""
+I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
+
+
+def field_to_int64(col, name, truncate=False):
+    """One event field -> int64.  Integer fields pass through; float fields must hold integral values unless
+    ``truncate`` -- the reference's own ``.astype(np.int32)`` / ``.astype(np.int64)`` of
+    MixedDensityEventStack.stack and EventStack.pre_stack (mixed_density_event_stack.py:26-29,
+    event_stack.py:16-19), i.e. C truncation toward zero."""
+    col = np.asarray(col)
+    if col.dtype.kind == "f":
+        if col.size and not np.all(np.isfinite(col)):
+            raise OverflowError("non-finite %r values" % name)
+        if col.size and not truncate and not np.all(col == np.rint(col)):
+            raise NotImplementedError("non-integral %r values are not supported by the int32 device layout" % name)
+        return np.trunc(col).astype(np.int64)
+    if col.dtype.kind not in "iub":
+        raise TypeError("event field %r has dtype %s" % (name, col.dtype))
+    if col.dtype == np.uint64 and col.size and col.max() > np.iinfo(np.int64).max:
+        raise OverflowError("event field %r exceeds int64" % name)
+    return col.astype(np.int64)
+
+
+def int64_to_int32(v, name):
+    """Range-checked narrowing: values outside int32 raise OverflowError instead of wrapping silently."""
+    if v.size and (v.min() < I32_MIN or v.max() > I32_MAX):
+        raise OverflowError("event field %r exceeds the int32 range of the device layout "
+                            "(absolute timestamps: subtract the window's first timestamp)" % name)
+    return v.astype(np.int32)
+
+
+def narrow_to_int32(col, name, truncate=False):
+    return int64_to_int32(field_to_int64(col, name, truncate), name)
+
+
+def from_structured(rec, truncate=False, rebase_t=False):
+    """Structured x,y,t,p record array -> (n,4) int32.  ``truncate``: float fields are cut toward zero as
+    the reference's astype does (else they must be integral); ``rebase_t``: t - t.min() in int64 first (what
+    MixedDensityEventStack.stack does itself, mixed_density_event_stack.py:33), so absolute timestamps fit."""
     n = rec.shape[0]
     ev = np.empty((n, 4), dtype=np.int32)
     for k, name in enumerate(("x", "y", "t", "p")):
-        col = np.asarray(rec[name])
-        if col.dtype.kind == "f":
-            if n and not np.all(col == np.rint(col)):
-                raise NotImplementedError(
-                    "non-integral %r values are not supported by the int32 device layout" % name)
-        ev[:, k] = col.astype(np.int64).astype(np.int32)
+        v = field_to_int64(rec[name], name, truncate)
+        if name == "t" and rebase_t and n:
+            v = v - v.min()
+        ev[:, k] = int64_to_int32(v, name)
     return ev

@@ -96,8 +96,11 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
 int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                     double scale, int32_t out_dtype, void *out, void *stream);
 
-/* EventStack.pre_stack + post_stack (event_stack.py:15-131) for last_timestamp = t[-1]:
- * out DEVICE (B,H,W,S) float32; premap != 0 applies p -> (p+1)//2 first (gen1_transforms.py:34). */
+/* EventStack.make_stack + post_stack (event_stack.py:45-131) of one half (past, or the reversed future) per
+ * window: level k = polarity of the last event at each pixel among events[off_k:].
+ * out DEVICE (B,H,W,S) float32; premap 1 applies p -> (p+1)//2 first (gen1_transforms.py:34) and the value is
+ * int8(2p - 1) (event_stack.py:18); premap 0: p is {0,1}; premap 2: the p column already holds the int8 value
+ * (EventStack.pre_stack builds both halves on the host side: past as is, future reversed and negated, :21-41). */
 int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                       int32_t stack_size, int32_t premap, float scale, float *out, void *stream);
 
@@ -127,6 +130,12 @@ int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *off
  * its optional normalisation.  out DEVICE (B,H,W,bins) float64. */
 int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                 int32_t bins, int32_t mode, double scale, double *out, void *stream);
+/* The same with an explicit time range per window (mode 2 only): t_range DEVICE int64 [B,2] = the t0_us, t1_us
+ * arguments of events_to_voxel_grid (utils.py:52,60-63), in the units of the events' t column; NULL = t[0], t[-1].
+ * Events outside the range fall outside the bins and are dropped, except that the bin index is truncated toward
+ * zero as the reference's astype("int32") does (:67), so up to one bin before t0_us still counts into bin 0. */
+int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      int32_t bins, int32_t mode, double scale, const int64_t *t_range, double *out, void *stream);
 
 /* n_imagenet's per-polarity accumulators (n_imagenet/real_cnn_model/data/imagenet.py:169-511,841-871:
  * reshape_then_acc, _acc_time, _acc_count, _acc_count_pol, _acc_count_only, _acc_all, _flat, _flat_pol,

@@ -180,8 +180,9 @@ int oracle_event_stack(const int32_t *ev, int64_t n, int H, int W, int S, int pr
             if (idx < -hw || idx >= hw) { free(img); return ORACLE_EINDEX; }
             if (idx < 0) idx += hw; /* numpy put wraps negative indices in 'raise' mode */
             int p = ev[4 * i + 3];
-            if (premap) p = (p + 1) >> 1; /* floor division by 2 */
-            img[idx] = (int8_t)(2 * p - 1);
+            if (premap == 1) p = (p + 1) >> 1; /* floor division by 2 */
+            /* premap 2: the column already holds the int8 value 2p-1 (or its negation, the future half, :35) */
+            img[idx] = (int8_t)(premap == 2 ? p : 2 * p - 1);
         }
         for (int64_t q = 0; q < hw; ++q) out[q * S + k] = (float)img[q];
         cur = cur / 2;
@@ -344,11 +345,19 @@ int oracle_voxel(const int32_t *ev, int64_t n, int H, int W, int bins, double *o
  * float64; both tlim in {int(t_norm), int(t_norm)+1} are drawn with weight (1 - |tlim - int(t_norm)|)*p,
  * i.e. p and 0, accumulated with np.add.at into a float32 grid.  out is (bins, H, W) float32.
  * ------------------------------------------------------------------------------------------- */
+int oracle_evl_voxel_range(const int32_t *ev, int64_t n, int H, int W, int bins, int has_t0, int64_t t0_us,
+                           int has_t1, int64_t t1_us, float *out);
 int oracle_evl_voxel(const int32_t *ev, int64_t n, int H, int W, int bins, float *out) {
+    return oracle_evl_voxel_range(ev, n, H, W, bins, 0, 0, 0, 0, out);
+}
+/* the same with the optional t0_us / t1_us arguments (utils.py:60-63); events outside the range get a bin index
+ * outside [0, bins) and are masked (:69), except that astype("int32") truncates toward zero (:67) */
+int oracle_evl_voxel_range(const int32_t *ev, int64_t n, int H, int W, int bins, int has_t0, int64_t t0_us,
+                           int has_t1, int64_t t1_us, float *out) {
     int64_t hw = (int64_t)H * W;
     memset(out, 0, sizeof(float) * hw * bins);
     if (n < 2) return ORACLE_OK;
-    int64_t t0 = ev[2], t1 = ev[4 * (n - 1) + 2];
+    int64_t t0 = has_t0 ? t0_us : ev[2], t1 = has_t1 ? t1_us : ev[4 * (n - 1) + 2];
     double deltaT = (double)(t1 - t0);
     if (t1 - t0 == 0) deltaT = 1.0;
     for (int pass = 0; pass < 2; ++pass) {

@@ -100,6 +100,28 @@ def event_stack(ev, H, W, stack_size=12, premap=True):
     return out
 
 
+def event_stack_split(x, y, p, t, last_timestamp, H, W, stack_size=12):
+    """EventStack.pre_stack + post_stack for any last_timestamp (event_stack.py:15-68): the past half
+    (t <= last) as is, the future half (t > last) reversed with negated polarity, each stacked on its own;
+    the future half's level axis is reversed.  -> (H, W, 1 or 2, S) float32."""
+    x = np.asarray(x).astype(np.int32)
+    y = np.asarray(y).astype(np.int32)
+    pv = 2 * np.asarray(p).astype(np.int8) - 1
+    t = np.asarray(t).astype(np.int64)
+    past, future = t <= last_timestamp, t > last_timestamp
+    halves = [(x[past], y[past], pv[past])]
+    if future.sum():
+        halves.append((x[future][::-1], y[future][::-1], pv[future][::-1] * -1))
+    levels = []
+    for hx, hy, hp in halves:
+        ev = np.zeros((len(hx), 4), np.int32)
+        ev[:, 0], ev[:, 1], ev[:, 3] = hx, hy, hp
+        levels.append(event_stack(ev, H, W, stack_size, premap=2))
+    if len(levels) == 2:
+        levels[1] = levels[1][:, :, ::-1]
+    return np.stack(levels, axis=2)
+
+
 def time_surface(ev, H, W, slices=6, tau=50000.0, premap=True, return_idx=False):
     ev = _ev(ev)
     out = np.empty((H, W, 2 * slices), dtype=np.float64)
@@ -135,11 +157,13 @@ def voxel(ev, H, W, bins=5):
     return out
 
 
-def evl_voxel(ev, H, W, bins):
-    """ev-licious events_to_voxel_grid(events, bins, normalize=False): (bins, H, W) float32."""
+def evl_voxel(ev, H, W, bins, t0_us=None, t1_us=None):
+    """ev-licious events_to_voxel_grid(events, bins, normalize=False, t0_us, t1_us): (bins, H, W) float32."""
     ev = _ev(ev)
     out = np.empty((bins, H, W), dtype=np.float32)
-    _chk(lib().oracle_evl_voxel(_p(ev), ctypes.c_int64(ev.shape[0]), H, W, bins, _p(out)))
+    _chk(lib().oracle_evl_voxel_range(_p(ev), ctypes.c_int64(ev.shape[0]), H, W, bins,
+                                      int(t0_us is not None), ctypes.c_int64(int(t0_us or 0)),
+                                      int(t1_us is not None), ctypes.c_int64(int(t1_us or 0)), _p(out)))
     return out
 
 

@@ -145,4 +145,21 @@ def test_batch_of_only_empty_windows():
     assert float(eb.event_stack().abs().sum()) == 0.0
     assert float(eb.voxel(5).abs().sum()) == 0.0
     assert float(eb.polstats(torch.zeros(0, dtype=torch.float64, device="cuda:0"), [0, 1], [0, 1]).abs().sum()) == 0.0
-    assert tuple(eb.tore(6, frame_mode=2).shape) == (3, H, W, 12)
+    # TORE's empty-FIFO value (tore.py:69-79: inf -> 5e8 -> log(5e8 + 1) - log(151)) in EVERY element, in both
+    # full-frame modes, and for an empty window sitting between non-empty ones of a batch
+    bgv = np.float32(np.float64(np.log(np.float32(5e8) + np.float32(1.0))) - np.log(151.0))
+    for mode in (1, 2):
+        tr = eb.tore(6, frame_mode=mode)
+        assert tuple(tr.shape) == (3, H, W, 12)
+        vals = np.unique(tr.cpu().numpy())
+        assert vals.size == 1 and abs(float(vals[0]) - float(bgv)) <= 1e-6 * float(bgv)   # device logf vs libm: 1 ulp
+    some = make_events(500, W, H, seed=5)
+    mixed = eng.EventBatch.from_numpy([some, np.zeros((0, 4), np.int32), some], H, W)
+    for mode in (1, 2):
+        out = torch.full((3, H, W, 12), float("nan"), device="cuda:0")     # poisoned: every element must be written
+        tr = mixed.tore(6, frame_mode=mode, out=out).cpu().numpy()
+        vals = np.unique(tr[1])
+        assert vals.size == 1 and abs(float(vals[0]) - float(bgv)) <= 1e-6 * float(bgv)
+        assert np.array_equal(tr[0], tr[2]) and not np.isnan(tr).any()
+    ts = eb.time_surface().cpu().numpy()
+    assert not np.isnan(ts).any() and float(np.abs(ts).sum()) == 0.0       # no slice is ever reached: all zero

@@ -159,6 +159,45 @@ def test_bin_build_pipeline_matches_serial(eng):
         assert torch.equal(outs[j], serial[j])
 
 
+def test_bin_build_pipeline_refilled_and_resubmitted_batch(eng):
+    """The stream-of-batches use: two resident batches alternate and the caller REFILLS a batch's events on its
+    own stream once that batch's build has been issued.  The side-stream binning must see the refilled events
+    (it is ordered behind the caller's stream) and must not start while a build of the same workspace is
+    outstanding -- also when the same batch is submitted twice in a row."""
+    H, W, N, B, G = 240, 320, 40000, 4, 6
+    streams = [np.concatenate([make_events(N, W, H, seed=900 + 10 * g + i) for i in range(B)]) for g in range(G)]
+    dev = [torch.from_numpy(s).cuda() for s in streams]
+    mk = lambda g: eng.EventBatch.from_numpy([streams[g][i * N:(i + 1) * N] for i in range(B)], H, W)  # noqa: E731
+    batches = [mk(0), mk(1)]
+    expect = []
+    for g in range(G):
+        batches[g % 2].events.copy_(dev[g])
+        expect.append(batches[g % 2].rebin().optimized().clone())
+    batches[0].events.copy_(dev[0])
+    batches[1].events.copy_(dev[1])
+    torch.cuda.synchronize()
+    pipe = eng.BinBuildPipeline("cuda:0")
+    outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda") for _ in range(G)]
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    for g in range(G):
+        j = g % 2
+        if g >= 2:                             # the build of generation g-2 (same buffer) was issued by submit(g-1)
+            big.normal_()                      # keeps the caller's stream busy: a missing wait would race the copy
+            batches[j].events.copy_(dev[g])    # refill on the caller's stream
+        pipe.submit(batches[j], lambda b, g=g: b.optimized(out=outs[g]))
+    pipe.drain()
+    torch.cuda.synchronize()
+    for g in range(G):
+        assert torch.equal(outs[g], expect[g]), "generation %d" % g
+    # the same batch twice in a row: the second submission builds the first before re-binning the workspace
+    again = [torch.empty_like(outs[0]) for _ in range(2)]
+    pipe.submit(batches[1], lambda b: b.optimized(out=again[0]))
+    pipe.submit(batches[1], lambda b: b.optimized(out=again[1]))
+    pipe.drain()
+    torch.cuda.synchronize()
+    assert torch.equal(again[0], expect[G - 1]) and torch.equal(again[1], expect[G - 1])
+
+
 def test_step_is_graph_capturable(eng):
     """bin + build make no synchronising call, so the whole step records into a hipGraph and replays to the
     same tensor (what a launch-bound caller would do with many small batches)."""

@@ -69,12 +69,60 @@ def test_event_stack_class():
     post = es.post_stack(es.pre_stack(rec, rec[-1]["t"]))
     assert post.shape == (H, W, 1, 12) and post.dtype == np.float32
     assert_bit_equal(np.ascontiguousarray(post.transpose(0, 1, 3, 2)[..., 0]), g["event_stack"])
-    with pytest.raises(NotImplementedError):
-        es.pre_stack(rec, rec[10]["t"])                       # a non-empty "future" half
+    with pytest.raises(ValueError):
+        es.pre_stack(rec, rec[0]["t"] - 1)                    # empty past half: p_t.min() of nothing (:24)
     bad = rec.copy()
     bad["x"][7] = W * H
     with pytest.raises(IndexError):
         es.pre_stack(bad, bad[-1]["t"])
+
+
+def test_event_stack_future_half():
+    """last_timestamp inside the window: the reversed, polarity-negated "future" half and post_stack's reversed
+    level axis (event_stack.py:28-41,64-65), bit-exact against the reference's own (H, W, 2, S) output."""
+    from event_representation_study_amd.representations.event_stack import EventStack
+    g = load_golden("boundary")
+    for tag in "abc":
+        ev = g["future_%s_events" % tag]
+        H, W = int(g["future_%s_H" % tag]), int(g["future_%s_W" % tag])
+        es = EventStack(12, ev.shape[0], H, W)
+        post = es.post_stack(es.pre_stack(to_structured(ev), int(g["future_%s_last" % tag])))
+        assert post.dtype == np.float32
+        assert_bit_equal(post, g["future_%s_post" % tag], "future half " + tag)
+
+
+def _f8_record(g):
+    rec = np.empty(g["float_rec_x"].shape[0], dtype=[("x", "<f8"), ("y", "<f8"), ("t", "<f8"), ("p", "<f8")])
+    for n in "xytp":
+        rec[n] = g["float_rec_" + n]
+    return rec
+
+
+def test_float_fields_are_truncated_like_the_reference():
+    """n_imagenet hands every builder all-'<f8' fields with non-integral x, y, t (imagenet.py:1002-1006); the
+    reference truncates them (mixed_density_event_stack.py:26-29, event_stack.py:16-19) -- so do the mirrors."""
+    from event_representation_study_amd.representations.event_stack import EventStack
+    from event_representation_study_amd.representations.optimized_representation import get_optimized_representation
+    from event_representation_study_amd.representations.representation_search.mixed_density_event_stack import \
+        MixedDensityEventStack
+    g = load_golden("boundary")
+    H, W = int(g["float_H"]), int(g["float_W"])
+    rec = _f8_record(g)
+    N = rec.shape[0]
+    assert_bit_equal(get_optimized_representation(rec.copy(), N, H, W), g["float_ergo12"], "float ergo12")
+    triples = ([0, 3, 5, 1], ["timestamp", "count_neg", "polarity", "timestamp_pos"], ["mean", "sum", "variance", "max"])
+    assert_bit_equal(MixedDensityEventStack(4, N, H, W, triples, "SBN").stack(rec.copy()), g["float_mdes"], "float mdes")
+    r2 = rec.copy()
+    r2["p"] = (r2["p"] + 1) // 2
+    es = EventStack(12, N, H, W)
+    assert_bit_equal(es.post_stack(es.pre_stack(r2, r2[-1]["t"])), g["float_event_stack"], "float event stack")
+    # absolute int64 timestamps (above 2^31): MDES only sees t - t.min()
+    big = np.empty(N, dtype=[("x", "<i4"), ("y", "<i4"), ("t", "<i8"), ("p", "<i4")])
+    big["x"], big["y"], big["p"] = np.trunc(rec["x"]), np.trunc(rec["y"]), rec["p"]
+    ev = make_events(N, W, H, seed=701)
+    big["x"], big["y"], big["p"] = ev[:, 0], ev[:, 1], ev[:, 3]
+    big["t"] = g["abs_t"]
+    assert_bit_equal(get_optimized_representation(big, N, H, W), g["abs_ergo12"], "absolute int64 t")
 
 
 def test_to_timesurface_class():
@@ -212,6 +260,18 @@ def test_evlicious_voxel_grid():
         got = events_to_voxel_grid(e, 5, normalize=True)
         np.testing.assert_allclose(got, g[tag + "_norm5"], rtol=1e-5, atol=1e-6)   # float32 mean / std
         assert np.array_equal(got == 0, g[tag + "_norm5"] == 0)
+    # explicit t0_us / t1_us (utils.py:60-63), absolute int64 timestamps
+    g = load_golden("boundary")
+    ev = g["evl_events"]
+    e = Events()
+    e.x, e.y, e.t, e.p = ev[:, 0].astype(np.uint16), ev[:, 1].astype(np.uint16), g["evl_t_abs"], ev[:, 3].astype(np.int8)
+    e.width, e.height = int(g["evl_W"]), int(g["evl_H"])
+    for k, (t0, t1) in enumerate(g["evl_ranges"]):
+        got = events_to_voxel_grid(e, 5, normalize=False, t0_us=int(t0), t1_us=int(t1))
+        assert_bit_equal(got, g["evl_raw5_%d" % k], "t range %d" % k)
+    assert_bit_equal(events_to_voxel_grid(e, 5, normalize=False, t0_us=1_010_000), g["evl_raw5_t0only"], "t0 only")
+    got = events_to_voxel_grid(e, 5, normalize=True, t0_us=int(g["evl_ranges"][0][0]), t1_us=int(g["evl_ranges"][0][1]))
+    np.testing.assert_allclose(got, g["evl_norm5_0"], rtol=1e-5, atol=1e-6)
 
 
 def test_gwd_caller_pipeline_f1():

@@ -35,8 +35,38 @@ def test_structured_round_trip_and_float_fields():
         f8[n] = ev[:, k]
     assert np.array_equal(from_structured(f8), ev)
     f8["t"][3] += 0.5
+    f8["x"][5] += 0.25
     with pytest.raises(NotImplementedError):
-        from_structured(f8)
+        from_structured(f8)                               # builders whose reference does NOT truncate stay strict
+    cut = from_structured(f8, truncate=True)              # MDES / EventStack: the reference's astype truncation
+    assert np.array_equal(cut, ev)
+    f8["t"] += 5e9                                        # absolute microseconds beyond int32
+    with pytest.raises(OverflowError):
+        from_structured(f8, truncate=True)
+    reb = from_structured(f8, truncate=True, rebase_t=True)
+    assert np.array_equal(reb[:, 2], ev[:, 2] - ev[:, 2].min()) and np.array_equal(reb[:, [0, 1, 3]], ev[:, [0, 1, 3]])
+    i8 = np.empty(4, dtype=[("x", "<i4"), ("y", "<i4"), ("t", "<i8"), ("p", "<i4")])
+    i8["x"], i8["y"], i8["p"], i8["t"] = 1, 2, 1, [2**31, 2**31 + 1, 2**31 + 2, 2**31 + 5]
+    with pytest.raises(OverflowError):                    # no silent wrap of timestamps >= 2^31
+        from_structured(i8)
+    assert list(from_structured(i8, rebase_t=True)[:, 2]) == [0, 1, 2, 5]
+
+
+def test_float_field_goldens_through_host_narrowing(oracle):
+    """The reference's outputs on all-'<f8' fields (boundary.npz) = the oracle on the host-narrowed events."""
+    from conftest import assert_bit_equal
+    g = load_golden("boundary")
+    rec = np.empty(g["float_rec_x"].shape[0], dtype=[("x", "<f8"), ("y", "<f8"), ("t", "<f8"), ("p", "<f8")])
+    for n in "xytp":
+        rec[n] = g["float_rec_" + n]
+    H, W = int(g["float_H"]), int(g["float_W"])
+    ev = from_structured(rec, truncate=True, rebase_t=True)
+    assert_bit_equal(oracle.ergo12(ev, H, W), g["float_ergo12"], "float ergo12")
+    assert_bit_equal(oracle.mdes(ev, H, W, [0, 3, 5, 1], ["timestamp", "count_neg", "polarity", "timestamp_pos"],
+                                 ["mean", "sum", "variance", "max"]), g["float_mdes"], "float mdes")
+    r2p = (rec["p"] + 1) // 2
+    assert_bit_equal(oracle.event_stack_split(rec["x"], rec["y"], r2p, rec["t"], rec["t"][-1], H, W),
+                     g["float_event_stack"], "float event stack")
 
 
 def test_otmi_point_clouds_match_oracle_restatement(oracle):
