@@ -37,6 +37,14 @@ __device__ inline int wave_max(int v) { return wave_reduce_dpp(v, INT32_MIN, [](
 __device__ inline uint32_t wave_or(uint32_t v) { return (uint32_t)wave_reduce_dpp((int)v, 0, [](int a, int b) { return a | b; }); }
 __device__ inline int wave_sum(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
 
+// Ordering point between LDS phases of ONE wave (LDS operations of a wave execute in program order; the
+// compiler only has to keep them in order).  Nothing is drained, no s_barrier.
+__device__ inline void wave_phase_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per-(window, block) partial statistics; reduced into WindowMeta by k_row_scan (no global atomics).
 struct BlockStats {
     int32_t tmin, tmax, xmin, xmax, ymin, ymax;
@@ -527,6 +535,357 @@ __global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sort
             if (valid && last) vcnt[col] = pos + 1;
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// =====================================================================================================
+// Two-kernel binning pass (windows of up to kBsMaxBlocks * 8192 events on sensors of up to ~720 rows; the
+// three-kernel pass above stays for everything larger).
+//
+// The three-kernel pass cuts a window into 2048-event blocks that must agree on where every (block,row) run
+// goes in ONE row-major stream -- hence a histogram kernel, a table every scatter block re-reads in full, and
+// three launch boundaries.  Here NO block depends on any other:
+//   k_block_rowsort : a 1024-thread workgroup (16 waves per CU) orders ITS 8192 events by sensor row, stably,
+//                     inside LDS and writes them to ITS OWN 8192-record slot of sorted1, plus the exclusive
+//                     row offsets of its run (table[b][blk][0..H]).  One read of the events, one coalesced
+//                     write, no inter-block communication of any kind.
+//   k_col_sort_runs : the wave that owns (window, row) gathers the row's records from the <= 16 block runs
+//                     (block order = time order), orders them by column exactly as k_col_sort does and
+//                     writes sorted2 / the chunk offsets.  Its output position needs no scan either:
+//                     records of earlier rows = sum over blocks of table[b][blk][row].
+// =====================================================================================================
+#ifndef BS_DEBUG
+#define BS_DEBUG 0  // timing experiments only (tools/ab): 1 = no statistics, 2 = no placement, 4 = no write-out, 8 = no counting
+#endif
+constexpr int kBsThreads = 1024;
+constexpr int kBsWaves = kBsThreads / kWave;     // 16
+constexpr int kBsPerLane = 8;
+constexpr int kBsChunk = kBsThreads * kBsPerLane;  // 8192 events per workgroup
+constexpr int kBsMaxBlocks = 16;                 // runs one k_col_sort_runs wave gathers (one lane each)
+
+__host__ __device__ inline int bs_hp(int H) { return (H + 1) & ~1; }
+__host__ __device__ inline size_t block_rowsort_lds_bytes(int H) {
+    return (size_t)kBsChunk * sizeof(Rec) + (size_t)kBsWaves * bs_hp(H) * sizeof(uint16_t) + (size_t)(H + 2) * sizeof(uint32_t);
+}
+
+// grid (8 * ceil(B/8) * nblk), 1024 threads, dynamic LDS = block_rowsort_lds_bytes(H).
+// table: [B][nblk][H + 1] exclusive offsets of the block's rows inside its run (entry H = in-frame events).
+__global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+                                                             int B, int H, int W, int nblk, uint32_t *__restrict__ table,
+                                                             BlockStats *__restrict__ stats, Rec *__restrict__ sorted1) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Rec *stage = reinterpret_cast<Rec *>(smem_raw);                               // [kBsChunk], output order
+    const int Hp = bs_hp(H), Hw = Hp >> 1;
+    uint16_t *cnt16 = reinterpret_cast<uint16_t *>(stage + kBsChunk);             // [kBsWaves][Hp] counts -> next positions
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(cnt16);                        // the same, two rows per word
+    uint32_t *lbase = reinterpret_cast<uint32_t *>(cnt16 + (size_t)kBsWaves * Hp);  // [H + 1]
+    __shared__ BlockStats wstats[kBsWaves];
+    __shared__ uint32_t tmp[kBsWaves];
+    int b, blk;
+    if (!decode_window_block(B, nblk, b, blk)) return;
+    const int64_t beg = off[b];
+    const int64_t n = off[b + 1] - beg;
+    const int64_t lo = (int64_t)blk * kBsChunk;
+    if (lo >= n) return;  // k_col_sort_runs only reads the blocks a window really has
+    const int64_t hi = (lo + kBsChunk < n) ? lo + kBsChunk : n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wlo = lo + (int64_t)wave * (kBsPerLane * kWave);
+    const int64_t whi = (wlo + kBsPerLane * kWave < hi) ? wlo + kBsPerLane * kWave : hi;
+    const int64_t HW = (int64_t)H * W;
+    // the wave's 512 events stay in registers from counting to placement
+    int4 e[kBsPerLane];
+    int tprev[kBsPerLane];
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        const int64_t r = wlo + i * kWave + lane;
+        e[i] = make_int4(-1, -1, INT32_MAX, 0);
+        tprev[i] = INT32_MIN;
+        if (r < whi) {
+            e[i] = ev[beg + r];
+            if (lane == 0 && r > 0) tprev[i] = ev[beg + r - 1].z;  // other lanes take it from their neighbour
+        }
+    }
+    for (int i = threadIdx.x; i < kBsWaves * Hw; i += kBsThreads) cnt32[i] = 0;
+    __syncthreads();
+    // MDES window membership of a rank: uniform for the whole block unless a window boundary cuts it
+    const MdesWindows mw = mdes_windows(n);
+    uint32_t full = 0, part = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (mw.lo[i] <= lo && hi <= mw.hi[i]) full |= 1u << i;
+        else if (!(hi <= mw.lo[i] || lo >= mw.hi[i])) part |= 1u << i;
+    }
+    uint32_t *mycnt32 = cnt32 + wave * Hw;
+    BlockStats st;
+    stats_identity(st);
+    uint32_t rows[kBsPerLane];  // row of the event, 0xffffffff = not placed (padding lane or out of frame)
+    uint32_t sneg = 0;          // wave-uniform part of neg_flags
+    // MDES window membership of this wave's 512 consecutive ranks: wave-uniform unless a window boundary cuts them
+    bool cut = false;
+    if (part) {
+        const int32_t a0 = (int32_t)wlo, a1 = (int32_t)whi;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) cut |= (mw.lo[q] > a0 && mw.lo[q] < a1) || (mw.hi[q] > a0 && mw.hi[q] < a1);
+    }
+    const uint32_t memb_u = cut ? 0u : (full | (part ? (mdes_membership(mw, (int32_t)wlo) & part) : 0u));
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        const int64_t r0 = wlo + i * kWave;
+        const int64_t r = r0 + lane;
+        const bool in = r < whi;
+        // the predecessor's timestamp: one DPP wave shift (no LDS crossbar); lane 0 loaded it itself
+        const int up = __builtin_amdgcn_update_dpp(0, e[i].z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane != 0) tprev[i] = up;
+
+        // in-frame test on the flat index x + y*W, as the reference's scatter sees it (an x outside [0, W) can
+        // still land in the frame); the common case x in [0, W) needs no 64-bit arithmetic and no division
+        uint32_t row = (uint32_t)e[i].y;
+        bool valid = in && (uint32_t)e[i].x < (uint32_t)W && (uint32_t)e[i].y < (uint32_t)H;
+        if (__any(in && (uint32_t)e[i].x >= (uint32_t)W)) {
+            const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+            valid = in && key >= 0 && key < HW;
+            if (valid) row = (uint32_t)key / (uint32_t)W;
+        }
+        rows[i] = valid ? row : 0xffffffffu;
+        if (valid && !(BS_DEBUG & 8)) atomicAdd(&mycnt32[row >> 1], 1u << ((row & 1u) * 16));
+        if (!(BS_DEBUG & 1)) {
+            if (!cut) {
+                if (__any(in && e[i].w == -1)) sneg |= memb_u;
+            } else if (in && e[i].w == -1) {
+                st.neg_flags |= full | (mdes_membership(mw, (int32_t)r) & part);
+            }
+            if (__any(in && !valid)) {  // rare: out-of-frame events
+                if (in && !valid) {
+                    const uint32_t memb = cut ? (full | (mdes_membership(mw, (int32_t)r) & part)) : memb_u;
+                    st.status |= EVREP_ST_OOB;
+                    const int cls = e[i].w == 1 ? 1 : (e[i].w == -1 ? 2 : (e[i].w == 0 ? 3 : 0));
+                    st.oob_flags |= memb | (cls ? (memb << (7 * cls)) : 0u);
+                }
+            }
+        }
+        if (in && !(BS_DEBUG & 1)) {
+            if (valid) ++st.n_valid;
+            if (tprev[i] > e[i].z) st.status |= EVREP_ST_UNSORTED;
+            st.tmin = min(st.tmin, e[i].z); st.tmax = max(st.tmax, e[i].z);
+            st.xmin = min(st.xmin, e[i].x); st.xmax = max(st.xmax, e[i].x);
+            st.ymin = min(st.ymin, e[i].y); st.ymax = max(st.ymax, e[i].y);
+        }
+    }
+    st.neg_flags |= sneg;
+    stats_wave_reduce(st);
+    if (lane == 0) wstats[wave] = st;
+    __syncthreads();
+    // two rows per thread (one packed word): exclusive running count over the waves, then over the rows
+    uint32_t run = 0;
+    if ((int)threadIdx.x < Hw) {
+#pragma unroll
+        for (int w = 0; w < kBsWaves; ++w) { const uint32_t c = cnt32[w * Hw + threadIdx.x]; cnt32[w * Hw + threadIdx.x] = run; run += c; }
+    }
+    const uint32_t own0 = run & 0xffffu, own1 = run >> 16;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<kBsWaves>(own0 + own1, tmp, &total);
+    if ((int)threadIdx.x < Hw) {
+        const uint32_t l0 = ex, l1 = ex + own0;  // <= 8192: fits the 16-bit halves, no carry between them
+        const uint32_t add = l0 | (l1 << 16);
+#pragma unroll
+        for (int w = 0; w < kBsWaves; ++w) cnt32[w * Hw + threadIdx.x] += add;
+        uint32_t *tb = table + ((size_t)b * nblk + blk) * (H + 1);
+        const int r0 = 2 * (int)threadIdx.x;
+        tb[r0] = l0; lbase[r0] = l0;
+        if (r0 + 1 < H) { tb[r0 + 1] = l1; lbase[r0 + 1] = l1; }
+    }
+    if (threadIdx.x == 0) {
+        table[((size_t)b * nblk + blk) * (H + 1) + H] = total;
+        BlockStats t = wstats[0];
+        for (int w = 1; w < kBsWaves; ++w) stats_merge(t, wstats[w]);
+        stats[(size_t)b * nblk + blk] = t;
+    }
+    __syncthreads();
+    // stable placement into the stage, in output order
+    const int nbits = bits_for(H);
+    volatile uint16_t *vpos = cnt16 + (size_t)wave * Hp;
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        if (wlo + i * kWave >= whi) break;  // uniform
+        const bool valid = rows[i] != 0xffffffffu;
+        const uint32_t row = valid ? rows[i] : 0u;
+        uint32_t rk = 0; bool last = false;
+        if (!(BS_DEBUG & 2)) wave_match(row, nbits, valid, lane, rk, last);
+        uint32_t pos = 0;
+        if (valid) {
+            pos = (BS_DEBUG & 2) ? (uint32_t)(wave * 512 + i * 64 + lane) : (uint32_t)vpos[row] + rk;
+            const int64_t r = wlo + i * kWave + lane;
+            const Rec rec = make_int4((int)((int64_t)e[i].x + (int64_t)e[i].y * W), (int)r, e[i].z, e[i].w);
+            if (BS_DEBUG & 16) sorted1[beg + lo + pos] = rec; else stage[pos] = rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && last) vpos[row] = (uint16_t)(pos + 1);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    Rec *dst = sorted1 + beg + lo;
+    if (!(BS_DEBUG & (4 | 16)))
+        for (uint32_t t = threadIdx.x; t < total; t += kBsThreads) dst[t] = stage[t];
+}
+
+// grid (ceil(H / (kCsWaves * R)), B), 256 threads = kCsWaves independent waves (no block barrier), each wave R
+// consecutive rows; dynamic LDS = kCsWaves * W * 4.  The run table of all R rows is loaded first and the record
+// fetches of all R rows are in flight together (R x 4 loads per lane) before the first row is ordered: one
+// memory latency chain per R rows instead of one per row.
+constexpr int kCsWaves = 4;
+__host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / kWave + 3) / 4; }
+__host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
+#ifndef EVREP_CS_ROWS
+#define EVREP_CS_ROWS 1
+#endif
+constexpr int kCsRowsPerWave = EVREP_CS_ROWS;
+
+template <int R>
+__global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
+                                                                     const uint32_t *__restrict__ table,
+                                                                     const BlockStats *__restrict__ stats, int H, int W, int nblk,
+                                                                     int nchunk, Rec *__restrict__ sorted2,
+                                                                     uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
+    extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_words(W)]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, row0 = (blockIdx.x * kCsWaves + wave) * R;
+    if (row0 >= H) return;
+    uint32_t *cnt = cnt_all + (size_t)wave * col_sort_words(W);
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);  // <= kBsMaxBlocks: one lane per block run
+    // run k of row r = sorted1[beg + k*8192 + t_k[r], ... + t_k[r+1]); records of earlier rows = sum_k t_k[r]
+    uint32_t t[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) {
+        t[r] = 0;
+        if (lane < nb) t[r] = table[((size_t)b * nblk + lane) * (H + 1) + min(row0 + r, H)];
+    }
+    if (row0 == 0) {  // this wave also publishes the window's statistics
+        BlockStats st;
+        stats_identity(st);
+        if (lane < nb) {  // three 16-byte loads, fields assigned one by one (a struct copy would go through scratch)
+            const int4 *sp = reinterpret_cast<const int4 *>(stats + (size_t)b * nblk + lane);
+            const int4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+            st.tmin = q0.x; st.tmax = q0.y; st.xmin = q0.z; st.xmax = q0.w;
+            st.ymin = q1.x; st.ymax = q1.y; st.neg_flags = (uint32_t)q1.z; st.oob_flags = (uint32_t)q1.w;
+            st.status = (uint32_t)q2.x; st.n_valid = q2.y;
+        }
+        stats_wave_reduce(st);
+        if (lane == 0) {
+            WindowMeta m;
+            m.tmin = st.tmin; m.tmax = st.tmax; m.xmin = st.xmin; m.xmax = st.xmax; m.ymin = st.ymin; m.ymax = st.ymax;
+            m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status; m.n_valid = st.n_valid;
+            if (n_win <= 0) m.status |= EVREP_ST_EMPTY;
+            else if (st.tmin == st.tmax) m.status |= EVREP_ST_FLAT_TIME;
+            for (int i = 0; i < 6; ++i) m.pad[i] = 0;
+            meta[b] = m;
+        }
+    }
+    constexpr uint32_t kSuper = 4 * kWave;  // records of a row held in registers (longer rows are walked twice)
+    uint32_t rs[R + 1], pre[R], src[R];
+    rs[0] = (uint32_t)beg + (uint32_t)wave_sum((int)t[0]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t len = t[r + 1] - t[r];
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        pre[r] = incl - len;                                                            // this row's records in earlier blocks
+        rs[r + 1] = rs[r] + (uint32_t)__builtin_amdgcn_readlane((int)incl, kBsMaxBlocks - 1);  // rows are contiguous in sorted2
+        src[r] = (uint32_t)beg + (uint32_t)lane * kBsChunk + t[r] - pre[r];            // record j of the row: src_k + j
+    }
+    // record j of row r lies in the run k with pre_k <= j < pre_{k+1}: a sum of conditional steps over the runs
+    // (lanes >= nb hold pre = n, so they never match a j < n)
+    auto fetch = [&](int r, uint32_t j) -> Rec {
+        uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src[r], 0);
+        uint32_t prev = s;
+        for (int k = 1; k < nb; ++k) {
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre[r], k);
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src[r], k);
+            s += (j >= pk) ? sk - prev : 0u;
+            prev = sk;
+        }
+        return sorted1[s + j];
+    };
+    Rec e[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t n = rs[r + 1] - rs[r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j = i * kWave + lane;
+            e[r][i] = make_int4(0, 0, 0, 0);
+            if (row0 + r < H && j < n) e[r][i] = fetch(r, j);
+        }
+    }
+    const int nbits = bits_for(W);
+    const int per4 = col_sort_per4(W);  // 16-byte vectors of column counters per lane (the array is padded to 64 * per4 * 4)
+    uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt) + (size_t)lane * per4;
+    volatile uint32_t *vcnt = cnt;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= H) break;  // uniform
+        const uint32_t n = rs[r + 1] - rs[r];
+        const uint32_t rbeg = rs[r], rend = rs[r + 1];
+        uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+        if (n == 0) {
+            for (int c = lane; c <= nchunk; c += kWave) co[c] = rbeg;
+            continue;
+        }
+        const int rowbase = row * W;
+        const uint32_t nsuper = (n + kSuper - 1) / kSuper;
+        for (int k = 0; k < per4; ++k) cnt4[k] = make_uint4(0u, 0u, 0u, 0u);
+        wave_phase_lds();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)(i * kWave + lane) < n) atomicAdd(&cnt[e[r][i].x - rowbase], 1u);
+        for (uint32_t sb = 1; sb < nsuper; ++sb)  // a row longer than the register batch
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t j = sb * kSuper + i * kWave + lane;
+                if (j < n) atomicAdd(&cnt[fetch(r, j).x - rowbase], 1u);
+            }
+        wave_phase_lds();
+        // exclusive scan over the W column counters: `per` consecutive columns per lane
+        uint32_t local = 0;
+        for (int k = 0; k < per4; ++k) { const uint4 v = cnt4[k]; local += v.x + v.y + v.z + v.w; }
+        uint32_t inc2 = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc2, d, 64); if (lane >= d) inc2 += o; }
+        uint32_t run = inc2 - local;
+        for (int k = 0; k < per4; ++k) {
+            const uint4 v = cnt4[k];
+            uint4 o;
+            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            cnt4[k] = o;
+        }
+        wave_phase_lds();
+        for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rbeg + cnt[c * kChunkPx] : rend;
+        wave_phase_lds();
+        for (uint32_t sb = 0; sb < nsuper; ++sb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t j0 = sb * kSuper + i * kWave;
+                if (j0 >= n) break;  // uniform
+                const bool valid = j0 + lane < n;
+                Rec rec = e[r][i];
+                if (sb > 0) { rec = make_int4(0, 0, 0, 0); if (valid) rec = fetch(r, j0 + lane); }
+                const uint32_t col = valid ? (uint32_t)(rec.x - rowbase) : 0u;
+                uint32_t rk; bool last;
+                wave_match(col, nbits, valid, lane, rk, last);
+                uint32_t pos = 0;
+                if (valid) {
+                    pos = vcnt[col] + rk;
+                    sorted2[rbeg + pos] = rec;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (valid && last) vcnt[col] = pos + 1;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        wave_phase_lds();  // the next row zeroes the counters
     }
 }
 

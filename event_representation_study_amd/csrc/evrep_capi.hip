@@ -51,13 +51,22 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
         chunk = ((max_events_per_window + 127) / 128 + 255) / 256 * 256;
         nblk = (max_events_per_window + chunk - 1) / chunk;
     }
+    // the two-kernel pass (k_block_rowsort + k_col_sort_runs): windows of <= 16 blocks of 8192 events on sensors
+    // whose per-wave row counters fit next to the 128 KB record stage in one workgroup's LDS (H <= ~900)
+    const bool two_kernel = max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk &&
+                            block_rowsort_lds_bytes(H) + 1024 <= 160 * 1024 && !getenv("EVREP_BIN_THREE_KERNEL");
+    if (two_kernel) {
+        chunk = kBsChunk;
+        nblk = (max_events_per_window + chunk - 1) / chunk;
+    }
     if (nblk < 1) nblk = 1;
     plan->chunk = (int32_t)chunk;
     plan->nblk = (int32_t)nblk;
     plan->nchunk = (W + kChunkPx - 1) / kChunkPx;
+    plan->reserved = two_kernel ? 1 : 0;
     size_t o = 0;
     plan->off_meta = o;    o += up256((size_t)B * sizeof(WindowMeta));
-    plan->off_table = o;   o += up256((size_t)B * nblk * H * sizeof(uint32_t));
+    plan->off_table = o;   o += up256((size_t)B * nblk * (H + 1) * sizeof(uint32_t));
     plan->off_stats = o;   o += up256((size_t)B * nblk * sizeof(BlockStats));
     plan->off_rowoff = o;  o += up256((size_t)B * (H + 1) * sizeof(uint32_t));
     plan->off_chunkoff = o; o += up256((size_t)B * H * (plan->nchunk + 1) * sizeof(uint32_t));
@@ -95,6 +104,26 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     Rec *s2 = WS(Rec, off_sorted2);
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
+    if (plan->reserved == 1) {
+        if (chunk != kBsChunk || nblk > kBsMaxBlocks) return EVREP_EINVAL;
+        const size_t lds = block_rowsort_lds_bytes(H);
+        static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
+        if (!attr_set) {
+            int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_rowsort),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
+                                "hipFuncSetAttribute(k_block_rowsort)");
+            if (rc2) return rc2;
+            attr_set = true;
+        }
+        k_block_rowsort<<<xgrid, kBsThreads, lds, stream>>>(ev, offsets, B, H, W, nblk, table, stats, s1);
+        LAUNCH_CHECK("k_block_rowsort");
+        if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
+        constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
+        k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_words(W) * 4, stream>>>(
+            s1, offsets, table, stats, H, W, nblk, plan->nchunk, s2, WS(uint32_t, off_chunkoff), meta);
+        LAUNCH_CHECK("k_col_sort_runs");
+        return EVREP_OK;
+    }
     k_row_hist<<<xgrid, kBinThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
     if (chunk <= kStageRecs && fused_scatter_lds_bytes(H) <= 65536 && !getenv("EVREP_NO_FUSED_SCATTER")) {
