@@ -149,6 +149,25 @@ def gwd_leg(rank, world, pairs, device, dry=False):
     res = {"pairs": pairs, "n": n, "m": m, "wall_ms": el * 1e3, "kernel_entries_per_s": entries / el,
            "n_ranks": world, "solves_per_rank": [len(range(r, pairs, world)) for r in range(world)],
            "all_solved": bool((costs != 0).all().item()), "first_cost": float(costs[0].item())}
+    if not dry:
+        # matrix-core work of one solve (evrep_gwd.hip): upper-triangular 128 x 128 tiles of the L x L grid, each
+        # 16 blocks of 32 x 32 pairs; a block costs steps(d) v_mfma_f32_32x32x2_f32 of 4096 flop per cloud present
+        # (steps = (d + 2) / 2 rounded up to 3 / 8 / 17: the two extra inner dimensions carry the squared norms)
+        steps = lambda d: 3 if d + 2 <= 6 else (8 if d + 2 <= 16 else 17)  # noqa: E731
+        T = (max(n, m) + 127) // 128
+        flops = 0
+        for bi in range(T):
+            for bj in range(bi, T):
+                flops += 16 * 4096 * ((steps(4) if bj * 128 < n else 0) + (steps(14) if bj * 128 < m else 0))
+        per_solve_s = el / max(len(mine), 1)          # this rank's queue of solves, back to back (4 launches each)
+        tf = flops / per_solve_s / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "k_gwd_tiles<3, 8> (+ k_gwd_stats, k_gwd_prep, k_gwd_finish: the "
+                           "whole solve is timed, so this is a lower bound of the tile kernel's own rate; its rocprofv3 "
+                           "average is in profiles/)", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                           "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact float32; no reduced-precision MFMA is used: the "
+                           "1e-5 budget of the score does not survive bf16 distances)",
+                           "mfma_flop_per_solve": flops, "us_per_solve": per_solve_s * 1e6,
+                           "exp2_per_solve": 2 * sum(min(128 * (T - bi), 128 * T) * 128 for bi in range(T))}
     return res
 
 

@@ -28,6 +28,20 @@ static int hip_check(hipError_t e, const char *what) {
 
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+template <int NSS, int NST>
+static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (2 * NSS + 2 * NST) * kTile * sizeof(float);  // row + column tile of both clouds
+    static bool attr_set = false;  // the widest instantiations need > 64 KB of dynamic LDS: opt in once
+    if (!attr_set && lds > 64 * 1024) {
+        int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gwd_tiles<NSS, NST>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_gwd_tiles)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    k_gwd_tiles<NSS, NST><<<P.ntiles, kThreads, lds, stream>>>(P);
+    return EVREP_OK;
+}
+
 extern "C" {
 
 int evrep_abi_version(void) { return EVREP_ABI_VERSION; }
@@ -355,11 +369,11 @@ size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m) {
     if (n <= 0 || m <= 0) return 0;
     const int64_t L = n > m ? n : m;
     const int64_t T = pad_tile(L) / kTile;
-    size_t o = up256(sizeof(GwdStats));
-    o += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
-    o += up256((size_t)kGwdMaxD * pad_tile(n) * sizeof(float));
-    o += up256((size_t)kGwdMaxD * pad_tile(m) * sizeof(float));
-    o += up256((size_t)(T * (T + 1) / 2) * sizeof(double));
+    size_t o = 0;
+    o += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));         // statistics partial sums
+    o += 2 * up256((size_t)2 * gwd_steps(kGwdMaxD) * pad_tile(n) * sizeof(float));  // augmented cloud s: row + column form
+    o += 2 * up256((size_t)2 * gwd_steps(kGwdMaxD) * pad_tile(m) * sizeof(float));  // augmented cloud t
+    o += up256((size_t)(T * (T + 1) / 2) * sizeof(double));                      // per-tile sums
     return o;
 }
 
@@ -369,28 +383,38 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
         return EVREP_EINVAL;
     if (!(h > 0.0) || (reinterpret_cast<uintptr_t>(scratch) & 255u)) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int64_t npad = pad_tile(n), mpad = pad_tile(m);
     const int64_t L = n > m ? n : m;
     const int T = (int)(pad_tile(L) / kTile);
     if ((int64_t)T * (T + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
     char *p = static_cast<char *>(scratch);
-    GwdStats *st = reinterpret_cast<GwdStats *>(p); p += up256(sizeof(GwdStats));
     double *stat_partial = reinterpret_cast<double *>(p); p += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
-    float *Ys = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * npad * sizeof(float));
-    float *Yt = reinterpret_cast<float *>(p); p += up256((size_t)kGwdMaxD * mpad * sizeof(float));
+    const int64_t npad = pad_tile(n), mpad = pad_tile(m);
+    const size_t sbytes = up256((size_t)2 * gwd_steps(kGwdMaxD) * npad * sizeof(float));
+    const size_t tbytes = up256((size_t)2 * gwd_steps(kGwdMaxD) * mpad * sizeof(float));
+    float *YsA = reinterpret_cast<float *>(p); p += sbytes;
+    float *YsB = reinterpret_cast<float *>(p); p += sbytes;
+    float *YtA = reinterpret_cast<float *>(p); p += tbytes;
+    float *YtB = reinterpret_cast<float *>(p); p += tbytes;
     double *partial = reinterpret_cast<double *>(p);
+    // four launches per solve: the clouds' partial sums; one prep launch for both clouds (every block finishes
+    // the statistics itself); the tiles; the final sum
     k_gwd_stats<<<dim3(kStatBlocks, 2), kThreads, 0, stream>>>(Xs, n, ds, Xt, m, dt, stat_partial);
     LAUNCH_CHECK("k_gwd_stats");
-    k_gwd_stats_finish<<<1, 64, 0, stream>>>(stat_partial, n, ds, m, dt, st);
-    LAUNCH_CHECK("k_gwd_stats_finish");
-    k_gwd_prep<<<(unsigned)((npad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xs, n, ds, npad, st, 0, h, Ys);
-    LAUNCH_CHECK("k_gwd_prep(s)");
-    k_gwd_prep<<<(unsigned)((mpad + kThreads - 1) / kThreads), kThreads, 0, stream>>>(Xt, m, dt, mpad, st, 1, h, Yt);
-    LAUNCH_CHECK("k_gwd_prep(t)");
-    const int ntiles = T * (T + 1) / 2;
-    k_gwd_tiles<<<ntiles, kThreads, (size_t)2 * (ds + dt) * kTile * sizeof(float), stream>>>(Ys, ds, n, npad, Yt, dt, m, mpad, T, partial);
+    const int sblocks = (int)((npad + kThreads - 1) / kThreads), tblocks = (int)((mpad + kThreads - 1) / kThreads);
+    k_gwd_prep<<<sblocks + tblocks, kThreads, 0, stream>>>(Xs, n, ds, npad, Xt, m, dt, mpad, stat_partial, h, sblocks, YsA, YsB, YtA, YtB);
+    LAUNCH_CHECK("k_gwd_prep");
+    GwdTileArgs P;
+    P.YsA = YsA; P.YsB = YsB; P.YtA = YtA; P.YtB = YtB; P.n = n; P.m = m; P.npad = npad; P.mpad = mpad;
+    P.T = T; P.ntiles = T * (T + 1) / 2; P.partial = partial;
+    int rc = EVREP_OK;
+    const int ss = gwd_steps(ds), st = gwd_steps(dt);
+#define GWD_CASE(A, B) if (ss == A && st == B) rc = gwd_launch_tiles<A, B>(P, stream)
+    GWD_CASE(3, 3); else GWD_CASE(3, 8); else GWD_CASE(3, 17); else GWD_CASE(8, 3); else GWD_CASE(8, 8);
+    else GWD_CASE(8, 17); else GWD_CASE(17, 3); else GWD_CASE(17, 8); else GWD_CASE(17, 17);
+#undef GWD_CASE
+    if (rc) return rc;
     LAUNCH_CHECK("k_gwd_tiles");
-    k_gwd_finish<<<1, kThreads, 0, stream>>>(partial, ntiles, (double)L, cost);
+    k_gwd_finish<<<1, 1024, 0, stream>>>(partial, P.ntiles, (double)L, cost);
     LAUNCH_CHECK("k_gwd_finish");
     return EVREP_OK;
 }
