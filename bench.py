@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-gwd", action="store_true")
     ap.add_argument("--gwd-pairs", type=int, default=144,
                     help="GWD solves of the wall-time leg; 144 = the metric's 12x12 representation matrix")
+    ap.add_argument("--no-gw-extension", action="store_true",
+                    help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -169,6 +171,41 @@ def gwd_leg(rank, world, pairs, device, dry=False):
                            "mfma_flop_per_solve": flops, "us_per_solve": per_solve_s * 1e6,
                            "exp2_per_solve": 2 * sum(min(128 * (T - bi), 128 * T) * 128 for bi in range(T))}
     return res
+
+
+def gw_extension_leg(device):
+    """EXTENSION (no reference call computes it): entropic Gromov-Wasserstein at the reference's GWD
+    problem size.  One outer iteration = the tensor product h1(C1) T h2(C2)^T as two MFMA GEMMs (float64:
+    v_mfma_f64_16x16x4_f64) + the Sinkhorn passes; reported as TFLOP/s of the GEMM pair against the float64
+    matrix-core peak, measured with HIP-side wall time over whole solves (so launches and the cheap init / plan
+    kernels count against it)."""
+    from event_representation_study_amd.gw_solver import entropic_gromov_wasserstein, flops_per_outer_iteration
+    n, m = 12500, 14400
+    g = torch.Generator(device=device).manual_seed(1)
+
+    def kern(k, d):
+        X = torch.rand((k, d), generator=g, device=device, dtype=torch.float64)
+        D2 = torch.cdist(X, X) ** 2
+        return torch.exp(-D2 / (2 * 0.49 * D2.mean() / 2))
+    C1, C2 = kern(n, 4), kern(m, 14)
+
+    def run(outer, sk):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, gw = entropic_gromov_wasserstein(C1, C2, None, None, "square_loss", 0.1, outer, sk, "f64", return_plan=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, float(gw)
+    run(1, 1)                                   # warm
+    t1, _ = run(1, 1)                           # 2 GEMM pairs (iteration + final loss) + 1 Sinkhorn iteration
+    t2, gw = run(1, 11)
+    sk = (t2 - t1) / 10
+    pair = (t1 - sk) / 2
+    fl = flops_per_outer_iteration(n, m)
+    return {"what": "entropic Gromov-Wasserstein (PGD + Sinkhorn), EXTENSION: not a reference computation, parity unpinned vs POT",
+            "n": n, "m": m, "precision": "f64", "gw": gw, "gemm_pair_ms": pair * 1e3, "sinkhorn_iter_ms": sk * 1e3,
+            "roofline": {"bound": "mfma", "kernel": "k_gw_gemm<double> x 2 (tensor product)", "achieved": fl / pair / 1e12,
+                         "peak": 78.6, "unit": "TFLOP/s", "frac": fl / pair / 1e12 / 78.6, "flop_per_pair": fl},
+            "sinkhorn_GBps": 2 * n * m * 8 / sk / 1e9}
 
 
 def self_launch(args):
@@ -326,6 +363,8 @@ def main():
                 pass
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
+    if rank == 0 and not dry and not args.no_gw_extension:
+        result["gw_extension"] = gw_extension_leg(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         result["cpu_baseline"] = cpu_baseline(N)
     elif rank == 0:

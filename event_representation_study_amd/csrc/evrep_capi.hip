@@ -10,6 +10,7 @@
 #include "evrep_bin.hip"
 #include "evrep_builders.hip"
 #include "evrep_gwd.hip"
+#include "evrep_gw.hip"
 
 using namespace evrep;
 
@@ -39,6 +40,76 @@ static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
         attr_set = true;
     }
     k_gwd_tiles<NSS, NST><<<P.ntiles, kThreads, lds, stream>>>(P);
+    return EVREP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- entropic GW (F5)
+template <typename T>
+struct GwScratch {
+    T *hC1, *hC2, *ai, *bj, *Tp, *G, *Km;
+    double *u, *v, *colpart, *losspart;
+    size_t bytes;
+};
+template <typename T>
+static GwScratch<T> gw_carve(void *scratch, int64_t n, int64_t m) {
+    GwScratch<T> w;
+    char *p = static_cast<char *>(scratch);
+    size_t o = 0;
+    auto take = [&](size_t b) { char *r = p ? p + o : nullptr; o += up256(b); return r; };
+    w.hC1 = reinterpret_cast<T *>(take((size_t)n * n * sizeof(T)));
+    w.hC2 = reinterpret_cast<T *>(take((size_t)m * m * sizeof(T)));
+    w.ai = reinterpret_cast<T *>(take((size_t)n * sizeof(T)));
+    w.bj = reinterpret_cast<T *>(take((size_t)m * sizeof(T)));
+    w.Tp = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
+    w.G = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
+    w.Km = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
+    w.u = reinterpret_cast<double *>(take((size_t)n * sizeof(double)));
+    w.v = reinterpret_cast<double *>(take((size_t)m * sizeof(double)));
+    w.colpart = reinterpret_cast<double *>(take((size_t)kGwSlices * m * sizeof(double)));
+    const size_t tiles = (size_t)((n + kGwBM - 1) / kGwBM) * ((m + kGwBN - 1) / kGwBN);
+    w.losspart = reinterpret_cast<double *>(take(tiles * sizeof(double)));
+    w.bytes = o;
+    return w;
+}
+
+template <typename T>
+static int gw_solve(const double *C1, int n, const double *C2, int m, const double *p, const double *q, int loss, double eps,
+                    int outer_iters, int sinkhorn_iters, void *scratch, double *T_out, double *gw_out, hipStream_t stream) {
+    GwScratch<T> w = gw_carve<T>(scratch, n, m);
+    const dim3 ggrid((m + kGwBN - 1) / kGwBN, (n + kGwBM - 1) / kGwBM);
+    const size_t nm = (size_t)n * m;
+    const unsigned eblocks = (unsigned)((nm + 255) / 256);
+    k_gw_init<T><<<n, kWave, 0, stream>>>(C1, n, p, loss, 1, w.hC1, w.ai);
+    k_gw_init<T><<<m, kWave, 0, stream>>>(C2, m, q, loss, 2, w.hC2, w.bj);
+    k_gw_outer<T><<<eblocks, 256, 0, stream>>>(p, q, n, m, w.Tp);
+    LAUNCH_CHECK("k_gw_init");
+    GwGemmArgs<T> g1;   // G = hC1 T
+    memset(&g1, 0, sizeof(g1));
+    g1.A = w.hC1; g1.B = w.Tp; g1.C = w.G; g1.M = n; g1.N = m; g1.K = n;
+    GwGemmArgs<T> g2;   // exp(-2 (a_i + b_j - G hC2^T) / eps)   or the loss
+    memset(&g2, 0, sizeof(g2));
+    g2.A = w.G; g2.B = w.hC2; g2.C = w.Km; g2.M = n; g2.N = m; g2.K = m; g2.ai = w.ai; g2.bj = w.bj;
+    g2.Tplan = w.Tp; g2.inv_eps = 1.0 / eps; g2.partial = w.losspart;
+    for (int it = 0; it < outer_iters; ++it) {
+        k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g1);
+        k_gw_gemm<T, true, GW_EPI_GIBBS><<<ggrid, kThreads, 0, stream>>>(g2);
+        LAUNCH_CHECK("k_gw_gemm");
+        k_gw_fill<<<(n + 255) / 256, 256, 0, stream>>>(w.u, n, 1.0 / n);
+        k_gw_fill<<<(m + 255) / 256, 256, 0, stream>>>(w.v, m, 1.0 / m);
+        for (int s = 0; s < sinkhorn_iters; ++s) {
+            k_gw_colsum<T><<<dim3((m + kThreads - 1) / kThreads, kGwSlices), kThreads, 0, stream>>>(w.Km, w.u, n, m, w.colpart);
+            k_gw_col_finish<<<(m + 255) / 256, 256, 0, stream>>>(w.colpart, q, m, w.v);
+            k_gw_rowdot<T><<<n, kWave, 0, stream>>>(w.Km, w.v, p, m, w.u);
+        }
+        k_gw_plan<T><<<eblocks, 256, 0, stream>>>(w.Km, w.u, w.v, n, m, w.Tp);
+        LAUNCH_CHECK("sinkhorn");
+    }
+    k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g1);
+    k_gw_gemm<T, true, GW_EPI_LOSS><<<ggrid, kThreads, 0, stream>>>(g2);
+    k_gw_loss_finish<<<1, kThreads, 0, stream>>>(w.losspart, (int)(ggrid.x * ggrid.y), gw_out);
+    if (T_out) k_gw_export<T><<<eblocks, 256, 0, stream>>>(w.Tp, nm, T_out);
+    LAUNCH_CHECK("k_gw_loss");
     return EVREP_OK;
 }
 
@@ -417,6 +488,23 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     k_gwd_finish<<<1, 1024, 0, stream>>>(partial, P.ntiles, (double)L, cost);
     LAUNCH_CHECK("k_gwd_finish");
     return EVREP_OK;
+}
+
+size_t evrep_gw_scratch_bytes(int64_t n, int64_t m, int32_t precision) {
+    if (n <= 0 || m <= 0) return 0;
+    return precision == EVREP_F32 ? gw_carve<float>(nullptr, n, m).bytes : gw_carve<double>(nullptr, n, m).bytes;
+}
+
+int evrep_entropic_gw(const double *C1, int64_t n, const double *C2, int64_t m, const double *p, const double *q,
+                      int32_t loss, double epsilon, int32_t outer_iters, int32_t sinkhorn_iters, int32_t precision,
+                      void *scratch, double *T_out, double *gw_out, void *stream_) {
+    if (!C1 || !C2 || !p || !q || !scratch || !gw_out || n <= 0 || m <= 0 || n > 46340 || m > 46340) return EVREP_EINVAL;
+    if ((loss != 0 && loss != 1) || !(epsilon > 0.0) || outer_iters < 0 || sinkhorn_iters < 1) return EVREP_EINVAL;
+    if ((precision != EVREP_F64 && precision != EVREP_F32) || (reinterpret_cast<uintptr_t>(scratch) & 255u)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (precision == EVREP_F32)
+        return gw_solve<float>(C1, (int)n, C2, (int)m, p, q, loss, epsilon, outer_iters, sinkhorn_iters, scratch, T_out, gw_out, stream);
+    return gw_solve<double>(C1, (int)n, C2, (int)m, p, q, loss, epsilon, outer_iters, sinkhorn_iters, scratch, T_out, gw_out, stream);
 }
 
 }  // extern "C"

@@ -187,6 +187,21 @@ size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m);
 int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt,
                         double h, void *scratch, double *cost, void *stream);
 
+/* EXTENSION (no live call of the reference computes this): entropic Gromov-Wasserstein by
+ * projected gradient, restated from POT's published ot.gromov.entropic_gromov_wasserstein (init_matrix,
+ * tensor_product, gwggrad, gwloss, sinkhorn_knopp) with FIXED iteration counts instead of its tolerance tests --
+ * the solver family of the reference's dead-code call ot.gromov.gromov_wasserstein(Ks, Kt, p, q, "kl_loss")
+ * (representation_search/gromov_wasserstein.py:62-69).  PARITY UNPINNED against POT (absent); checked against
+ * oracle/gw_oracle.py.
+ * C1 DEVICE double [n,n], C2 DEVICE double [m,m], p DEVICE double [n], q DEVICE double [m];
+ * loss 0 = "square_loss", 1 = "kl_loss"; precision EVREP_F64 (v_mfma_f64_16x16x4_f64) or EVREP_F32
+ * (v_mfma_f32_16x16x4_f32; plan and Gibbs kernel in float32, Sinkhorn scalings in float64);
+ * scratch DEVICE of evrep_gw_scratch_bytes(n, m, precision); T_out DEVICE double [n,m] or NULL; gw_out DEVICE double [1]. */
+size_t evrep_gw_scratch_bytes(int64_t n, int64_t m, int32_t precision);
+int evrep_entropic_gw(const double *C1, int64_t n, const double *C2, int64_t m, const double *p, const double *q,
+                      int32_t loss, double epsilon, int32_t outer_iters, int32_t sinkhorn_iters, int32_t precision,
+                      void *scratch, double *T_out, double *gw_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
