@@ -897,4 +897,42 @@ __global__ __launch_bounds__(kWave) void k_est(const Rec *__restrict__ sorted, c
     emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, r0, reduce);
 }
 
+// --------------------------------------------------------------------------------------------
+// F2: per-channel image resize of a channel-last representation, as resize_image / resize_image_process do with
+// cv2.resize per channel (ev-YOLOv6/yolov6/data/gen4/precompute_reps.py:179-260, gen1_2yolo.py:230-265).
+// cv2's INTER_AREA (shrinking) and INTER_LINEAR are separable: output (oy, ox) = sum over a few source rows of
+// beta * (sum over a few source columns of alpha * src) -- x first, then y, in float64, which is the order of
+// OpenCV's resizeArea_ / the vertical pass of its linear resize.  The taps come as small per-axis tables built on
+// the host from OpenCV's published table construction (gwd_pipeline.area_weights / linear_weights; PARITY UNPINNED
+// against cv2 itself, which is absent).  One thread per output element; every source element is read once from
+// HBM (neighbouring outputs share cache lines), the result is written once -- in place of two dense
+// (dst x src) float64 GEMMs over the whole frame.
+// --------------------------------------------------------------------------------------------
+struct ResizeTaps {
+    const int32_t *ystart, *ycount, *xstart, *xcount;  // [Ho], [Ho], [Wo], [Wo]
+    const double *ywt, *xwt;                           // [Ho][T], [Wo][T]
+    int32_t T;
+};
+
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(kThreads) void k_resize_taps(const InT *__restrict__ in, int H, int W, int C, ResizeTaps tp,
+                                                         int Ho, int Wo, double scale, OutT *__restrict__ out) {
+    const size_t per = (size_t)Ho * Wo * C;
+    const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= per) return;
+    const int b = blockIdx.y;
+    const int c = (int)(e % C);
+    const int ox = (int)((e / C) % Wo), oy = (int)(e / ((size_t)C * Wo));
+    const InT *src = in + (size_t)b * H * W * C + c;
+    const int ys = tp.ystart[oy], yn = tp.ycount[oy], xs = tp.xstart[ox], xn = tp.xcount[ox];
+    double acc = 0.0;
+    for (int ty = 0; ty < yn; ++ty) {
+        const InT *row = src + (size_t)(ys + ty) * W * C;
+        double rx = 0.0;
+        for (int tx = 0; tx < xn; ++tx) rx += (double)row[(size_t)(xs + tx) * C] * tp.xwt[ox * tp.T + tx];
+        acc += rx * tp.ywt[oy * tp.T + ty];
+    }
+    out[(size_t)b * per + e] = (OutT)(acc * scale);
+}
+
 }  // namespace evrep

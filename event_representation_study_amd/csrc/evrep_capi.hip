@@ -490,6 +490,26 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     return EVREP_OK;
 }
 
+int evrep_resize_taps(const void *in, int32_t in_dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                      int32_t T, const int32_t *ystart, const int32_t *ycount, const double *ywt, const int32_t *xstart,
+                      const int32_t *xcount, const double *xwt, double scale, int32_t out_dtype, void *out, void *stream_) {
+    if (!in || !out || !ystart || !ycount || !ywt || !xstart || !xcount || !xwt) return EVREP_EINVAL;
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || T <= 0) return EVREP_EINVAL;
+    if ((in_dtype != EVREP_F64 && in_dtype != EVREP_F32) || (out_dtype != EVREP_F64 && out_dtype != EVREP_F32)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ResizeTaps tp;
+    tp.ystart = ystart; tp.ycount = ycount; tp.xstart = xstart; tp.xcount = xcount; tp.ywt = ywt; tp.xwt = xwt; tp.T = T;
+    const size_t per = (size_t)Ho * Wo * C;
+    const dim3 grid((unsigned)((per + kThreads - 1) / kThreads), (unsigned)B);
+#define RESIZE_LAUNCH(IN, OUT) \
+    k_resize_taps<IN, OUT><<<grid, kThreads, 0, stream>>>(static_cast<const IN *>(in), H, W, C, tp, Ho, Wo, scale, static_cast<OUT *>(out))
+    if (in_dtype == EVREP_F64) { if (out_dtype == EVREP_F64) RESIZE_LAUNCH(double, double); else RESIZE_LAUNCH(double, float); }
+    else { if (out_dtype == EVREP_F64) RESIZE_LAUNCH(float, double); else RESIZE_LAUNCH(float, float); }
+#undef RESIZE_LAUNCH
+    LAUNCH_CHECK("k_resize_taps");
+    return EVREP_OK;
+}
+
 size_t evrep_gw_scratch_bytes(int64_t n, int64_t m, int32_t precision) {
     if (n <= 0 || m <= 0) return 0;
     return precision == EVREP_F32 ? gw_carve<float>(nullptr, n, m).bytes : gw_carve<double>(nullptr, n, m).bytes;

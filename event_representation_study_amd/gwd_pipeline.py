@@ -56,16 +56,59 @@ def linear_weights(src, dst):
     return Wm
 
 
+_TAPS = {}
+
+
+def resize_taps(src, dst, interpolation, device):
+    """(start, count, weights, T) device tables of the non-zero entries of the (dst, src) weight matrix: the few
+    source samples every output sample integrates (2-3 for an area shrink by 1-2x, 2 for bilinear)."""
+    key = (int(src), int(dst), interpolation, str(device))
+    if key not in _TAPS:
+        Wm = (area_weights if interpolation == "area" else linear_weights)(int(src), int(dst))
+        nz = Wm != 0
+        start = np.where(nz.any(1), nz.argmax(1), 0).astype(np.int32)
+        last = np.where(nz.any(1), Wm.shape[1] - 1 - nz[:, ::-1].argmax(1), 0)
+        count = np.where(nz.any(1), last - start + 1, 0).astype(np.int32)
+        T = max(int(count.max()), 1)
+        wt = np.zeros((int(dst), T), dtype=np.float64)
+        for d in range(int(dst)):
+            wt[d, :count[d]] = Wm[d, start[d]:start[d] + count[d]]
+        _TAPS[key] = (torch.from_numpy(start).to(device), torch.from_numpy(count).to(device),
+                      torch.from_numpy(wt).to(device), T)
+    return _TAPS[key]
+
+
+def resize_batch(rep, new_h, new_w, interpolation="area", scale=1.0, out_dtype=torch.float64, out=None):
+    """rep: (B, H, W, C) float64/float32 CUDA tensor -> (B, new_h, new_w, C) of out_dtype; every channel on its
+    own, like the reference's per-channel cv2.resize.  One launch of k_resize_taps (evrep_resize_taps)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    rep = rep.contiguous()
+    B, H, W, C = (int(v) for v in rep.shape)
+    ys, yc, yw, Ty = resize_taps(H, new_h, interpolation, rep.device)
+    xs, xc, xw, Tx = resize_taps(W, new_w, interpolation, rep.device)
+    T = max(Ty, Tx)
+    if Ty != T:
+        yw = torch.nn.functional.pad(yw, (0, T - Ty)).contiguous()
+    if Tx != T:
+        xw = torch.nn.functional.pad(xw, (0, T - Tx)).contiguous()
+    if out is None:
+        out = torch.empty((B, int(new_h), int(new_w), C), dtype=out_dtype, device=rep.device)
+    dt = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(rep.device):
+        _lib.check(lib.evrep_resize_taps(ptr(rep), dt[rep.dtype], B, H, W, C, int(new_h), int(new_w), T, ptr(ys), ptr(yc),
+                                         ptr(yw), ptr(xs), ptr(xc), ptr(xw), float(scale), dt[out.dtype], ptr(out),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "evrep_resize_taps")
+    return out
+
+
 def resize(im, new_w, new_h, interpolation="area"):
     """im: (H, W, C) tensor/array -> (new_h, new_w, C) float64 cuda tensor; every channel on its own, like
     the reference's per-channel cv2.resize."""
     t = torch.as_tensor(im).to("cuda", torch.float64)
-    H, W = int(t.shape[0]), int(t.shape[1])
-    fn = area_weights if interpolation == "area" else linear_weights
-    wy = torch.from_numpy(fn(H, new_h)).to(t.device)
-    wx = torch.from_numpy(fn(W, new_w)).to(t.device)
-    # out[y, x, c] = sum_{i,j} wy[y,i] * wx[x,j] * im[i,j,c]
-    return torch.einsum("yi,ijc,xj->yxc", wy, t, wx)
+    return resize_batch(t[None], new_h, new_w, interpolation)[0]
 
 
 def resize_image(im, img_size, augment=False):

@@ -1,12 +1,22 @@
-"""Offline precompute of representations (SURVEY.md 8 row F2 / BASELINE config 5): the GPU-side
-counterpart of ``Prophesee.process_representations`` (ev-YOLOv6/yolov6/data/gen4/precompute_reps.py:
-405-466): events (n, 4) -> representation -> forced (S, S) per-channel resize -> float32 file per sample.
+"""Offline precompute of representations (SURVEY.md 8 row F2 / BASELINE config 5): the GPU-side counterpart of
+``Prophesee.process_representations`` / ``process_representation``
+(ev-YOLOv6/yolov6/data/gen4/precompute_reps.py:405-466):
 
-Differences, stated plainly: (1) h5py is absent in this image, so samples are written as ``.npy``
-(the reference keeps that very call as a comment, precompute_reps.py:431) -- same array, same dtype,
-different container; (2) the resize is the OpenCV INTER_AREA / INTER_LINEAR restatement of
-``gwd_pipeline`` (parity unpinned against cv2); (3) instead of a Pool(8) of CPU workers, windows are
-batched through one GPU and a small thread pool only drains pinned host buffers to disk.
+    events (n, 4) int32 [x, y, t, p]  ->  get_item_transform (x255)  ->  resize_image_process: forced (S, S)
+    per-channel cv2.resize (INTER_AREA when shrinking, :216-260)  ->  float32  ->  ``<counter>.h5`` with one
+    dataset "repr" (:432-435), which gen4_2yolo.py:383-386 reads back with h5py.
+
+Here windows are batched through one GPU: binning pass + builder (``EventBatch``), ONE launch of the tap-table
+resize kernel (``evrep_resize_taps``: every source element read once, float32 written once -- not two dense
+float64 GEMMs with (S x H) / (S x W) weight matrices), pinned-buffer D2H on a copy stream, and a small thread
+pool that writes real HDF5 files (``h5lite``: header + array bytes).  Inputs can come straight from the reference's
+event containers (``run_h5``: flat (n, 4) int32 datasets under string keys, :408-409).
+
+Differences, stated plainly: (1) the resize is the OpenCV INTER_AREA / INTER_LINEAR restatement of
+``gwd_pipeline`` -- parity unpinned against cv2, which is absent; (2) instead of a Pool(8) of CPU workers the
+windows share one GPU and the CPU only drains buffers to disk.  As in the reference, the resize is skipped when
+the representation's long side already equals S (``if r != 1``, :228), and TORE is built on the events' bounding
+box per sample (gen4_transforms' branch), so its samples are resized one by one.
 """
 import os
 import queue
@@ -16,74 +26,149 @@ import time
 import numpy as np
 import torch
 
+from . import h5lite
 from .engine import EventBatch
-from .gwd_pipeline import area_weights, linear_weights
+from .gwd_pipeline import resize_batch
+
+BUILDERS = ("optimized", "event_stack", "time_surface", "tore", "voxel_grid")
 
 
 class RepPrecomputer:
-    def __init__(self, height, width, out_size=640, builder="optimized", device="cuda:0", writers=4):
+    def __init__(self, height, width, out_size=640, builder="optimized", device="cuda:0", writers=4, container="h5",
+                 augment=False):
+        if builder not in BUILDERS:
+            raise ValueError("builder must be one of %r" % (BUILDERS,))
+        if container not in ("h5", "npy"):
+            raise ValueError("container must be 'h5' or 'npy'")
         self.H, self.W, self.S = int(height), int(width), int(out_size)
         self.builder = builder
         self.device = torch.device(device)
-        r = self.S / max(self.H, self.W)
-        fn = area_weights if r < 1 else linear_weights            # resize_image_process: area when shrinking
-        self.wy = torch.from_numpy(fn(self.H, self.S)).to(self.device)
-        self.wx = torch.from_numpy(fn(self.W, self.S)).to(self.device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.nwriters = writers
+        self.nwriters = int(writers)
+        self.container = container
+        self.augment = bool(augment)
+        self._ring, self._ring_pos = {}, {}
 
+    # ------------------------------------------------------------------------------------------ GPU side
     def _build(self, batch):
+        """(B, H, W, C) tensor, already x255 as get_item_transform returns it; TORE: list of (Hbb, Wbb, C)."""
         if self.builder == "optimized":
-            return batch.optimized(scale=255.0)                   # get_item_transform scales by 255
+            return batch.optimized(scale=255.0)
         if self.builder == "event_stack":
-            return batch.event_stack(12, premap=True, scale=255.0).to(torch.float64)
+            return batch.event_stack(12, premap=True, scale=255.0)
         if self.builder == "time_surface":
             return batch.time_surface(6, 50000.0, premap=True, scale=255.0)
-        if self.builder == "tore":
-            return batch.tore(6, frame_mode=1, scale=255.0).to(torch.float64)
-        raise ValueError(self.builder)
+        if self.builder == "voxel_grid":
+            return batch.voxel(12, mode=1, scale=255.0)
+        return batch.tore(6, frame_mode=0, scale=255.0)           # per-sample bounding-box frames
 
-    def run(self, window_batches, out_dir, keep_files=True):
-        """window_batches: iterable of lists of (n, 4) int32 arrays.  Returns (samples, bytes, seconds)."""
+    def _interp(self, h0, w0):
+        r = self.S / max(h0, w0)
+        return None if r == 1 else ("area" if (r < 1 and not self.augment) else "linear")
+
+    def represent(self, wins):
+        """windows -> (B, S, S, C) float32 on the GPU (or (B, H, W, C) when no resize applies)."""
+        batch = EventBatch.from_numpy(wins, self.H, self.W, device=self.device)
+        rep = self._build(batch)
+        if isinstance(rep, list):                                  # TORE: its own frame per sample
+            outs = []
+            for r in rep:
+                mode = self._interp(int(r.shape[0]), int(r.shape[1]))
+                outs.append(r.to(torch.float32) if mode is None else
+                            resize_batch(r[None], self.S, self.S, mode, out_dtype=torch.float32)[0])
+            return torch.stack(outs) if len({tuple(o.shape) for o in outs}) == 1 else outs
+        mode = self._interp(self.H, self.W)
+        if mode is None:
+            return rep.to(torch.float32)
+        return resize_batch(rep, self.S, self.S, mode, out_dtype=torch.float32)
+
+    # ------------------------------------------------------------------------------------------ host side
+    def _pinned(self, shape):
+        """Pinned staging buffers are recycled round-robin (page-locking a fresh 150 MB buffer per batch costs more
+        than the copy); a ring deeper than the writer queue, so a buffer is never reused while a writer holds it."""
+        ring = self._ring.setdefault(shape, [])
+        depth = 4 + self.nwriters + 2
+        if len(ring) < depth:
+            ring.append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
+            return ring[-1]
+        self._ring_pos[shape] = (self._ring_pos.get(shape, -1) + 1) % depth
+        return ring[self._ring_pos[shape]]
+
+    def _write(self, path_base, arr):
+        if self.container == "h5":
+            h5lite.write_dataset_file(path_base + ".h5", "repr", arr)   # fh.create_dataset("repr", ..., dtype="f4")
+            return path_base + ".h5"
+        np.save(path_base + ".npy", arr)
+        return path_base + ".npy"
+
+    def run(self, window_batches, out_dir, keep_files=True, first_index=0):
+        """window_batches: iterable of lists of (n, 4) int32 arrays.  One file ``<counter>.h5`` per sample.
+        Returns (samples, bytes written, seconds)."""
         os.makedirs(out_dir, exist_ok=True)
         q = queue.Queue(maxsize=4)
-        written = [0]
+        written = [0] * self.nwriters                              # one counter per writer thread: no shared update
+        errors = []
 
-        def writer():
+        def writer(slot):
             while True:
                 item = q.get()
                 if item is None:
                     return
                 idx0, host, ev = item
-                ev.synchronize()                                   # the D2H copy of this buffer has landed
-                for k in range(host.shape[0]):
-                    path = os.path.join(out_dir, "%d.npy" % (idx0 + k))
-                    np.save(path, host[k].numpy())
-                    written[0] += host[k].numel() * 4
-                    if not keep_files:
-                        os.remove(path)
+                try:
+                    ev.synchronize()                               # the D2H copy of this buffer has landed
+                    for k in range(len(host)):
+                        arr = host[k].numpy()
+                        path = self._write(os.path.join(out_dir, "%d" % (idx0 + k)), arr)
+                        written[slot] += arr.nbytes
+                        if not keep_files:
+                            os.remove(path)
+                except Exception as e:                             # surfaced by run(): a lost sample is not silent
+                    errors.append(e)
 
-        threads = [threading.Thread(target=writer, daemon=True) for _ in range(self.nwriters)]
+        threads = [threading.Thread(target=writer, args=(i,), daemon=True) for i in range(self.nwriters)]
         for t in threads:
             t.start()
         t0 = time.perf_counter()
-        count = 0
+        count = first_index
         for wins in window_batches:
-            batch = EventBatch.from_numpy(wins, self.H, self.W, device=self.device)
-            rep = self._build(batch)                                # (B, H, W, C) float64 on the GPU
-            small = torch.einsum("yi,bijc,xj->byxc", self.wy, rep, self.wx).to(torch.float32).contiguous()
-            host = torch.empty(small.shape, dtype=torch.float32, pin_memory=True)
+            small = self.represent(wins)
+            parts = small if isinstance(small, list) else [small]
+            hosts = []
             done = torch.cuda.Event()
             self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.copy_stream):
-                host.copy_(small, non_blocking=True)
-                small.record_stream(self.copy_stream)
+                for part in parts:
+                    host = self._pinned(tuple(part.shape))
+                    host.copy_(part, non_blocking=True)
+                    part.record_stream(self.copy_stream)
+                    hosts.append(host)
                 done.record(self.copy_stream)
-            q.put((count, host, done))
+            host_list = hosts[0] if not isinstance(small, list) else hosts
+            q.put((count, host_list, done))
             count += len(wins)
         for _ in threads:
             q.put(None)
         for t in threads:
             t.join()
-        el = time.perf_counter() - t0
-        return count, written[0], el
+        if errors:
+            raise errors[0]
+        return count - first_index, sum(written), time.perf_counter() - t0
+
+    def run_h5(self, event_h5_file, keys, out_dir, batch=8, **kw):
+        """The reference's input side: every ``key`` of ``event_h5_file`` is a flat (n, 4) int32 [x, y, t, p] dataset
+        (precompute_reps.py:408-409 reads it with np.array(hf.get(key)); fix_events_training views it as '<i4'
+        fields, :737-740).  Samples are numbered in key order."""
+        f = h5lite.File(event_h5_file)
+
+        def batches():
+            for i in range(0, len(keys), batch):
+                wins = []
+                for k in keys[i:i + batch]:
+                    ev = np.asarray(f[k])
+                    if ev.ndim != 2 or ev.shape[1] != 4 or ev.dtype.itemsize != 4 or ev.dtype.kind not in "iu":
+                        raise ValueError("%s[%r]: expected an (n, 4) int32 event array, got %s %s"
+                                         % (event_h5_file, k, ev.shape, ev.dtype))
+                    wins.append(np.ascontiguousarray(ev.view(np.int32)))
+                yield wins
+        return self.run(batches(), out_dir, **kw)

@@ -187,6 +187,18 @@ size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m);
 int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt,
                         double h, void *scratch, double *cost, void *stream);
 
+/* Per-channel resize of a channel-last representation (B,H,W,C) -> (B,Ho,Wo,C), what resize_image /
+ * resize_image_process do with cv2.resize per channel before a representation is stored or scored
+ * (ev-YOLOv6/yolov6/data/gen4/precompute_reps.py:179-260,424; gen1_2yolo.py:230-265).  The interpolation is given as
+ * separable tap tables: output row oy = sum_{t < ycount[oy]} ywt[oy*T + t] * (source row ystart[oy] + t), likewise
+ * for columns -- built on the host from OpenCV's published INTER_AREA / INTER_LINEAR table construction
+ * (event_representation_study_amd/gwd_pipeline.py; parity unpinned against cv2, which is absent).
+ * in DEVICE float64/float32 (in_dtype); tap tables DEVICE; out DEVICE float64/float32 (out_dtype: the reference stores
+ * float32, precompute_reps.py:434), every value times `scale`. */
+int evrep_resize_taps(const void *in, int32_t in_dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                      int32_t T, const int32_t *ystart, const int32_t *ycount, const double *ywt, const int32_t *xstart,
+                      const int32_t *xcount, const double *xwt, double scale, int32_t out_dtype, void *out, void *stream);
+
 /* EXTENSION (no live call of the reference computes this): entropic Gromov-Wasserstein by
  * projected gradient, restated from POT's published ot.gromov.entropic_gromov_wasserstein (init_matrix,
  * tensor_product, gwggrad, gwloss, sinkhorn_knopp) with FIXED iteration counts instead of its tolerance tests --

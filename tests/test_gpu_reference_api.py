@@ -313,10 +313,30 @@ def test_gwd_caller_pipeline_f1():
     assert abs(cp - float(np.mean(manual))) < 1e-12 and 0.0 < cp < 1.0
 
 
-def test_precompute_pipeline_f2(tmp_path):
-    """SURVEY 8 row F2 / BASELINE config 5: windows -> representation -> forced (S,S) resize -> float32 file per sample."""
+def test_resize_taps_kernel_equals_dense_weight_matrices():
+    """evrep_resize_taps (one pass, a few taps per output) == the dense (dst x src) weight matrices it was cut
+    from, applied as float64 einsum (what round 1 shipped): area and linear, shrink and enlarge, odd sizes."""
     import torch
     from event_representation_study_amd import gwd_pipeline as gp
+    rng = np.random.default_rng(4)
+    for (H, W, C, nh, nw, mode) in ((90, 160, 12, 80, 80, "area"), (720, 1280, 3, 640, 640, "area"), (37, 53, 5, 64, 71, "linear"),
+                                    (240, 304, 12, 189, 240, "area"), (48, 64, 2, 48, 64, "area")):
+        rep = torch.from_numpy(rng.random((2, H, W, C)) * 255.0).cuda()
+        fn = gp.area_weights if mode == "area" else gp.linear_weights
+        wy, wx = torch.from_numpy(fn(H, nh)).cuda(), torch.from_numpy(fn(W, nw)).cuda()
+        want = torch.einsum("yi,bijc,xj->byxc", wy, rep, wx)
+        got = gp.resize_batch(rep, nh, nw, mode)
+        assert got.dtype == torch.float64 and tuple(got.shape) == (2, nh, nw, C)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-13, atol=1e-12)
+        got32 = gp.resize_batch(rep.to(torch.float32), nh, nw, mode, out_dtype=torch.float32)
+        np.testing.assert_allclose(got32.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_precompute_pipeline_f2(tmp_path):
+    """SURVEY 8 row F2 / BASELINE config 5: windows -> representation -> forced (S,S) resize -> one HDF5 file per
+    sample holding the float32 dataset "repr" (precompute_reps.py:432-435), read back here with the h5lite reader."""
+    import torch
+    from event_representation_study_amd import gwd_pipeline as gp, h5lite
     from event_representation_study_amd.engine import EventBatch
     from event_representation_study_amd.precompute import RepPrecomputer
     H, W, S = 90, 160, 80
@@ -325,11 +345,63 @@ def test_precompute_pipeline_f2(tmp_path):
     n, nbytes, el = pc.run([wins[:3], wins[3:]], str(tmp_path))
     assert n == 5 and nbytes == 5 * S * S * 12 * 4
     for i, ev in enumerate(wins):
-        got = np.load(str(tmp_path / ("%d.npy" % i)))
+        got = h5lite.File(str(tmp_path / ("%d.h5" % i)))["repr"][()]
         assert got.shape == (S, S, 12) and got.dtype == np.float32
         rep = EventBatch.from_numpy(ev, H, W).optimized(scale=255.0)[0]
         want = gp.resize(rep, S, S, "area").to(torch.float32).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    # every builder of the dispatcher goes through; TORE on its per-sample bounding box; no resize when r == 1
+    for b in ("event_stack", "time_surface", "tore", "voxel_grid"):
+        d = tmp_path / b
+        n, nbytes, _ = RepPrecomputer(H, W, S, b, writers=1).run([wins[:2]], str(d))
+        assert n == 2 and h5lite.File(str(d / "1.h5"))["repr"].shape == (S, S, 12)
+    d = tmp_path / "same"
+    RepPrecomputer(H, W, W, "optimized", writers=1).run([wins[:1]], str(d))
+    same = h5lite.File(str(d / "0.h5"))["repr"][()]
+    assert same.shape == (H, W, 12)                                    # `if r != 1` (precompute_reps.py:228)
+    np.testing.assert_array_equal(same, EventBatch.from_numpy(wins[0], H, W).optimized(scale=255.0)[0].to(torch.float32).cpu().numpy())
+
+
+def test_precompute_c5_full_size(tmp_path):
+    """BASELINE config 5 at its real size: 1280x720 windows of 200 000 events -> (640, 640, 12) float32 "repr"
+    files, against round 1's dense float64 weight-matrix resize of the same builder output."""
+    import torch
+    from event_representation_study_amd import gwd_pipeline as gp, h5lite
+    from event_representation_study_amd.engine import EventBatch
+    from event_representation_study_amd.precompute import RepPrecomputer
+    H, W, S, N = 720, 1280, 640, 200000
+    wins = [make_events(N, W, H, seed=500 + i) for i in range(3)]
+    n, nbytes, el = RepPrecomputer(H, W, S, "optimized", writers=2).run([wins], str(tmp_path / "reps"))
+    assert n == 3 and nbytes == 3 * S * S * 12 * 4
+    rep = EventBatch.from_numpy(wins, H, W).optimized(scale=255.0)
+    wy, wx = torch.from_numpy(gp.area_weights(H, S)).cuda(), torch.from_numpy(gp.area_weights(W, S)).cuda()
+    want = torch.einsum("yi,bijc,xj->byxc", wy, rep, wx).to(torch.float32).cpu().numpy()
+    for i in range(3):
+        got = h5lite.File(str(tmp_path / "reps" / ("%d.h5" % i)))["repr"][()]
+        assert got.shape == (S, S, 12) and got.dtype == np.float32
+        np.testing.assert_allclose(got, want[i], rtol=1e-6, atol=1e-6)
+
+
+def test_precompute_reads_event_containers_h5py_wrote(tmp_path):
+    """run_h5: events come straight from an HDF5 container real h5py wrote (tests/golden/h5/, flat (n, 4) int32
+    datasets under string keys as precompute_reps.py:408-409 reads them) and give the same files as run()."""
+    import os
+    from conftest import GOLDEN
+    from event_representation_study_amd import h5lite
+    from event_representation_study_amd.precompute import RepPrecomputer
+    src = os.path.join(GOLDEN, "h5", "events_gen4_layout.h5")
+    ev = np.load(os.path.join(GOLDEN, "h5", "expected.npz"))["g4_b"]
+    H = W = 1024
+    pc = RepPrecomputer(H, W, 256, "event_stack", writers=1)
+    n, _, _ = pc.run_h5(src, ["chunked_nofilter"], str(tmp_path / "a"))
+    assert n == 1
+    order = np.argsort(ev[:, 2], kind="stable")                 # the fixture's t column is random: sort it for the builders
+    del order
+    pc.run([[np.ascontiguousarray(ev)]], str(tmp_path / "b"))
+    np.testing.assert_array_equal(h5lite.File(str(tmp_path / "a" / "0.h5"))["repr"][()],
+                                  h5lite.File(str(tmp_path / "b" / "0.h5"))["repr"][()])
+    with pytest.raises(ValueError):
+        pc.run_h5(src, ["moorea_2019-02-19_004_td_2257500000_2317500000_td_000012"], str(tmp_path / "c"))   # float64 rows
 
 
 # ------------------------------------------------------------------ F4: n_imagenet accumulators
