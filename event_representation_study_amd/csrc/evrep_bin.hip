@@ -561,7 +561,8 @@ constexpr int kBsThreads = 1024;
 constexpr int kBsWaves = kBsThreads / kWave;     // 16
 constexpr int kBsPerLane = 8;
 constexpr int kBsChunk = kBsThreads * kBsPerLane;  // 8192 events per workgroup
-constexpr int kBsMaxBlocks = 16;                 // runs one k_col_sort_runs wave gathers (one lane each)
+constexpr int kBsMaxBlocks = 64;                 // runs one k_col_sort_runs wave gathers (one lane each): 524 288 events / window
+constexpr int kBsChainBlocks = 16;               // up to here the run of a record is found by a readlane chain, above by an LDS search
 
 __host__ __device__ inline int bs_hp(int H) { return (H + 1) & ~1; }
 __host__ __device__ inline size_t block_rowsort_lds_bytes(int H) {
@@ -735,6 +736,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__rest
 constexpr int kCsWaves = 4;
 __host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / kWave + 3) / 4; }
 __host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
+__host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_words(W) + 128; }   // + the run table (pre, src)
 #ifndef EVREP_CS_ROWS
 #define EVREP_CS_ROWS 1
 #endif
@@ -746,11 +748,11 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
                                                                      int nchunk, Rec *__restrict__ sorted2,
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
-    extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_words(W)]
+    extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, row0 = (blockIdx.x * kCsWaves + wave) * R;
     if (row0 >= H) return;
-    uint32_t *cnt = cnt_all + (size_t)wave * col_sort_words(W);
+    uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
     const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);  // <= kBsMaxBlocks: one lane per block run
@@ -790,23 +792,44 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         const uint32_t len = t[r + 1] - t[r];
         uint32_t incl = len;
 #pragma unroll
-        for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }  // full wave
         pre[r] = incl - len;                                                            // this row's records in earlier blocks
         rs[r + 1] = rs[r] + (uint32_t)__builtin_amdgcn_readlane((int)incl, kBsMaxBlocks - 1);  // rows are contiguous in sorted2
         src[r] = (uint32_t)beg + (uint32_t)lane * kBsChunk + t[r] - pre[r];            // record j of the row: src_k + j
     }
     // record j of row r lies in the run k with pre_k <= j < pre_{k+1}: a sum of conditional steps over the runs
     // (lanes >= nb hold pre = n, so they never match a j < n)
+    // (more than kBsChainBlocks runs: pre / src of the row go through 2 x 64 words of the wave's LDS and every lane
+    // finds its run by a 6-step binary search -- pre is non-decreasing, the LAST k with pre_k <= j holds record j)
+    uint32_t *runs = cnt + col_sort_words(W);  // [2][64], only used when nb > kBsChainBlocks
+    int runs_row = -1;
     auto fetch = [&](int r, uint32_t j) -> Rec {
-        uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src[r], 0);
-        uint32_t prev = s;
-        for (int k = 1; k < nb; ++k) {
-            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre[r], k);
-            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src[r], k);
-            s += (j >= pk) ? sk - prev : 0u;
-            prev = sk;
+        if (nb <= kBsChainBlocks) {
+            uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src[r], 0);
+            uint32_t prev = s;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre[r], k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src[r], k);
+                s += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return sorted1[s + j];
         }
-        return sorted1[s + j];
+        if (runs_row != r) {  // uniform
+            wave_phase_lds();
+            runs[lane] = pre[r];
+            runs[64 + lane] = src[r];
+            wave_phase_lds();
+            runs_row = r;
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && runs[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return sorted1[runs[64 + lo] + j];
     };
     Rec e[R][4];
 #pragma unroll

@@ -35,6 +35,10 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #ifndef EVREP_XCD_MAP
 #define EVREP_XCD_MAP 1
 #endif
+#ifndef EVREP_NT_STORES
+#define EVREP_NT_STORES 1  // non-temporal output stores (the tensor is written once and never re-read by the step): -3 us on
+                           // the ERGO-12 launch and -3 us on the next binning pass, whose loads find less of L2 evicted (r02)
+#endif
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
@@ -105,14 +109,26 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
     constexpr int V = 16 / (int)sizeof(OutT);
     if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
         const int nvec = count / V;
+        int v = threadIdx.x;
+#if EVREP_NT_STORES
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        const nt4 *n4 = reinterpret_cast<const nt4 *>(tile);
+        nt4 *o4 = reinterpret_cast<nt4 *>(dst);
+        for (; v + 3 * kWave < nvec; v += 4 * kWave) {
+            const nt4 a = n4[v], b = n4[v + kWave], c = n4[v + 2 * kWave], d = n4[v + 3 * kWave];
+            __builtin_nontemporal_store(a, o4 + v); __builtin_nontemporal_store(b, o4 + v + kWave);
+            __builtin_nontemporal_store(c, o4 + v + 2 * kWave); __builtin_nontemporal_store(d, o4 + v + 3 * kWave);
+        }
+        for (; v < nvec; v += kWave) __builtin_nontemporal_store(n4[v], o4 + v);
+#else
         const float4 *s4 = reinterpret_cast<const float4 *>(tile);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        int v = threadIdx.x;
         for (; v + 3 * kWave < nvec; v += 4 * kWave) {
             const float4 a = s4[v], b = s4[v + kWave], c = s4[v + 2 * kWave], d = s4[v + 3 * kWave];
             d4[v] = a; d4[v + kWave] = b; d4[v + 2 * kWave] = c; d4[v + 3 * kWave] = d;
         }
         for (; v < nvec; v += kWave) d4[v] = s4[v];
+#endif
         for (int e = nvec * V + threadIdx.x; e < count; e += kWave) dst[e] = tile[e];
     } else {
         for (int e = threadIdx.x; e < count; e += kWave) dst[e] = tile[e];

@@ -136,7 +136,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
         chunk = ((max_events_per_window + 127) / 128 + 255) / 256 * 256;
         nblk = (max_events_per_window + chunk - 1) / chunk;
     }
-    // the two-kernel pass (k_block_rowsort + k_col_sort_runs): windows of <= 16 blocks of 8192 events on sensors
+    // the two-kernel pass (k_block_rowsort + k_col_sort_runs): windows of <= 64 blocks of 8192 events on sensors
     // whose per-wave row counters fit next to the 128 KB record stage in one workgroup's LDS (H <= ~900)
     const bool two_kernel = max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk &&
                             block_rowsort_lds_bytes(H) + 1024 <= 160 * 1024 && !getenv("EVREP_BIN_THREE_KERNEL");
@@ -204,7 +204,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         LAUNCH_CHECK("k_block_rowsort");
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
-        k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_words(W) * 4, stream>>>(
+        k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
             s1, offsets, table, stats, H, W, nblk, plan->nchunk, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
