@@ -361,6 +361,13 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
         }
     }
 
+    // Float64 divisions are the expensive instructions of this kernel (dense windows are VALU-bound), and two thirds
+    // of them can go without changing one bit of the result:
+    //  * `max` of the normalised timestamp: the quotient (t - tmin) / interval is monotone in t, so the maximum is
+    //    taken over the INTEGER timestamps and divided once per pixel instead of once per event;
+    //  * a count of 1 (the usual case: most pixels see one event of a window): x / 1.0 == x exactly, so mean and
+    //    variance skip their divisions;
+    //  * the per-event quotient is only formed for events that some sum / mean / variance timestamp channel takes.
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[D::kMaxC]) {
         double s[D::kMaxC], s2[D::kMaxC];
         int cnt[D::kMaxC];
@@ -369,20 +376,35 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
         for (uint32_t j = jb; j < je; ++j) {
             const Rec e = get(j);
             const int rank = e.y, p = e.w;
-            const double tn = (double)((int64_t)e.z - (int64_t)tmin) / interval;
+            const double trel = (double)((int64_t)e.z - (int64_t)tmin);  // exact: |t - tmin| < 2^32
             const double pv = (double)p;
+            bool need_tn = false;
+#pragma unroll
+            for (int c = 0; c < D::kMaxC; ++c) {
+                if (c < C && active[c]) {
+                    const int f = D::func(P, c), a = D::agg(P, c);
+                    const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
+                    if (is_t && a != EVREP_A_MAX)
+                        need_tn |= rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
+                }
+            }
+            double tn = 0.0;
+            if (need_tn) tn = trel / interval;
 #pragma unroll
             for (int c = 0; c < D::kMaxC; ++c) {
                 if (c < C && active[c]) {
                     const bool hit = rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
                     const int f = D::func(P, c), a = D::agg(P, c);
-                    const double v = (f == EVREP_F_POLARITY) ? pv : (is_count_func(f) ? 1.0 : tn);
+                    const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
                     if (hit) {
                         if (a == EVREP_A_MAX) {
+                            // timestamp channels keep the running maximum of t - tmin (an exact integer) in s[c]
+                            const double v = is_t ? trel : ((f == EVREP_F_POLARITY) ? pv : 1.0);
                             if (cnt[c] == 0 || v > s[c]) s[c] = v;
                         } else if (is_count_func(f)) {
                             // src = ones: sum, sum of squares and count coincide (exact small integers)
                         } else {
+                            const double v = (f == EVREP_F_POLARITY) ? pv : tn;
                             s[c] = s[c] + v;
                             if (a == EVREP_A_VARIANCE) { const double vv = v * v; s2[c] = s2[c] + vv; }
                         }
@@ -396,16 +418,17 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             double r = 0.0;
             if (c < C && active[c]) {
                 const int f = D::func(P, c), a = D::agg(P, c);
+                const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
                 const double n = (double)cnt[c];
                 const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
                 if (is_count_func(f) && a != EVREP_A_MAX) {
                     // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
                     r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
                 } else if (a == EVREP_A_SUM) r = s[c];
-                else if (a == EVREP_A_MEAN) r = s[c] / d;
-                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+                else if (a == EVREP_A_MEAN) r = cnt[c] > 1 ? s[c] / d : s[c];
+                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? (is_t ? s[c] / interval : s[c]) : 0.0;
                 else {
-                    const double mean = s[c] / d, mean2 = s2[c] / d;
+                    const double mean = cnt[c] > 1 ? s[c] / d : s[c], mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
                     const double mm = mean * mean;
                     r = mean2 - mm;
                 }
@@ -781,7 +804,9 @@ struct PolStatParams {
 };
 
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
-__global__ __launch_bounds__(kWave) void k_polstats(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+// (6 waves per SIMD asked for: 110 -> 80 VGPRs with 52 bytes of scratch, 81 -> 64 us at 32 x 50 000 events, 640x480x6;
+// the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
+__global__ __launch_bounds__(kWave, 6) void k_polstats(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, int span,
                                                    float *__restrict__ out) {
