@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-gwd", action="store_true")
     ap.add_argument("--gwd-pairs", type=int, default=144,
                     help="GWD solves of the wall-time leg; 144 = the metric's 12x12 representation matrix")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes (~40 s) that measure roofline.traffic; the value is then "
+                         "replayed from profiles/traffic.json and labelled so")
     ap.add_argument("--no-gw-extension", action="store_true",
                     help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
     ap.add_argument("--pipeline", action="store_true",
@@ -171,6 +174,48 @@ def gwd_leg(rank, world, pairs, device, dry=False):
                            "mfma_flop_per_solve": flops, "us_per_solve": per_solve_s * 1e6,
                            "exp2_per_solve": 2 * sum(min(128 * (T - bi), 128 * T) * 128 for bi in range(T))}
     return res
+
+
+def live_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected NOW: two rocprofv3 passes
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters only with --kernel-trace) over tools/pmc_workload.py,
+    corrected by the calibration kernels that script runs first.  None if rocprofv3 is missing or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import parse_pmc
+        tmp = tempfile.mkdtemp(prefix="evrep_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        found = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py")],
+                           cwd="/tmp", env=env, check=True, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for dirpath, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        found[ctr] = os.path.join(dirpath, fn)
+        out = os.path.join(tmp, "traffic.json")
+        with open(os.devnull, "w") as devnull:
+            old = sys.stdout
+            sys.stdout = devnull
+            try:
+                parse_pmc.main(found["FETCH_SIZE"], found["WRITE_SIZE"], out)
+            finally:
+                sys.stdout = old
+        with open(out) as f:
+            res = json.load(f)
+        shutil.rmtree(tmp, ignore_errors=True)
+        return res.get(key)
+    except Exception as e:   # a profiler hiccup must not cost the bench line
+        print("[bench] live PMC traffic unavailable (%s: %s); replaying profiles/traffic.json" % (type(e).__name__, e), file=sys.stderr)
+        return None
 
 
 def gw_extension_leg(device):
@@ -365,6 +410,15 @@ def main():
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
     if rank == 0 and not dry and not args.no_gw_extension:
         result["gw_extension"] = gw_extension_leg(device)
+    if not dry and rank == 0 and world == 1 and not args.no_live_traffic and B == BATCH and N == EVENTS_PER_WINDOW:
+        live = live_traffic("k_mdes_f64" if elem == 8 else "k_mdes_f32")   # last GPU leg: two profiler passes, ~40 s
+        if live is not None:
+            result["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_read_bytes"] = live["read_bytes"]
+            result["roofline"]["traffic_write_bytes"] = live["write_bytes"]
+            result["roofline"]["traffic_source"] = ("collected in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                                                    "(two separate passes of tools/pmc_workload.py), calibrated on a 1 GiB fill "
+                                                    "and a 1 GiB copy of the same process as MI355X_MICROARCH.md prescribes")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         result["cpu_baseline"] = cpu_baseline(N)
     elif rank == 0:

@@ -3,7 +3,7 @@
 TAG=${1:-kt}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-gwd --no-gw-extension "$@" > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-gwd --no-gw-extension --no-live-traffic "$@" > $O/kt.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1)
 cp $f $O/kernel_stats.csv
 python3 - "$f" <<'PY'

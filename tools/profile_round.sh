@@ -1,24 +1,30 @@
 #!/bin/bash
 # One measurement session for profiles/rNN (run on the GPU box through gpurun, from the repository root):
 #   gpurun --timeout 2400 -- 'bash tools/profile_round.sh'
-# bench (f64, f32), rocprofv3 kernel trace + stats, the three PMC passes (separate, as MI355X_MICROARCH.md asks),
-# the builder sweep, per-sample latency, the GWD matrix and the EST bench -> gpurun_out/final/, from where the
-# summaries are copied into profiles/rNN/ (see profiles/README.md).
+# bench (f64 with live PMC traffic, f32), rocprofv3 kernel trace + stats of the bench step and of the GWD / GW legs,
+# the PMC passes (separate, as MI355X_MICROARCH.md asks), the builder sweep, per-sample latency, the GWD matrix, the
+# EST bench and the precompute pipeline -> gpurun_out/final/, from where the summaries are copied into
+# profiles/rNN/ (see profiles/README.md).
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --out-dtype f32 --no-cpu-baseline --no-gwd > $O/bench_f32.json 2>> $O/bench.err
+python bench.py --out-dtype f32 --no-cpu-baseline --no-gwd --no-gw-extension --no-live-traffic > $O/bench_f32.json 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o pmc_fetch -- python $R/tools/pmc_workload.py > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o pmc_write -- python $R/tools/pmc_workload.py > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -o pmc_sq -- python $R/tools/pmc_workload.py > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gwd_sq -o pmc_gwd -- python $R/tools/gwd_prof.py > $O/gwd_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gw_sq -o pmc_gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gw_kt -o gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_kt.log 2>&1
 cd $R
 python tools/bench_sweep.py > $O/sweep.jsonl 2> $O/sweep.err
 python tools/per_sample_latency.py > $O/per_sample.jsonl 2>&1
 python tools/gwd_matrix.py > $O/gwd_matrix.log 2>&1
 python tools/est_bench.py > $O/est_bench.json 2>/dev/null
-find $O -name "*.csv" | head -30
-tail -c 600 $O/bench.json
+python tools/gw_bench.py > $O/gw_bench_f64.json 2>/dev/null
+python tools/gw_bench.py --precision f32 > $O/gw_bench_f32.json 2>/dev/null
 python tools/precompute_reps.py --samples 256 2>/dev/null | grep "^{" > $O/precompute.json
+find $O -name "*.csv" | head -40
+tail -c 900 $O/bench.json
