@@ -49,6 +49,7 @@ template <typename T>
 struct GwScratch {
     T *hC1, *hC2, *ai, *bj, *Tp, *G, *Km;
     double *u, *v, *colpart, *losspart;
+    int ldn, ldm;  // leading dimensions of the n-column (hC1) and m-column (hC2^T, T, G, K) matrices
     size_t bytes;
 };
 template <typename T>
@@ -57,18 +58,18 @@ static GwScratch<T> gw_carve(void *scratch, int64_t n, int64_t m) {
     char *p = static_cast<char *>(scratch);
     size_t o = 0;
     auto take = [&](size_t b) { char *r = p ? p + o : nullptr; o += up256(b); return r; };
-    w.hC1 = reinterpret_cast<T *>(take((size_t)n * n * sizeof(T)));
-    w.hC2 = reinterpret_cast<T *>(take((size_t)m * m * sizeof(T)));
+    w.ldn = gw_ld((int)n, sizeof(T)); w.ldm = gw_ld((int)m, sizeof(T));
+    w.hC1 = reinterpret_cast<T *>(take((size_t)n * w.ldn * sizeof(T)));
+    w.hC2 = reinterpret_cast<T *>(take((size_t)m * w.ldm * sizeof(T)));
     w.ai = reinterpret_cast<T *>(take((size_t)n * sizeof(T)));
     w.bj = reinterpret_cast<T *>(take((size_t)m * sizeof(T)));
-    w.Tp = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
-    w.G = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
-    w.Km = reinterpret_cast<T *>(take((size_t)n * m * sizeof(T)));
+    w.Tp = reinterpret_cast<T *>(take((size_t)n * w.ldm * sizeof(T)));
+    w.G = reinterpret_cast<T *>(take((size_t)n * w.ldm * sizeof(T)));
+    w.Km = reinterpret_cast<T *>(take((size_t)n * w.ldm * sizeof(T)));
     w.u = reinterpret_cast<double *>(take((size_t)n * sizeof(double)));
     w.v = reinterpret_cast<double *>(take((size_t)m * sizeof(double)));
     w.colpart = reinterpret_cast<double *>(take((size_t)kGwSlices * m * sizeof(double)));
-    const size_t tiles = (size_t)((n + kGwBM - 1) / kGwBM) * ((m + kGwBN - 1) / kGwBN);
-    w.losspart = reinterpret_cast<double *>(take(tiles * sizeof(double)));
+    w.losspart = reinterpret_cast<double *>(take((size_t)n * sizeof(double)));   // one loss partial per row
     w.bytes = o;
     return w;
 }
@@ -80,35 +81,38 @@ static int gw_solve(const double *C1, int n, const double *C2, int m, const doub
     const dim3 ggrid((m + kGwBN - 1) / kGwBN, (n + kGwBM - 1) / kGwBM);
     const size_t nm = (size_t)n * m;
     const unsigned eblocks = (unsigned)((nm + 255) / 256);
-    k_gw_init<T><<<n, kWave, 0, stream>>>(C1, n, p, loss, 1, w.hC1, w.ai);
-    k_gw_init<T><<<m, kWave, 0, stream>>>(C2, m, q, loss, 2, w.hC2, w.bj);
-    k_gw_outer<T><<<eblocks, 256, 0, stream>>>(p, q, n, m, w.Tp);
+    k_gw_init<T><<<n, kWave, 0, stream>>>(C1, n, p, loss, 1, w.hC1, w.ldn, w.ai);
+    k_gw_init<T><<<m, kWave, 0, stream>>>(C2, m, q, loss, 2, w.hC2, w.ldm, w.bj);
+    k_gw_outer<T><<<eblocks, 256, 0, stream>>>(p, q, n, m, w.ldm, w.Tp);
     LAUNCH_CHECK("k_gw_init");
     GwGemmArgs<T> g1;   // G = hC1 T
     memset(&g1, 0, sizeof(g1));
-    g1.A = w.hC1; g1.B = w.Tp; g1.C = w.G; g1.M = n; g1.N = m; g1.K = n;
-    GwGemmArgs<T> g2;   // exp(-2 (a_i + b_j - G hC2^T) / eps)   or the loss
+    g1.A = w.hC1; g1.B = w.Tp; g1.C = w.G; g1.M = n; g1.N = m; g1.K = n; g1.lda = w.ldn; g1.ldb = w.ldm; g1.ldc = w.ldm;
+    GwGemmArgs<T> g2;   // exp(-2 (a_i + b_j - G hC2^T) / eps)   or the loss; w.hC2 holds h2(C2)^T, [K = m][N = m]
     memset(&g2, 0, sizeof(g2));
     g2.A = w.G; g2.B = w.hC2; g2.C = w.Km; g2.M = n; g2.N = m; g2.K = m; g2.ai = w.ai; g2.bj = w.bj;
+    g2.lda = w.ldm; g2.ldb = w.ldm; g2.ldc = w.ldm;
     g2.Tplan = w.Tp; g2.inv_eps = 1.0 / eps; g2.partial = w.losspart;
     for (int it = 0; it < outer_iters; ++it) {
         k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g1);
-        k_gw_gemm<T, true, GW_EPI_GIBBS><<<ggrid, kThreads, 0, stream>>>(g2);
+        k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g2);
+        k_gw_gibbs<T><<<eblocks, 256, 0, stream>>>(w.Km, w.ai, w.bj, n, m, w.ldm, 1.0 / eps);
         LAUNCH_CHECK("k_gw_gemm");
         k_gw_fill<<<(n + 255) / 256, 256, 0, stream>>>(w.u, n, 1.0 / n);
         k_gw_fill<<<(m + 255) / 256, 256, 0, stream>>>(w.v, m, 1.0 / m);
         for (int s = 0; s < sinkhorn_iters; ++s) {
-            k_gw_colsum<T><<<dim3((m + kThreads - 1) / kThreads, kGwSlices), kThreads, 0, stream>>>(w.Km, w.u, n, m, w.colpart);
+            k_gw_colsum<T><<<dim3((m + kThreads - 1) / kThreads, kGwSlices), kThreads, 0, stream>>>(w.Km, w.u, n, m, w.ldm, w.colpart);
             k_gw_col_finish<<<(m + 255) / 256, 256, 0, stream>>>(w.colpart, q, m, w.v);
-            k_gw_rowdot<T><<<n, kWave, 0, stream>>>(w.Km, w.v, p, m, w.u);
+            k_gw_rowdot<T><<<n, kWave, 0, stream>>>(w.Km, w.v, p, m, w.ldm, w.u);
         }
-        k_gw_plan<T><<<eblocks, 256, 0, stream>>>(w.Km, w.u, w.v, n, m, w.Tp);
+        k_gw_plan<T><<<eblocks, 256, 0, stream>>>(w.Km, w.u, w.v, n, m, w.ldm, w.Tp);
         LAUNCH_CHECK("sinkhorn");
     }
     k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g1);
-    k_gw_gemm<T, true, GW_EPI_LOSS><<<ggrid, kThreads, 0, stream>>>(g2);
-    k_gw_loss_finish<<<1, kThreads, 0, stream>>>(w.losspart, (int)(ggrid.x * ggrid.y), gw_out);
-    if (T_out) k_gw_export<T><<<eblocks, 256, 0, stream>>>(w.Tp, nm, T_out);
+    k_gw_gemm<T, false, GW_EPI_STORE><<<ggrid, kThreads, 0, stream>>>(g2);
+    k_gw_lossrows<T><<<n, kWave, 0, stream>>>(w.Km, w.Tp, w.ai, w.bj, m, w.ldm, w.losspart);
+    k_gw_loss_finish<<<1, kThreads, 0, stream>>>(w.losspart, n, gw_out);
+    if (T_out) k_gw_export<T><<<eblocks, 256, 0, stream>>>(w.Tp, n, m, w.ldm, T_out);
     LAUNCH_CHECK("k_gw_loss");
     return EVREP_OK;
 }

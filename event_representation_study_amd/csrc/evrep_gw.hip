@@ -13,8 +13,8 @@
 // The two GEMMs of the tensor product (2 n^2 m + 2 n m^2 flop per outer iteration, 9.7 TFLOP at the reference's
 // n = 12 500, m = 14 400) run on the matrix cores: v_mfma_f64_16x16x4_f64 for float64 parity with the oracle, or
 // v_mfma_f32_16x16x4_f32 (exact float32, twice the rate) when the caller asks for float32.  constC is rank one
-// (a_i + b_j), so it never exists as a matrix; the Gibbs kernel exp(-2 tens / epsilon) is produced by the second
-// GEMM's epilogue, and the final loss by a third pass's epilogue -- tens itself never touches HBM.
+// (a_i + b_j), so it never exists as a matrix; the Gibbs kernel exp(-2 tens / epsilon) and the final loss are one
+// streaming pass each over the second GEMM's product (0.6 ms against ~180 ms of GEMM).
 // Sinkhorn is HBM-bound (two passes over the n x m kernel per iteration): row sums by one wave per row, column
 // sums by row slices + a fixed-order finish (no floating-point atomics: the result is deterministic).
 #include "evrep_common.h"
@@ -39,7 +39,14 @@ template <> struct Mfma16<float> {
 };
 
 constexpr int kGwBM = 128, kGwBN = 128, kGwBK = 16;  // workgroup tile; 4 waves, each a 64 x 64 quadrant
-constexpr int kGwPad = 4;                            // LDS row padding (elements): breaks the power-of-two stride
+// LDS row padding (elements).  A fragment read takes 16 consecutive rows of k = lane >> 4 and of k + 1 in one 32-lane
+// group: with a pitch of 128 + 16 the two k rows land on disjoint halves of the banks for both element sizes
+// (float: pitch = 16 mod 32 words; double: 32 mod 64 words); 128 + 4 left them overlapping (2-way conflicts).
+constexpr int kGwPad = 16;
+// Leading dimension of the solver's own matrices: a row pitch that is a multiple of 512 bytes lets the 128 rows of
+// a GEMM tile fall on a few HBM channels (m = 14 400 doubles = 225 x 512 B: the K = 14 400 GEMM ran at 38 TFLOP/s
+// against 55 for the K = 12 500 one); such pitches get 64 bytes more.
+__host__ __device__ inline int gw_ld(int cols, size_t elem) { return ((size_t)cols * elem) % 512 == 0 ? cols + (int)(64 / elem) : cols; }
 
 enum GwEpilogue { GW_EPI_STORE = 0, GW_EPI_GIBBS = 1, GW_EPI_LOSS = 2 };
 
@@ -49,6 +56,7 @@ struct GwGemmArgs {
     const T *B;      // BT = false: [K][N] row-major;  BT = true: [N][K] row-major (the product uses B^T)
     T *C;            // [M][N] (STORE: A B;  GIBBS: exp(-2 (a_i + b_j - A B) / eps))
     int M, N, K;
+    int lda, ldb, ldc;    // leading dimensions (elements) of A, B and of C / Tplan, see gw_ld()
     const T *ai, *bj;     // constC = a_i + b_j (GIBBS, LOSS)
     const T *Tplan;       // [M][N] (LOSS: sum over the tile of (a_i + b_j - A B) * T)
     double inv_eps;       // GIBBS
@@ -61,43 +69,75 @@ __global__ __launch_bounds__(kThreads) void k_gw_gemm(GwGemmArgs<T> P) {
     using MF = Mfma16<T>;
     using acc_t = typename MF::acc_t;
     constexpr int LD = kGwBM + kGwPad;
-    __shared__ T As[2][kGwBK][LD];  // k-major: a fragment read is 16 consecutive rows of one k
-    __shared__ T Bs[2][kGwBK][LD];
+    __shared__ __align__(16) T As[2][kGwBK][LD];  // k-major: a fragment read is 16 consecutive rows of one k
+    __shared__ __align__(16) T Bs[2][kGwBK][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * kGwBM, n0 = blockIdx.x * kGwBN;
     const int M = P.M, N = P.N, K = P.K;
 
-    // global -> register staging of one K step.  Row-major operand with K contiguous (A always; B when BT): thread
-    // t takes row t / 2, k half t % 2 -> 8 consecutive k (one or two 16-byte runs).  [K][N] operand: thread t takes
-    // k = t / 16, columns (t % 16) * 8 .. + 8.
-    T ra[8], rb[8];
-    auto load_kcontig = [&](const T *X, int rows, int r0, int k0, T (&r)[8]) {
-        const int row = r0 + (tid >> 1), kk = k0 + (tid & 1) * 8;
-        const T *src = X + (size_t)row * K + kk;
+    // global -> register staging of one K step, 16 bytes per lane per load (VEC elements).  Operand with K
+    // contiguous (A always; B when BT): the 128 x 16 tile is 128 rows of 16 / VEC vectors, consecutive lanes take
+    // consecutive vectors of a row.  [K][N] operand: 16 k rows of 128 / VEC vectors, a wave reads whole rows.
+    // A vector that is not entirely inside the matrix, or operands whose pitch is not a multiple of VEC, take
+    // the element-wise path (zero fill).
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int NV = kGwBM * kGwBK / VEC / kThreads;  // vectors per thread and operand: 2 (float), 4 (double)
+    struct alignas(16) Vec { T e[VEC]; };
+    Vec ra[NV], rb[NV];
+    const bool a_vec = (P.lda % VEC) == 0, b_vec = (P.ldb % VEC) == 0;
+    auto load_kcontig = [&](const T *X, int ld, bool vec_ok, int rows, int r0, int k0, Vec (&r)[NV]) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = (row < rows && kk + q < K) ? src[q] : (T)0;
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * kThreads;
+            const int row = r0 + v / (kGwBK / VEC), kk = k0 + (v % (kGwBK / VEC)) * VEC;
+            const T *src = X + (size_t)row * ld + kk;
+            if (vec_ok && row < rows && kk + VEC <= K) {
+                r[i] = *reinterpret_cast<const Vec *>(src);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) r[i].e[q] = (row < rows && kk + q < K) ? src[q] : (T)0;
+            }
+        }
     };
-    auto load_ncontig = [&](const T *X, int k0, T (&r)[8]) {
-        const int k = k0 + (tid >> 4), col = n0 + (tid & 15) * 8;
-        const T *src = X + (size_t)k * N + col;
+    auto load_ncontig = [&](const T *X, int k0, Vec (&r)[NV]) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = (k < K && col + q < N) ? src[q] : (T)0;
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * kThreads;
+            const int k = k0 + v / (kGwBN / VEC), col = n0 + (v % (kGwBN / VEC)) * VEC;
+            const T *src = X + (size_t)k * P.ldb + col;
+            if (b_vec && k < K && col + VEC <= N) {
+                r[i] = *reinterpret_cast<const Vec *>(src);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) r[i].e[q] = (k < K && col + q < N) ? src[q] : (T)0;
+            }
+        }
+    };
+    auto stage_kcontig = [&](T (&S)[kGwBK][LD], const Vec (&r)[NV]) {   // transposing: S[k][row]
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * kThreads;
+            const int row = v / (kGwBK / VEC), kq = (v % (kGwBK / VEC)) * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) S[kq + q][row] = r[i].e[q];
+        }
     };
     auto stage = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) As[buf][(tid & 1) * 8 + q][tid >> 1] = ra[q];
+        stage_kcontig(As[buf], ra);
         if (BT) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) Bs[buf][(tid & 1) * 8 + q][tid >> 1] = rb[q];
+            stage_kcontig(Bs[buf], rb);
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) Bs[buf][tid >> 4][(tid & 15) * 8 + q] = rb[q];
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * kThreads;
+                *reinterpret_cast<Vec *>(&Bs[buf][v / (kGwBN / VEC)][(v % (kGwBN / VEC)) * VEC]) = rb[i];
+            }
         }
     };
     auto fetch = [&](int k0) {
-        load_kcontig(P.A, M, m0, k0, ra);
-        if (BT) load_kcontig(P.B, N, n0, k0, rb); else load_ncontig(P.B, k0, rb);
+        load_kcontig(P.A, P.lda, a_vec, M, m0, k0, ra);
+        if (BT) load_kcontig(P.B, P.ldb, b_vec, N, n0, k0, rb); else load_ncontig(P.B, k0, rb);
     };
 
     acc_t acc[4][4];
@@ -144,11 +184,11 @@ __global__ __launch_bounds__(kThreads) void k_gw_gemm(GwGemmArgs<T> P) {
                 if (row < M && col < N) {
                     const T v = acc[i][j][r];
                     if (EPI == GW_EPI_STORE) {
-                        P.C[(size_t)row * N + col] = v;
+                        P.C[(size_t)row * P.ldc + col] = v;
                     } else {
                         const double tens = ((double)P.ai[row] + (double)P.bj[col]) - (double)v;
-                        if (EPI == GW_EPI_GIBBS) P.C[(size_t)row * N + col] = (T)exp(-2.0 * tens * P.inv_eps);
-                        else lsum += tens * (double)P.Tplan[(size_t)row * N + col];
+                        if (EPI == GW_EPI_GIBBS) P.C[(size_t)row * P.ldc + col] = (T)exp(-2.0 * tens * P.inv_eps);
+                        else lsum += tens * (double)P.Tplan[(size_t)row * P.ldc + col];
                     }
                 }
             }
@@ -168,18 +208,21 @@ __device__ inline double gw_f1(double a, int loss) { return loss == 0 ? a * a : 
 __device__ inline double gw_f2(double b, int loss) { return loss == 0 ? b * b : b; }
 __device__ inline double gw_h2(double b, int loss) { return loss == 0 ? 2.0 * b : log(b + 1e-15); }
 
-// grid (rows), 64 threads: out_vec[i] = sum_k f(C[i][k]) w[k];  hC[i][k] = h(C[i][k]) (optional).
-// which = 1: (f1, h1 = identity, no hC written);  which = 2: (f2, h2).
+// grid (rows), 64 threads: out_vec[i] = sum_k f(C[i][k]) w[k];  hC = h(C).
+// which = 1: (f1, h1 = identity), hC[i][k];  which = 2: (f2, h2), stored TRANSPOSED, hC[k][i] = h2(C2[i][k]): the
+// second GEMM of the tensor product multiplies by h2(C2)^T, and with the transpose laid down once here both GEMMs
+// of every iteration read their B operand with N contiguous (135.7 -> ~94 ms for the K = 14 400 GEMM in float64).
 template <typename T>
 __global__ __launch_bounds__(kWave) void k_gw_init(const double *__restrict__ C, int n, const double *__restrict__ w, int loss,
-                                                  int which, T *__restrict__ hC, T *__restrict__ out_vec) {
+                                                  int which, T *__restrict__ hC, int ld, T *__restrict__ out_vec) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const double *row = C + (size_t)i * n;
     double s = 0.0;
     for (int k = lane; k < n; k += kWave) {
         const double c = row[k];
         s += (which == 1 ? gw_f1(c, loss) : gw_f2(c, loss)) * w[k];
-        hC[(size_t)i * n + k] = (T)(which == 1 ? c : gw_h2(c, loss));
+        if (which == 1) hC[(size_t)i * ld + k] = (T)c;
+        else hC[(size_t)k * ld + i] = (T)gw_h2(c, loss);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -188,9 +231,9 @@ __global__ __launch_bounds__(kWave) void k_gw_init(const double *__restrict__ C,
 
 // T = p q^T;  u = 1/n, v = 1/m are (re)set per Sinkhorn call by k_gw_fill.
 template <typename T>
-__global__ void k_gw_outer(const double *__restrict__ p, const double *__restrict__ q, int n, int m, T *__restrict__ Tp) {
+__global__ void k_gw_outer(const double *__restrict__ p, const double *__restrict__ q, int n, int m, int ld, T *__restrict__ Tp) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (size_t)n * m) Tp[e] = (T)(p[e / m] * q[e % m]);
+    if (e < (size_t)n * m) Tp[(e / m) * ld + e % m] = (T)(p[e / m] * q[e % m]);
 }
 __global__ void k_gw_fill(double *__restrict__ x, int n, double v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +245,7 @@ constexpr int kGwSlices = 64;  // row slices of the column-sum pass
 // grid (ceil(m / 256), kGwSlices), 256 threads: part[s][j] = sum over the slice's rows of K[i][j] u[i]
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_gw_colsum(const T *__restrict__ Km, const double *__restrict__ u, int n, int m,
-                                                       double *__restrict__ part) {
+                                                       int ld, double *__restrict__ part) {
     const int j = blockIdx.x * kThreads + threadIdx.x;
     const int per = (n + kGwSlices - 1) / kGwSlices;
     const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
@@ -210,12 +253,12 @@ __global__ __launch_bounds__(kThreads) void k_gw_colsum(const T *__restrict__ Km
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains: the loads pipeline; fixed order -> deterministic
     int i = i0;
     for (; i + 3 < i1; i += 4) {
-        s0 += (double)Km[(size_t)i * m + j] * u[i];
-        s1 += (double)Km[(size_t)(i + 1) * m + j] * u[i + 1];
-        s2 += (double)Km[(size_t)(i + 2) * m + j] * u[i + 2];
-        s3 += (double)Km[(size_t)(i + 3) * m + j] * u[i + 3];
+        s0 += (double)Km[(size_t)i * ld + j] * u[i];
+        s1 += (double)Km[(size_t)(i + 1) * ld + j] * u[i + 1];
+        s2 += (double)Km[(size_t)(i + 2) * ld + j] * u[i + 2];
+        s3 += (double)Km[(size_t)(i + 3) * ld + j] * u[i + 3];
     }
-    for (; i < i1; ++i) s0 += (double)Km[(size_t)i * m + j] * u[i];
+    for (; i < i1; ++i) s0 += (double)Km[(size_t)i * ld + j] * u[i];
     part[(size_t)blockIdx.y * m + j] = (s0 + s1) + (s2 + s3);
 }
 __global__ void k_gw_col_finish(const double *__restrict__ part, const double *__restrict__ q, int m, double *__restrict__ v) {
@@ -228,9 +271,9 @@ __global__ void k_gw_col_finish(const double *__restrict__ part, const double *_
 // grid (n), 64 threads: u[i] = p[i] / sum_j K[i][j] v[j]
 template <typename T>
 __global__ __launch_bounds__(kWave) void k_gw_rowdot(const T *__restrict__ Km, const double *__restrict__ v, const double *__restrict__ p,
-                                                    int m, double *__restrict__ u) {
+                                                    int m, int ld, double *__restrict__ u) {
     const int i = blockIdx.x, lane = threadIdx.x;
-    const T *row = Km + (size_t)i * m;
+    const T *row = Km + (size_t)i * ld;
     double s = 0.0;
     for (int j = lane; j < m; j += kWave) s += (double)row[j] * v[j];
 #pragma unroll
@@ -240,15 +283,40 @@ __global__ __launch_bounds__(kWave) void k_gw_rowdot(const T *__restrict__ Km, c
 // T = diag(u) K diag(v)
 template <typename T>
 __global__ void k_gw_plan(const T *__restrict__ Km, const double *__restrict__ u, const double *__restrict__ v, int n, int m,
-                          T *__restrict__ Tp) {
+                          int ld, T *__restrict__ Tp) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (size_t)n * m) Tp[e] = (T)(u[e / m] * (double)Km[e] * v[e % m]);
+    if (e < (size_t)n * m) { const size_t a = (e / m) * ld + e % m; Tp[a] = (T)(u[e / m] * (double)Km[a] * v[e % m]); }
+}
+// The tensor product's epilogues as their own streaming passes: folding exp() / the loss product into the GEMM's
+// epilogue cost its main loop an occupancy step (128 accumulator registers + the float64 exp's temporaries: 186
+// VGPRs, one workgroup per CU, 145 ms instead of 97 ms for the K = 14 400 GEMM), while one more pass over the
+// 1.44 GB product costs 0.6 ms.
+// K = exp(-2 (a_i + b_j - X) / eps), in place
+template <typename T>
+__global__ void k_gw_gibbs(T *__restrict__ X, const T *__restrict__ ai, const T *__restrict__ bj, int n, int m, int ld, double inv_eps) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * m) return;
+    const size_t a = (e / m) * ld + e % m;
+    const double tens = ((double)ai[e / m] + (double)bj[e % m]) - (double)X[a];
+    X[a] = (T)exp(-2.0 * tens * inv_eps);
+}
+// grid (n), 64 threads: rowpart[i] = sum_j (a_i + b_j - X[i][j]) * T[i][j]   (fixed order: deterministic)
+template <typename T>
+__global__ __launch_bounds__(kWave) void k_gw_lossrows(const T *__restrict__ X, const T *__restrict__ Tp, const T *__restrict__ ai,
+                                                      const T *__restrict__ bj, int m, int ld, double *__restrict__ rowpart) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double a = (double)ai[i];
+    double s = 0.0;
+    for (int j = lane; j < m; j += kWave) s += ((a + (double)bj[j]) - (double)X[(size_t)i * ld + j]) * (double)Tp[(size_t)i * ld + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) rowpart[i] = s;
 }
 // out_T (float64) = T;  gw = sum of the loss partials
 template <typename T>
-__global__ void k_gw_export(const T *__restrict__ Tp, size_t count, double *__restrict__ out) {
+__global__ void k_gw_export(const T *__restrict__ Tp, int n, int m, int ld, double *__restrict__ out) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < count) out[e] = (double)Tp[e];
+    if (e < (size_t)n * m) out[e] = (double)Tp[(e / m) * ld + e % m];
 }
 __global__ __launch_bounds__(kThreads) void k_gw_loss_finish(const double *__restrict__ partial, int count, double *__restrict__ gw) {
     __shared__ double red[kThreads];
