@@ -89,12 +89,12 @@ def cpu_baseline(events_per_window, budget_s=12.0, threads_budget_s=6.0):
     if ncpu > 1 and threads_budget_s > 0:
         def work(k):
             n = 0
-            while time.perf_counter() < deadline:              # wall-clock bounded whatever the scaling is
-                oracle.ergo12(wins[(k + n) % len(wins)], H, W)   # ctypes releases the GIL
+            buf = np.empty((H, W, C), dtype=np.float64)        # one result buffer per thread, reused: first-touching a
+            while time.perf_counter() < deadline:              # fresh 29.5 MB array per window would benchmark page faults
+                oracle.ergo12(wins[(k + n) % len(wins)], H, W, out=buf)   # ctypes releases the GIL
                 n += 1
             return n
-        # every window allocates and first-touches a fresh 29.5 MB result (as the reference does), so the
-        # scaling over threads is set by the host's page-fault path; report the best of a few thread counts
+        # wall-clock bounded whatever the scaling is; report the best of a few thread counts
         tried = []
         counts = sorted({min(ncpu, 8), min(ncpu, 32), ncpu})
         for nt in counts:

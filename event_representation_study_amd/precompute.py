@@ -18,6 +18,8 @@ windows share one GPU and the CPU only drains buffers to disk.  As in the refere
 the representation's long side already equals S (``if r != 1``, :228), and TORE is built on the events' bounding
 box per sample (gen4_transforms' branch), so its samples are resized one by one.
 """
+import collections
+import concurrent.futures
 import os
 import queue
 import threading
@@ -35,7 +37,7 @@ BUILDERS = ("optimized", "event_stack", "time_surface", "tore", "voxel_grid")
 
 class RepPrecomputer:
     def __init__(self, height, width, out_size=640, builder="optimized", device="cuda:0", writers=4, container="h5",
-                 augment=False):
+                 augment=False, loaders=3):
         if builder not in BUILDERS:
             raise ValueError("builder must be one of %r" % (BUILDERS,))
         if container not in ("h5", "npy"):
@@ -48,6 +50,8 @@ class RepPrecomputer:
         self.container = container
         self.augment = bool(augment)
         self._ring, self._ring_pos = {}, {}
+        self.nloaders = int(loaders)
+        self._in_ring, self._in_lock = [], threading.Lock()
 
     # ------------------------------------------------------------------------------------------ GPU side
     def _build(self, batch):
@@ -68,7 +72,9 @@ class RepPrecomputer:
 
     def represent(self, wins):
         """windows -> (B, S, S, C) float32 on the GPU (or (B, H, W, C) when no resize applies)."""
-        batch = EventBatch.from_numpy(wins, self.H, self.W, device=self.device)
+        return self.represent_batch(EventBatch.from_numpy(wins, self.H, self.W, device=self.device))
+
+    def represent_batch(self, batch):
         rep = self._build(batch)
         if isinstance(rep, list):                                  # TORE: its own frame per sample
             outs = []
@@ -131,22 +137,45 @@ class RepPrecomputer:
             t.start()
         t0 = time.perf_counter()
         count = first_index
-        for wins in window_batches:
-            small = self.represent(wins)
-            parts = small if isinstance(small, list) else [small]
-            hosts = []
-            done = torch.cuda.Event()
-            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.copy_stream):
-                for part in parts:
-                    host = self._pinned(tuple(part.shape))
-                    host.copy_(part, non_blocking=True)
-                    part.record_stream(self.copy_stream)
-                    hosts.append(host)
-                done.record(self.copy_stream)
-            host_list = hosts[0] if not isinstance(small, list) else hosts
-            q.put((count, host_list, done))
-            count += len(wins)
+        # loader stage: a few threads turn the next batches (lists of arrays, or callables that read them) into one
+        # pinned (total, 4) int32 buffer + offsets while the GPU works on the current one; numpy's copies and the
+        # file reads release the GIL.  The main thread only enqueues: H2D, bin, build, resize, D2H.
+        main = torch.cuda.current_stream(self.device)
+        it = iter(window_batches)
+        pending = collections.deque()
+        with concurrent.futures.ThreadPoolExecutor(self.nloaders) as ex:
+            def submit_next():
+                try:
+                    item = next(it)
+                except StopIteration:
+                    return
+                pending.append(ex.submit(self._load, item))
+            for _ in range(self.nloaders + 1):
+                submit_next()
+            while pending:
+                slot, total, offs, nwin, nmax = pending.popleft().result()
+                submit_next()
+                ev_dev = torch.empty((total, 4), dtype=torch.int32, device=self.device)
+                ev_dev.copy_(slot["buf"][:total], non_blocking=True)
+                slot["free"] = torch.cuda.Event()
+                slot["free"].record(main)                              # the loader may refill the buffer after this
+                slot["busy"] = False
+                batch = EventBatch(ev_dev, torch.from_numpy(offs), self.H, self.W, max_events_per_window=nmax)
+                small = self.represent_batch(batch)
+                parts = small if isinstance(small, list) else [small]
+                hosts = []
+                done = torch.cuda.Event()
+                self.copy_stream.wait_stream(main)
+                with torch.cuda.stream(self.copy_stream):
+                    for part in parts:
+                        host = self._pinned(tuple(part.shape))
+                        host.copy_(part, non_blocking=True)
+                        part.record_stream(self.copy_stream)
+                        hosts.append(host)
+                    done.record(self.copy_stream)
+                host_list = hosts[0] if not isinstance(small, list) else hosts
+                q.put((count, host_list, done))
+                count += nwin
         for _ in threads:
             q.put(None)
         for t in threads:
@@ -155,20 +184,46 @@ class RepPrecomputer:
             raise errors[0]
         return count - first_index, sum(written), time.perf_counter() - t0
 
+    def _load(self, item):
+        """Loader thread: windows -> one pinned (total, 4) int32 buffer (recycled) + int64 offsets."""
+        wins = item() if callable(item) else item
+        ws = [np.ascontiguousarray(w, dtype=np.int32).reshape(-1, 4) for w in wins]
+        offs = np.zeros(len(ws) + 1, dtype=np.int64)
+        np.cumsum([w.shape[0] for w in ws], out=offs[1:])
+        total = int(offs[-1])
+        with self._in_lock:
+            slot = None
+            for s in self._in_ring:
+                if not s["busy"] and s["cap"] >= total:
+                    slot = s
+                    break
+            if slot is None:
+                cap = max(total, 1)
+                slot = {"buf": torch.empty((cap, 4), dtype=torch.int32, pin_memory=True), "cap": cap, "busy": False, "free": None}
+                self._in_ring.append(slot)
+            slot["busy"] = True
+        if slot["free"] is not None:
+            slot["free"].synchronize()                             # its previous H2D has been consumed
+        dst = slot["buf"].numpy()
+        for w, o in zip(ws, offs[:-1]):
+            dst[o:o + w.shape[0]] = w
+        return slot, total, offs, len(ws), int(max([w.shape[0] for w in ws], default=0))
+
     def run_h5(self, event_h5_file, keys, out_dir, batch=8, **kw):
         """The reference's input side: every ``key`` of ``event_h5_file`` is a flat (n, 4) int32 [x, y, t, p] dataset
         (precompute_reps.py:408-409 reads it with np.array(hf.get(key)); fix_events_training views it as '<i4'
         fields, :737-740).  Samples are numbered in key order."""
         f = h5lite.File(event_h5_file)
 
-        def batches():
-            for i in range(0, len(keys), batch):
+        def read(ks):
+            def go():
                 wins = []
-                for k in keys[i:i + batch]:
+                for k in ks:
                     ev = np.asarray(f[k])
                     if ev.ndim != 2 or ev.shape[1] != 4 or ev.dtype.itemsize != 4 or ev.dtype.kind not in "iu":
                         raise ValueError("%s[%r]: expected an (n, 4) int32 event array, got %s %s"
                                          % (event_h5_file, k, ev.shape, ev.dtype))
                     wins.append(np.ascontiguousarray(ev.view(np.int32)))
-                yield wins
-        return self.run(batches(), out_dir, **kw)
+                return wins
+            return go
+        return self.run((read(keys[i:i + batch]) for i in range(0, len(keys), batch)), out_dir, **kw)

@@ -85,10 +85,12 @@ def mdes(ev, H, W, windows, funcs, aggs):
     return out
 
 
-def ergo12(ev, H, W):
-    """get_optimized_representation -> (H, W, 12) float64."""
+def ergo12(ev, H, W, out=None):
+    """get_optimized_representation -> (H, W, 12) float64.  `out`: optional result buffer to reuse (the threaded
+    CPU baseline of bench.py: a fresh 29.5 MB array per window makes the host's page-fault path the benchmark)."""
     ev = _ev(ev)
-    out = np.empty((H, W, 12), dtype=np.float64)
+    if out is None:
+        out = np.empty((H, W, 12), dtype=np.float64)
     _chk(lib().oracle_ergo12(_p(ev), ctypes.c_int64(ev.shape[0]), H, W, _p(out)))
     return out
 

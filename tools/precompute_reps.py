@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--container", default="h5", choices=["h5", "npy"])
     ap.add_argument("--writers", type=int, default=16)
+    ap.add_argument("--loaders", type=int, default=3)
     args = ap.parse_args()
     H, W = 720, 1280
     pool = [make_events(args.events, W, H, seed=9000 + i) for i in range(args.batch)]   # reused: generation is not the subject
     batches = ([pool[i % args.batch] for i in range(args.batch)] for _ in range(args.samples // args.batch))
-    pc = RepPrecomputer(H, W, 640, args.builder, container=args.container, writers=args.writers)
+    pc = RepPrecomputer(H, W, 640, args.builder, container=args.container, writers=args.writers, loaders=args.loaders)
     pc.run([pool], args.out, keep_files=False)                                           # warm-up
     n, nbytes, el = pc.run(batches, args.out, keep_files=args.keep)
     if not args.keep:
