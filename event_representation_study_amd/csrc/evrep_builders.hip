@@ -976,4 +976,66 @@ __global__ __launch_bounds__(kThreads) void k_resize_taps(const InT *__restrict_
     out[(size_t)b * per + e] = (OutT)(acc * scale);
 }
 
+// --------------------------------------------------------------------------------------------
+// F3: ev-licious events_to_voxel_grid with SUB-PIXEL coordinates (Events.divider > 1, e.g. after
+// resize_to_resolution; ev-licious/src/evlicious/tools/utils.py:86-102): every event is drawn into the four
+// pixels around (x, y) with weight (1 - |xlim - x|)(1 - |ylim - y|) p, accumulated in a float32 grid by np.add.at.
+// The stream is binned by the TRUNCATED coordinates; one thread per output cell (Y, X) gathers, in the reference's
+// accumulation order, the events of pixels (X, Y), (X, Y-1), (X-1, Y), (X-1, Y-1) -- the (xlim, ylim) loop nest of
+// _draw_xy_to_voxel_grid, events in time order inside each tap -- so the float32 sums round exactly as the
+// reference's.  xy[rank] = the event's float64 (x, y), gathered by the record's rank.  A gather kernel, not a
+// tile builder: this path serves resized event streams, not the headline windows.
+// grid (ceil(H*W / 256), B), 256 threads; out DEVICE float32 (B, H, W, bins).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
+                                                            const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
+                                                            const double *__restrict__ xy, int H, int W, int nchunk, int bins,
+                                                            const int64_t *__restrict__ t_range, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * kThreads + threadIdx.x;
+    if (cell >= H * W) return;
+    const int Y = cell / W, X = cell - Y * W;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    float acc[EVREP_MAX_CHANNELS];
+#pragma unroll
+    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) acc[c] = 0.0f;
+    if (n_win >= 2) {  // `if len(events) < 2: return voxel_grid` (:58-59)
+        int64_t t0 = ev[beg].z, t1 = ev[beg + n_win - 1].z;
+        if (t_range) { t0 = t_range[2 * b]; t1 = t_range[2 * b + 1]; }
+        const double den = (t1 - t0) == 0 ? 1.0 : (double)(t1 - t0);
+        for (int tap = 0; tap < 4; ++tap) {
+            const int px = X - (tap >> 1), py = Y - (tap & 1);  // the source pixel whose (xlim, ylim) tap is this cell
+            if (px < 0 || py < 0) continue;
+            const uint32_t *co = chunk_off + ((size_t)b * H + py) * (nchunk + 1);
+            uint32_t lo = co[px / kChunkPx], hi = co[px / kChunkPx + 1];
+            const int key = py * W + px;
+            const uint32_t end = hi;
+            while (lo < hi) {  // first record of the chunk with pixel id >= key
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sorted[mid].x < key) lo = mid + 1; else hi = mid;
+            }
+            for (uint32_t j = lo; j < end; ++j) {
+                const Rec e = sorted[j];
+                if (e.x != key) break;
+                const int64_t num = (int64_t)(bins - 1) * ((int64_t)e.z - t0);
+                const double bpos = (double)num / den;
+                if (!(bpos > -1.0 && bpos < 1.0e9)) continue;
+                const int bi = (int)bpos;  // astype("int32"): toward zero (:67)
+                if (bi < 0 || bi >= bins) continue;
+                const double x = xy[2 * (beg + e.y)], y = xy[2 * (beg + e.y) + 1];
+                const double w = (1.0 - fabs((double)X - x)) * (1.0 - fabs((double)Y - y));
+                // np.add.at(float32 grid, ..., float64 values) runs numpy's float64 add loop and rounds the SUM back to
+                // float32: one rounding per addition, of the exact float64 sum
+                const double val = w * (double)e.w;
+#pragma unroll
+                for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c == bi) acc[c] = (float)((double)acc[c] + val);
+            }
+        }
+    }
+    float *dst = out + ((size_t)b * H * W + cell) * bins;
+#pragma unroll
+    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c < bins) dst[c] = acc[c];
+}
+
 }  // namespace evrep

@@ -361,6 +361,20 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     return EVREP_OK;
 }
 
+int evrep_voxel_subpixel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                         const double *xy, int32_t bins, const int64_t *t_range, float *out, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (bins <= 0 || bins > EVREP_MAX_CHANNELS || !out || (plan->total_events > 0 && !xy)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid((unsigned)(((size_t)plan->H * plan->W + kThreads - 1) / kThreads), (unsigned)plan->B);
+    k_voxel_subpixel<<<grid, kThreads, 0, stream>>>(reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2),
+                                                   CWS(uint32_t, off_chunkoff), offsets, xy, plan->H, plan->W, plan->nchunk,
+                                                   bins, t_range, out);
+    LAUNCH_CHECK("k_voxel_subpixel");
+    return EVREP_OK;
+}
+
 int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                    const double *tnorm, int32_t C, const int32_t *pol, const int32_t *stat, double tau, float *out,
                    void *stream_) {

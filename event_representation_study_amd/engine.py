@@ -228,6 +228,24 @@ class EventBatch:
                                              _stream_ptr()), "evrep_voxel_range")
         return out
 
+    def voxel_subpixel(self, xy, bins=5, t_range=None, out=None):
+        """ev-licious events_to_voxel_grid for sub-pixel coordinates -> (B, H, W, bins) float32.  The batch holds the
+        truncated coordinates; xy: (total, 2) float64 device tensor with every event's original (x, y)."""
+        self.bin()
+        if xy.dtype != torch.float64 or xy.device != self.device or tuple(xy.shape) != (self.total, 2) or not xy.is_contiguous():
+            raise ValueError("xy must be a contiguous (total, 2) float64 tensor on %s" % self.device)
+        out = self._out(out, bins, torch.float32)
+        rptr, keep = ctypes.c_void_p(None), None
+        if t_range is not None:
+            keep = torch.as_tensor(np.asarray(t_range, dtype=np.int64)).reshape(-1).to(self.device)
+            if keep.numel() != 2 * self.B:
+                raise ValueError("t_range must hold (t0, t1) for each of the %d windows" % self.B)
+            rptr = _ptr(keep)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_voxel_subpixel(*self._args(), _ptr(xy), int(bins), rptr, _ptr(out), _stream_ptr()),
+                  "evrep_voxel_subpixel")
+        return out
+
     def polstats(self, tnorm, pol, stat, tau=0.3, out=None):
         """n_imagenet's per-polarity accumulators (imagenet.py:169-511): channel c = stat[c] over the events of
         polarity class pol[c] at each pixel.  tnorm: float64 device tensor, one normalised time per event."""

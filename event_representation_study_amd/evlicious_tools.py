@@ -1,9 +1,10 @@
 """events_to_voxel_grid -- mirrors ev-licious/src/evlicious/tools/utils.py:52-108.
 
 Only the numpy variant is a parity target (the reference's ``_cuda`` variant uses ``put_`` without
-accumulate and is undefined for repeated coordinates).  Integer pixel coordinates only
-(``Events.divider == 1``); the bilinear-in-x/y path for sub-pixel coordinates is not implemented.  The optional
-``t0_us`` / ``t1_us`` range (:60-63) is honoured (``evrep_voxel_range``).
+accumulate and is undefined for repeated coordinates).  uint16 pixel coordinates
+(``Events.divider == 1``) run the integer builder (``evrep_voxel`` mode 2); any other coordinate dtype -- sub-pixel
+positions after ``resize_to_resolution`` -- takes the reference's bilinear-in-x/y draw (``evrep_voxel_subpixel``, float32
+accumulation in the reference's tap order).  The optional ``t0_us`` / ``t1_us`` range (:60-63) is honoured.
 """
 import numpy as np
 import torch
@@ -22,11 +23,10 @@ def events_to_voxel_grid(events, num_bins, normalize=True, t0_us=None, t1_us=Non
     grid = np.zeros((num_bins, H, W), np.float32)
     if n < 2:
         return grid
-    x = np.asarray(events.x)
-    if x.dtype.kind == "f":
-        raise NotImplementedError("sub-pixel coordinates (divider > 1) are not supported")
+    x, y = np.asarray(events.x), np.asarray(events.y)
+    subpixel = x.dtype != np.uint16                    # utils.py:87-89: only uint16 coordinates take the integer path
     ev = np.empty((n, 4), np.int32)
-    ev[:, 0], ev[:, 1] = x, np.asarray(events.y)
+    ev[:, 0], ev[:, 1] = x.astype("int32"), y.astype("int32")   # x_int, y_int (:92-93): truncation
     t = np.asarray(events.t).astype(np.int64)
     base = int(t[0])
     ev[:, 2] = int64_to_int32(t - base, "t")          # the kernel only uses time differences
@@ -39,12 +39,15 @@ def events_to_voxel_grid(events, num_bins, normalize=True, t0_us=None, t1_us=Non
         t_range = [[t0 - base, t1 - base]]
     if int(batch.status()[0]) & 2:
         raise AssertionError("event coordinates outside the sensor")     # Events.__init__ asserts this
-    out = None
-    for b0 in range(0, num_bins, 16):                  # 16 bins per launch would need bin offsets; keep it simple
-        if num_bins > 16:
-            raise NotImplementedError("num_bins > 16")
-        out = batch.voxel(bins=num_bins, mode=2, t_range=t_range)[0]
-    g = out.permute(2, 0, 1).to(torch.float32)
+    if num_bins > 16:
+        raise NotImplementedError("num_bins > 16")
+    if subpixel:
+        # the bilinear draw into the four surrounding pixels (:95-98); integer-valued non-uint16 coordinates take
+        # this path too, as in the reference (their second taps weigh exactly zero)
+        xy = torch.from_numpy(np.stack([x.astype(np.float64), y.astype(np.float64)], axis=1)).to(batch.device)
+        g = batch.voxel_subpixel(xy, bins=num_bins, t_range=t_range)[0].permute(2, 0, 1)
+    else:
+        g = batch.voxel(bins=num_bins, mode=2, t_range=t_range)[0].permute(2, 0, 1).to(torch.float32)
     if normalize:
         nz = g != 0
         if bool(nz.any()):

@@ -137,6 +137,14 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
 int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                       int32_t bins, int32_t mode, double scale, const int64_t *t_range, double *out, void *stream);
 
+/* ev-licious events_to_voxel_grid for SUB-PIXEL event coordinates (Events.divider > 1; utils.py:86-102): the
+ * bilinear-in-x/y draw of every event into its four surrounding pixels, float32 accumulation in the reference's
+ * order.  `events` carries the TRUNCATED coordinates (x.astype("int32"), :92-93), xy DEVICE double [total,2] the
+ * original (x, y) of every event (indexed like `events`); t_range as evrep_voxel_range.
+ * out DEVICE float32 (B,H,W,bins), before the optional normalisation. */
+int evrep_voxel_subpixel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                         const double *xy, int32_t bins, const int64_t *t_range, float *out, void *stream);
+
 /* n_imagenet's per-polarity accumulators (n_imagenet/real_cnn_model/data/imagenet.py:169-511,841-871:
  * reshape_then_acc, _acc_time, _acc_count, _acc_count_pol, _acc_count_only, _acc_all, _flat, _flat_pol,
  * _acc_exp, _acc_time_pol, _acc_intensity) as ONE builder: channel c = stat[c] of the events of polarity

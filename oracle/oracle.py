@@ -169,6 +169,40 @@ def evl_voxel(ev, H, W, bins, t0_us=None, t1_us=None):
     return out
 
 
+def evl_voxel_subpixel(x, y, t, p, H, W, bins, t0_us=None, t1_us=None):
+    """ev-licious events_to_voxel_grid(normalize=False) for non-uint16 (sub-pixel) coordinates
+    (ev-licious/src/evlicious/tools/utils.py:52-108): per time-bin pass, per (xlim, ylim) tap, np.add.at into a
+    float32 grid -- restated with explicit loops in the same order.  Small inputs only."""
+    x, y = np.asarray(x), np.asarray(y)
+    t, p = np.asarray(t).astype(np.int64), np.asarray(p)
+    grid = np.zeros((bins, H, W), np.float32)
+    if len(x) < 2:
+        return grid
+    t0 = t0_us if t0_us is not None else t[0]
+    t1 = t1_us if t1_us is not None else t[-1]
+    dT = t1 - t0
+    if dT == 0:
+        dT = 1.0
+    tn = (bins - 1) * (t - t0) / dT
+    ti = tn.astype("int32")
+    xi, yi = x.astype("int32"), y.astype("int32")
+    for dt_ in (0, 1):
+        tl = ti + dt_
+        wt = (1 - np.abs(tl - ti)) * p
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for k in range(len(x)):
+                    if not (0 <= tl[k] < bins):
+                        continue
+                    X, Y = xi[k] + dx, yi[k] + dy
+                    if X < 0 or Y < 0 or X >= W or Y >= H:
+                        continue
+                    w = (1 - np.abs(X - x[k])) * (1 - np.abs(Y - y[k]))
+                    # np.add.at(float32 grid, ..., float64 values) runs the float64 add loop and rounds the sum back
+                    grid[tl[k], Y, X] = np.float32(np.float64(grid[tl[k], Y, X]) + np.float64(w * wt[k]))
+    return grid
+
+
 def gwd(Xs, Xt, h=0.7):
     """OTMI(Xs, Xt, h).solve()[1] in closed form (PARITY UNPINNED for POT's part)."""
     Xs = np.ascontiguousarray(Xs, dtype=np.float64)

@@ -14,6 +14,7 @@ third-party packages) and stores inputs and outputs only -> ``boundary.npz``.
 * ``future_*`` -- EventStack.pre_stack with last_timestamp inside the window: the "future" half
   (event_stack.py:28-41) and post_stack's reversed level axis (:64-65).
 * ``evl_*``    -- ev-licious events_to_voxel_grid with explicit t0_us / t1_us (tools/utils.py:60-63).
+* ``sp_*``     -- the same function on sub-pixel (float) coordinates: the bilinear-in-x/y draw (:86-102).
 """
 import importlib.util
 import os
@@ -107,6 +108,27 @@ def main():
             out["evl_raw5_%d" % k] = evl_utils.events_to_voxel_grid(e, 5, normalize=False, t0_us=t0, t1_us=t1)
         out["evl_norm5_0"] = evl_utils.events_to_voxel_grid(e, 5, normalize=True, t0_us=ranges[0][0], t1_us=ranges[0][1])
         out["evl_raw5_t0only"] = evl_utils.events_to_voxel_grid(e, 5, normalize=False, t0_us=1_010_000)
+        # sub-pixel coordinates (divider > 1): the bilinear-in-x/y draw (:86-102), float32 and float64 positions
+        for tag, Ws, Hs, Ns, seed, dt in (("sp_a", 80, 60, 6000, 731, np.float32), ("sp_b", 40, 30, 9000, 732, np.float64)):
+            evs = make_events(Ns, Ws, Hs, seed=seed)
+            r2 = np.random.default_rng(seed)
+            s_ = _Events()
+            s_.x = (evs[:, 0] + r2.random(Ns) * 0.999).astype(dt)
+            s_.y = (evs[:, 1] + r2.random(Ns) * 0.999).astype(dt)
+            s_.t, s_.p = evs[:, 2].astype(np.int64), evs[:, 3].astype(np.int8)
+            s_.width, s_.height = Ws, Hs
+            out[tag + "_x"], out[tag + "_y"], out[tag + "_t"], out[tag + "_p"] = s_.x, s_.y, s_.t, s_.p
+            out[tag + "_W"], out[tag + "_H"] = Ws, Hs
+            out[tag + "_raw5"] = evl_utils.events_to_voxel_grid(s_, 5, normalize=False)
+            out[tag + "_norm5"] = evl_utils.events_to_voxel_grid(s_, 5, normalize=True)
+            out[tag + "_raw3_range"] = evl_utils.events_to_voxel_grid(s_, 3, normalize=False, t0_us=5000, t1_us=40000)
+        # integer-valued coordinates in a non-uint16 dtype go through the same bilinear path
+        s_ = _Events()
+        evs = make_events(3000, 80, 60, seed=733)
+        s_.x, s_.y, s_.t, s_.p = evs[:, 0].astype(np.int32), evs[:, 1].astype(np.int32), evs[:, 2].astype(np.int64), evs[:, 3].astype(np.int8)
+        s_.width, s_.height = 80, 60
+        out["sp_int_events"] = evs
+        out["sp_int_raw5"] = evl_utils.events_to_voxel_grid(s_, 5, normalize=False)
     np.savez_compressed(os.path.join(HERE, "boundary.npz"), **out)
     print("wrote boundary.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 

@@ -274,6 +274,31 @@ def test_evlicious_voxel_grid():
     np.testing.assert_allclose(got, g["evl_norm5_0"], rtol=1e-5, atol=1e-6)
 
 
+def test_evlicious_voxel_grid_subpixel():
+    """ev-licious events_to_voxel_grid on sub-pixel coordinates (Events.divider > 1): bit-exact against the
+    reference's own float32 grids (goldens), float32 and float64 positions, explicit time range, and integer-valued
+    coordinates in a non-uint16 dtype (which take the bilinear path in the reference too)."""
+    from event_representation_study_amd.evlicious_tools import events_to_voxel_grid
+    g = load_golden("boundary")
+
+    class Events:
+        pass
+
+    for tag in ("sp_a", "sp_b"):
+        e = Events()
+        e.x, e.y, e.t, e.p = g[tag + "_x"], g[tag + "_y"], g[tag + "_t"], g[tag + "_p"]
+        e.width, e.height = int(g[tag + "_W"]), int(g[tag + "_H"])
+        assert_bit_equal(events_to_voxel_grid(e, 5, normalize=False), g[tag + "_raw5"], tag + " raw5")
+        assert_bit_equal(events_to_voxel_grid(e, 3, normalize=False, t0_us=5000, t1_us=40000), g[tag + "_raw3_range"], tag + " range")
+        got = events_to_voxel_grid(e, 5, normalize=True)
+        np.testing.assert_allclose(got, g[tag + "_norm5"], rtol=1e-5, atol=1e-6)
+    ev = g["sp_int_events"]
+    e = Events()
+    e.x, e.y, e.t, e.p = ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), ev[:, 2].astype(np.int64), ev[:, 3].astype(np.int8)
+    e.width, e.height = 80, 60
+    assert_bit_equal(events_to_voxel_grid(e, 5, normalize=False), g["sp_int_raw5"], "int32 coordinates")
+
+
 def test_gwd_caller_pipeline_f1():
     """keep-ratio area resize + letterbox(114) + otmi -> C_p (resize restated from
     OpenCV's published algorithm; parity unpinned: cv2 is absent)."""
