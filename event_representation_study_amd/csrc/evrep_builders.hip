@@ -643,6 +643,7 @@ constexpr int kMaxToreK = 8;
 __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
                                                const WindowMeta *__restrict__ meta, const int32_t *__restrict__ sample_times,
+                                               const double *__restrict__ tf, const double *__restrict__ sample_times_f,
                                                int H, int W, int nchunk, int span, int K, int frame_mode, float scale,
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -665,6 +666,10 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     const int npix = min(span * kChunkPx, Wf - oc0);
     const int row = orow + y0;  // sensor row feeding this output row
     const int T = empty ? 0 : (sample_times ? sample_times[b] : ev[beg + n_win - 1].z);
+    // float64 timestamps (n_imagenet hands seconds as floats, imagenet.py:1002-1006,1093-1103): the time of a record
+    // is gathered by its rank from the caller's array, the sample time is a float64 too, and the FIFOs hold RANKS
+    const double *tw = tf ? tf + beg : nullptr;
+    const double Td = (tf && !empty) ? (sample_times_f ? sample_times_f[b] : tw[n_win - 1]) : 0.0;
     // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
     uint32_t cs = 0, ce = 0;
     const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
@@ -689,15 +694,17 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
         for (int q = 0; q < kMaxToreK; ++q) { fp[q] = 0; fn[q] = 0; }
         for (uint32_t j = jb; j < je; ++j) {
             const Rec e = get(j);
-            if (!(e.z < T)) continue;  // ts < currentSampleTime (tore.py:17): events at T are dropped
+            // ts < currentSampleTime (tore.py:17): events at T are dropped
+            if (tw ? !(tw[e.y] < Td) : !(e.z < T)) continue;
+            const int held = tw ? e.y : e.z;
             if (e.w > 0) {
 #pragma unroll
                 for (int q = kMaxToreK - 1; q > 0; --q) fp[q] = fp[q - 1];
-                fp[0] = e.z; ++np_;
+                fp[0] = held; ++np_;
             } else {
 #pragma unroll
                 for (int q = kMaxToreK - 1; q > 0; --q) fn[q] = fn[q - 1];
-                fn[0] = e.z; ++nn_;
+                fn[0] = held; ++nn_;
             }
         }
 #pragma unroll
@@ -706,12 +713,12 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
         for (int q = 0; q < kMaxToreK; ++q) {
             float vp = bgv, vn = bgv;
             if (q < np_) {
-                float v = (float)(double)((int64_t)T - (int64_t)fp[q]);
+                float v = tw ? (float)(Td - tw[fp[q]]) : (float)(double)((int64_t)T - (int64_t)fp[q]);
                 v = fminf(v, 500e6f);
                 vp = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
             }
             if (q < nn_) {
-                float v = (float)(double)((int64_t)T - (int64_t)fn[q]);
+                float v = tw ? (float)(Td - tw[fn[q]]) : (float)(double)((int64_t)T - (int64_t)fn[q]);
                 v = fminf(v, 500e6f);
                 vn = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
             }

@@ -329,14 +329,22 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
 
 int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t k,
                int32_t frame_mode, const int32_t *sample_times, float scale, float *out, void *stream_) {
+    return evrep_tore_ftime(plan, events, offsets, workspace, k, frame_mode, sample_times, nullptr, nullptr, scale, out, stream_);
+}
+
+int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t k,
+                     int32_t frame_mode, const int32_t *sample_times, const double *tf, const double *sample_times_f,
+                     float scale, float *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
+    if (sample_times_f && !tf) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)2 * k * 4);
     k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx), stream>>>(
         reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
-        CWS(WindowMeta, off_meta), sample_times, plan->H, plan->W, plan->nchunk, span, k, frame_mode, scale, out);
+        CWS(WindowMeta, off_meta), sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, span, k, frame_mode,
+        scale, out);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
 }

@@ -191,16 +191,27 @@ class EventBatch:
                   "evrep_time_surface")
         return out
 
-    def tore(self, k=6, frame_mode=0, scale=1.0, out=None, sample_times=None):
+    def tore(self, k=6, frame_mode=0, scale=1.0, out=None, sample_times=None, times_f64=None, sample_times_f64=None):
         """TORE.  frame_mode 0 (bounding box, the gen1/gen4 dispatcher's behaviour) returns a list of
         per-window (Hbb, Wbb, 2k) views (needs one host sync for the boxes); modes 1/2 return
         (B, H, W, 2k)."""
         self.bin()
         out = self._out(out, 2 * k, torch.float32)
         keep, tptr = self._i32_dev(sample_times, 1)
+        fptr, sfptr, keep_f = ctypes.c_void_p(None), ctypes.c_void_p(None), None
+        if times_f64 is not None:      # float64 timestamps, one per event (the events' own t column is then not used)
+            if times_f64.dtype != torch.float64 or times_f64.device != self.device or times_f64.numel() != self.total \
+                    or not times_f64.is_contiguous():
+                raise ValueError("times_f64 must be a contiguous float64 tensor with one entry per event on %s" % self.device)
+            fptr = _ptr(times_f64)
+            if sample_times_f64 is not None:
+                keep_f = torch.as_tensor(np.asarray(sample_times_f64, dtype=np.float64)).reshape(-1).to(self.device)
+                if keep_f.numel() != self.B:
+                    raise ValueError("sample_times_f64 must hold one time per window")
+                sfptr = _ptr(keep_f)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_tore(*self._args(), int(k), int(frame_mode), tptr, float(scale), _ptr(out),
-                                      _stream_ptr()), "evrep_tore")
+            check(self.lib.evrep_tore_ftime(*self._args(), int(k), int(frame_mode), tptr, fptr, sfptr, float(scale), _ptr(out),
+                                            _stream_ptr()), "evrep_tore_ftime")
         if frame_mode != 0:
             return out
         bb = self.bbox()

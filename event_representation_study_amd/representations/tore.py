@@ -1,24 +1,45 @@
 """events2ToreFeature -- mirrors representations/tore.py:6-83 of the reference."""
 import numpy as np
+import torch
 
-from ._common import events_from_fields, raise_for_status
+from ._common import raise_for_status
 from ..engine import EventBatch
+from ..synthetic import field_to_int64, int64_to_int32
 
 
 def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     """TORE volume for one sample time.  x, y are 1-based (the reference indexes ``[i - 1, j - 1]``);
-    returns (frameSize[0], frameSize[1], 2k) float32: the k most recent log-intervals per polarity."""
+    returns (frameSize[0], frameSize[1], 2k) float32: the k most recent log-intervals per polarity.
+
+    Float inputs behave as in the reference: float coordinates cannot index (IndexError), so it falls into its
+    ``except`` branch and truncates them with int() (tore.py:29-33); float timestamps are used as they are --
+    ``currentSampleTime - ts`` in float64 (:21) -- which is how n_imagenet calls it (seconds, imagenet.py:1093-1103)."""
     Hf, Wf = int(frameSize[0]), int(frameSize[1])
-    x = np.asarray(x)
-    y = np.asarray(y)
-    if len(x) and (x.min() < 1 or y.min() < 1):
+    x, y, ts, pol = np.asarray(x), np.asarray(y), np.asarray(ts), np.asarray(pol)
+    xi = field_to_int64(x, "x", truncate=True)                     # int(i), int(j)
+    yi = field_to_int64(y, "y", truncate=True)
+    if len(xi) and (xi.min() < 1 or yi.min() < 1):
         raise NotImplementedError("events2ToreFeature: x, y below 1 (numpy negative-index wrap) are not supported")
-    ev = events_from_fields(x.astype(np.int64) - 1, y.astype(np.int64) - 1, ts, pol)
-    if ev.shape[0] == 0:
+    float_time = ts.dtype.kind == "f" and len(ts) and not np.all(ts == np.rint(ts)) or \
+        isinstance(sampleTimes, (float, np.floating)) and float(sampleTimes) != np.rint(float(sampleTimes))
+    n = len(xi)
+    ev = np.empty((n, 4), dtype=np.int32)
+    ev[:, 0], ev[:, 1] = int64_to_int32(xi - 1, "x"), int64_to_int32(yi - 1, "y")
+    # `pol > 0` is all the reference looks at (:19,34); fractional polarities keep their sign
+    ev[:, 3] = np.where(pol > 0, 1, np.where(pol < 0, -1, 0))
+    if n == 0:
         out = np.zeros((Hf, Wf, 2 * k), dtype=np.float32)
         out[...] = np.float32(np.log(np.float32(500e6) + 1) - np.log(151))
         return out
-    batch = EventBatch.from_numpy(ev, Hf, Wf)
-    raise_for_status(batch, what="events2ToreFeature")
-    rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(sampleTimes)])
+    if float_time:
+        ev[:, 2] = np.arange(n, dtype=np.int32) if np.all(np.diff(ts) >= 0) else -np.arange(n, dtype=np.int32)  # order marker only
+        batch = EventBatch.from_numpy(ev, Hf, Wf)
+        raise_for_status(batch, what="events2ToreFeature")
+        tf = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.float64)).to(batch.device)
+        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, times_f64=tf, sample_times_f64=[float(sampleTimes)])
+    else:
+        ev[:, 2] = int64_to_int32(field_to_int64(ts, "t"), "t")
+        batch = EventBatch.from_numpy(ev, Hf, Wf)
+        raise_for_status(batch, what="events2ToreFeature")
+        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(sampleTimes)])
     return rep[0].cpu().numpy()

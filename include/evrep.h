@@ -123,6 +123,14 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
 int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                int32_t k, int32_t frame_mode, const int32_t *sample_times, float scale, float *out, void *stream);
 
+/* The same with FLOAT64 timestamps (n_imagenet hands seconds as '<f8', imagenet.py:1002-1006,1093-1103; tore.py itself
+ * computes currentSampleTime - ts in whatever dtype it is given): tf DEVICE double [total_events] = every event's
+ * time, indexed like `events` (their t column is then only used for the sortedness check); sample_times_f DEVICE
+ * double [B] or NULL (= tf of the window's last event).  tf == NULL: exactly evrep_tore. */
+int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t k,
+                     int32_t frame_mode, const int32_t *sample_times, const double *tf, const double *sample_times_f,
+                     float scale, float *out, void *stream);
+
 /* compute_repr (representation_search/gromov_wasserstein.py:72-82) with t normalised as :96;
  * mode 0.  mode 1 = tonic.transforms.ToVoxelGrid as gen1_transforms.py:22-25 consumes it
  * (restated from tonic's published algorithm; parity unpinned).  mode 2 = ev-licious

@@ -15,6 +15,7 @@ third-party packages) and stores inputs and outputs only -> ``boundary.npz``.
   (event_stack.py:28-41) and post_stack's reversed level axis (:64-65).
 * ``evl_*``    -- ev-licious events_to_voxel_grid with explicit t0_us / t1_us (tools/utils.py:60-63).
 * ``sp_*``     -- the same function on sub-pixel (float) coordinates: the bilinear-in-x/y draw (:86-102).
+* ``tf_*``     -- events2ToreFeature on float coordinates and float-second timestamps, as n_imagenet calls it.
 """
 import importlib.util
 import os
@@ -129,6 +130,22 @@ def main():
         s_.width, s_.height = 80, 60
         out["sp_int_events"] = evs
         out["sp_int_raw5"] = evl_utils.events_to_voxel_grid(s_, 5, normalize=False)
+        # ---- TORE on float inputs, as n_imagenet's reshape_then_tore drives it (imagenet.py:1080-1107): float
+        # coordinates (truncated by the except branch, tore.py:29-33), timestamps in float SECONDS ------------
+        for tag, Wt, Ht, Nt, seed, tscale in (("tf_a", 64, 48, 4000, 741, 1e-6), ("tf_b", 40, 30, 2500, 742, 1.0)):
+            evt = make_events(Nt, Wt, Ht, seed=seed, dup_last=3)
+            r3 = np.random.default_rng(seed)
+            xf = evt[:, 0] + r3.random(Nt) * 0.999
+            yf = evt[:, 1] + r3.random(Nt) * 0.999
+            tf = (evt[:, 2] + np.sort(r3.random(Nt)) * 0.5) * tscale      # non-integral, ascending
+            tf[-3:] = tf[-1]
+            pf = evt[:, 3].astype(np.float64)
+            x1 = xf - min(xf) + 1
+            y1 = yf - min(yf) + 1
+            out[tag + "_x"], out[tag + "_y"], out[tag + "_t"], out[tag + "_p"] = xf, yf, tf, pf
+            out[tag + "_W"], out[tag + "_H"] = Wt, Ht
+            out[tag + "_tore"] = ref["tore"](x1, y1, tf, pf, tf[-1], 6, (Ht, Wt))
+            out[tag + "_tore_mid"] = ref["tore"](x1, y1, tf, pf, float(tf[Nt // 2]) + 1e-9, 4, (Ht, Wt))
     np.savez_compressed(os.path.join(HERE, "boundary.npz"), **out)
     print("wrote boundary.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 

@@ -299,6 +299,29 @@ def test_evlicious_voxel_grid_subpixel():
     assert_bit_equal(events_to_voxel_grid(e, 5, normalize=False), g["sp_int_raw5"], "int32 coordinates")
 
 
+def test_tore_float_coordinates_and_float_seconds():
+    """events2ToreFeature as n_imagenet drives it (imagenet.py:1080-1107): float coordinates (the reference's except
+    branch truncates them) and timestamps in float seconds; sample time = the last timestamp, or mid-window."""
+    from event_representation_study_amd.representations.tore import events2ToreFeature
+    g = load_golden("boundary")
+    for tag in ("tf_a", "tf_b"):
+        x, y, t, p = g[tag + "_x"], g[tag + "_y"], g[tag + "_t"], g[tag + "_p"]
+        H, W = int(g[tag + "_H"]), int(g[tag + "_W"])
+        x1, y1 = x - min(x) + 1, y - min(y) + 1
+        got = events2ToreFeature(x1, y1, t, p, t[-1], 6, (H, W))
+        assert got.dtype == np.float32 and got.shape == g[tag + "_tore"].shape
+        np.testing.assert_allclose(got, g[tag + "_tore"], rtol=1e-6, atol=1e-6)      # device logf vs libm
+        assert np.array_equal(got == got.max(), g[tag + "_tore"] == g[tag + "_tore"].max())   # same empty-FIFO pattern
+        got = events2ToreFeature(x1, y1, t, p, float(t[len(t) // 2]) + 1e-9, 4, (H, W))
+        np.testing.assert_allclose(got, g[tag + "_tore_mid"], rtol=1e-6, atol=1e-6)
+    # through n_imagenet's wrapper: (N, 4) float tensor rows [x, y, t, p]
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    x, y, t, p = g["tf_a_x"], g["tf_a_y"], g["tf_a_t"], g["tf_a_p"]
+    rep = ni.reshape_then_tore(torch.from_numpy(np.stack([x, y, t, p], 1)), height=int(g["tf_a_H"]), width=int(g["tf_a_W"]))
+    np.testing.assert_allclose(rep.numpy(), g["tf_a_tore"].transpose(2, 0, 1), rtol=1e-6, atol=1e-6)
+
+
 def test_gwd_caller_pipeline_f1():
     """keep-ratio area resize + letterbox(114) + otmi -> C_p (resize restated from
     OpenCV's published algorithm; parity unpinned: cv2 is absent)."""
