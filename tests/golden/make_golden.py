@@ -24,6 +24,29 @@ the smallest possible stand-ins *in sys.modules of this process only*
                         evaluations of ``loss_fun``.  PARITY UNPINNED for the
                         returned scalar (compute_otmi.py:81-93).
 """
+# What the two arithmetic stand-ins restate, so the claim can be audited against the upstream sources (both packages
+# are absent from this image and un-vendored by the reference; file names as published, quoted from memory):
+#
+# torch_scatter (csrc/cpu/scatter_cpu.cpp, `scatter_cpu`; python wrapper torch_scatter/scatter.py):
+#   * the CPU kernel is ONE sequential loop over `src` in index order per output slice -- `for i in range(E): out[idx] =
+#     reduce(out[idx], src[i])` -- hence "events of a pixel are added in time order";
+#   * reduce="sum": out starts at 0 (`torch.zeros`), `+=`;
+#   * reduce="mean": `scatter_sum`, then `count = scatter_sum(ones)`, `count[count < 1] = 1` (`count.clamp_(1)`),
+#     `out.true_divide_(count)`  (scatter.py `scatter_mean`);
+#   * reduce="max": `out.fill_(std::numeric_limits<scalar_t>::lowest())`, update where `src > out`, and afterwards
+#     `out.masked_fill_(arg_out == index.size(dim), 0)` -- slots nothing was scattered into become 0.
+#   The stand-in below does the same with torch.scatter_add_ / scatter_reduce_("amax") + the masked fill; for sums it
+#   relies on torch's CPU scatter_add_ being the same sequential in-order loop (it is: index_put-free, single thread
+#   here because torch.set_num_threads(1)).
+#
+# POT (ot/gromov/_estimators.py, `sampled_gromov_wasserstein` and `GW_distance_estimation`):
+#   * `T = np.outer(p, q)`; the `for cpt in range(max_iter)` body never runs for max_iter = 0;
+#   * with log=True: `log['gw_dist_estimated'], log['gw_dist_std'] = GW_distance_estimation(C1, C2, loss_fun, p, q, T,
+#     nb_samples_p, nb_samples_q, std=True)`, which draws index samples, evaluates `loss_fun` on the sampled
+#     sub-matrices `nb_samples_q` times, stacks the results and returns their `mean()` (and std);
+#   * the reference's loss_fun IGNORES its arguments and returns the full padded |Ks - Kt| (compute_otmi.py:73-75), so
+#     every one of the stacked evaluations is that same matrix whatever was sampled: the mean over the stack is its
+#     plain mean, deterministic despite POT's unseeded sampling.  The stand-in stacks two evaluations.
 import hashlib
 import json
 import os
