@@ -408,7 +408,7 @@ def main():
                 pass
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
-    if rank == 0 and not dry and not args.no_gw_extension:
+    if rank == 0 and world == 1 and not dry and not args.no_gw_extension:   # single-GPU leg: not part of a scaling run
         result["gw_extension"] = gw_extension_leg(device)
     if not dry and rank == 0 and world == 1 and not args.no_live_traffic and B == BATCH and N == EVENTS_PER_WINDOW:
         live = live_traffic("k_mdes_f64" if elem == 8 else "k_mdes_f32")   # last GPU leg: two profiler passes, ~40 s
