@@ -91,6 +91,56 @@ def test_window_sizes_around_partition_blocks(oracle):
     _check_all(eng, oracle, wins, H, W, "blocks")
 
 
+@pytest.mark.parametrize("sizes", [(8191, 8192, 8193), (16 * 8192, 16 * 8192 + 1), (17 * 8192 - 5, 40000),
+                                   (64 * 8192, 3), (64 * 8192 + 1, 9000)])
+def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes):
+    """The two-kernel binning pass: 8192-event workgroup blocks, <= 16 block runs per row found by a readlane chain,
+    17..64 by the LDS search, more than 64 x 8192 events per window -> the three-kernel pass.  Every size next to a
+    short window in the same batch; ERGO-12 / EventStack / voxel bit-exact vs the oracle."""
+    from event_representation_study_amd import engine as eng
+    H, W = 36, 200
+    wins = [make_events(n, W, H, seed=n % 1000 + 3) for n in sizes]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    assert eb.plan.reserved == (1 if max(sizes) <= 64 * 8192 else 0)
+    got, es, vx = eb.optimized().cpu().numpy(), eb.event_stack().cpu().numpy(), eb.voxel(5).cpu().numpy()
+    for b, ev in enumerate(wins):
+        assert_bit_equal(got[b], oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event stack n=%d" % len(ev))
+        if len(ev) > 3:
+            assert_bit_equal(vx[b], oracle.voxel(ev, H, W, 5), "voxel n=%d" % len(ev))
+    assert not eb.status().any()
+
+
+@pytest.mark.parametrize("H", [880, 882, 1200])
+def test_tall_sensors_around_the_lds_limit_of_the_row_sort(oracle, H):
+    """k_block_rowsort keeps 16 x H packed row counters next to its 128 KB record stage: sensors of up to ~881 rows
+    take the two-kernel pass, taller ones the three-kernel pass; same tensors either way."""
+    from event_representation_study_amd import engine as eng
+    W = 70
+    wins = [make_events(30000, W, H, seed=H), make_events(100, W, H, seed=H + 1)]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    assert eb.plan.reserved == (1 if H <= 881 else 0)
+    got = eb.optimized().cpu().numpy()
+    for b, ev in enumerate(wins):
+        assert_bit_equal(got[b], oracle.ergo12(ev, H, W), "ergo12 H=%d" % H)
+    assert_bit_equal(eb.event_stack()[0].cpu().numpy(), oracle.event_stack(wins[0], H, W), "event stack H=%d" % H)
+
+
+def test_three_kernel_binning_pass_still_agrees(oracle, monkeypatch):
+    """EVREP_BIN_THREE_KERNEL forces the round-1 pass for windows the two-kernel pass would take: same tensors."""
+    from event_representation_study_amd import engine as eng
+    H, W = 120, 160
+    wins = [make_events(20000, W, H, seed=5), make_events(9000, W, H, seed=6, polarity="01")]
+    a = eng.EventBatch.from_numpy(wins, H, W)
+    monkeypatch.setenv("EVREP_BIN_THREE_KERNEL", "1")
+    b = eng.EventBatch.from_numpy(wins, H, W)
+    assert a.plan.reserved == 1 and b.plan.reserved == 0
+    assert_bit_equal(a.optimized().cpu().numpy(), b.optimized().cpu().numpy(), "two- vs three-kernel ergo12")
+    assert_bit_equal(a.time_surface().cpu().numpy(), b.time_surface().cpu().numpy(), "two- vs three-kernel time surface")
+    np.testing.assert_array_equal(a.bbox(), b.bbox())
+    np.testing.assert_array_equal(a.status(), b.status())
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_tore_frame_modes(seed, oracle):
     """frame_mode 0 (bounding box, the dispatcher) and 1 (full frame, origin-shifted: n_imagenet's call) with
