@@ -35,6 +35,9 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #ifndef EVREP_XCD_MAP
 #define EVREP_XCD_MAP 1
 #endif
+#ifndef EVREP_SORT_EXPERIMENT
+#define EVREP_SORT_EXPERIMENT 0
+#endif
 #ifndef EVREP_NT_STORES
 #define EVREP_NT_STORES 1  // non-temporal output stores (the tensor is written once and never re-read by the step): -3 us on
                            // the ERGO-12 launch and -3 us on the next binning pass, whose loads find less of L2 evicted (r02)
@@ -258,6 +261,35 @@ template <typename OutT, int CMAX, typename Reduce>
 __device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, int npix, int C,
                                   OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
     const uint32_t nrec = ce - cs;
+#if EVREP_SORT_EXPERIMENT
+    // cost probe (r02): what an in-wave stable sort of the chunk's <= 64 records by pixel would add to every builder
+    // wave if the column level of the binning pass were dropped (the records ARE sorted here, so the result is the same)
+    if (nrec && nrec <= (uint32_t)kWave) {
+        const int lane = threadIdx.x;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(w.tile);   // 256 words of the not-yet-filled tile
+        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        wave_phase();
+        const bool valid = lane < (int)nrec;
+        const uint32_t px = valid ? (uint32_t)(r0.x - key0) & 255u : 0u;
+        if (valid) atomicAdd(&cnt[px], 1u);
+        wave_phase();
+        const uint4 c4 = reinterpret_cast<uint4 *>(cnt)[lane];
+        const uint32_t local = c4.x + c4.y + c4.z + c4.w;
+        uint32_t incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        uint4 o4;
+        o4.x = incl - local; o4.y = o4.x + c4.x; o4.z = o4.y + c4.y; o4.w = o4.z + c4.z;
+        reinterpret_cast<uint4 *>(cnt)[lane] = o4;
+        wave_phase();
+        uint32_t rk; bool last;
+        wave_match(px, 8, valid, lane, rk, last);
+        if (valid) w.evbuf[cnt[px] + rk] = r0;
+        wave_phase();
+        if (valid) r0 = w.evbuf[lane];
+        wave_phase();
+    }
+#endif
     if (nrec) w.evbuf[threadIdx.x] = r0;
     const Rec *evbuf = w.evbuf;
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : sorted[cs + j].x; };
