@@ -86,6 +86,13 @@ def cpu_baseline(events_per_window, budget_s=12.0, threads_budget_s=6.0):
                      % (done, events_per_window, el),
            "windows_per_s": done / el}
     ncpu = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu
+    quota = None
+    try:                                   # cgroup v2 CPU quota of the container: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
     if ncpu > 1 and threads_budget_s > 0:
         def work(k):
             n = 0
@@ -105,7 +112,7 @@ def cpu_baseline(events_per_window, budget_s=12.0, threads_budget_s=6.0):
             el2 = time.perf_counter() - t0
             tried.append({"value": total * events_per_window / el2, "unit": "events/s", "cores": nt,
                           "sample": "%d windows over %d threads, %.1f s" % (total, nt, el2)})
-        res["all_cores"] = dict(max(tried, key=lambda r: r["value"]), host_cores=ncpu,
+        res["all_cores"] = dict(max(tried, key=lambda r: r["value"]), host_cores=ncpu, affinity_cores=usable, cgroup_cpu_quota=quota,
                                 tried=[(r["cores"], round(r["value"])) for r in tried])
     return res
 
