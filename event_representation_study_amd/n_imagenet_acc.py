@@ -220,8 +220,9 @@ TIME_SCALE = 1000000     # imagenet.py:21
 
 
 def reshape_then_acc_sort(event_tensor, augment=None, **kwargs):
-    """Sorted timestamp image (imagenet.py:513-838), strict=False: per pixel (and polarity) the LATEST time index,
-    optionally with the binary event image and quantised copies; (C, H, W) float32."""
+    """Sorted timestamp image (imagenet.py:513-838): per pixel (and polarity) the LATEST time index (strict=False) or
+    the dense rank of it among the pixels' latest indices (strict=True), optionally with the binary event image and
+    quantised copies; (C, H, W) float32."""
     if augment is not None:
         event_tensor = augment(event_tensor)
     global_time, neglect, use_image, strict = (kwargs[k] for k in ("global_time", "neglect_polarity", "use_image", "strict"))
@@ -235,8 +236,6 @@ def reshape_then_acc_sort(event_tensor, augment=None, **kwargs):
     ev_t[:, 2] = time_idx                      # the reference overwrites the caller's time column as well (:525,539)
     if use_image and kwargs["denoise_image"]:
         raise NameError("name 'density_filter_event_image' is not defined")   # what the reference raises (:556,679)
-    if strict:
-        raise NotImplementedError("strict=True needs torch_scatter's arg-max tie-breaking (package absent)")
     if kwargs["denoise_sort"]:
         raise NameError("name 'density_filter_event_image' is not defined")   # (:609,777)
     ev = _as_f64(ev_t)
@@ -253,7 +252,28 @@ def reshape_then_acc_sort(event_tensor, augment=None, **kwargs):
     chans = []
     for k in range(len(classes)):
         image, srt = prim[..., 2 * k], prim[..., 2 * k + 1]
-        if not bool((srt > 0.0).any()):        # hot_event_sort.max() on an empty selection (:592-594,744-746)
+        if strict:
+            # :563-590,685-748: per pixel the event of the latest time index (scatter_max's arg; which of several
+            # events sharing pixel AND index it names does not matter, they carry the same value and the stream is
+            # time-ordered), then the DENSE RANK of those per-pixel maxima (+1), min-max normalised in float32
+            hot = image > 0
+            if not bool(hot.any()):
+                # a polarity without events is replaced by ONE event at pixel (0, 0), t = 0 (:647-652): its rank
+                # image is all zero (max == min -> fill_(0)), its event image has that one pixel set
+                image = torch.zeros_like(image)
+                image[0, 0] = 1.0
+                srt = torch.zeros_like(srt)
+            else:
+                vals = srt[hot]
+                uniq, inv = torch.unique(vals, sorted=True, return_inverse=True)
+                fs = inv.to(torch.float32) + 1
+                if int(uniq.numel()) > 1:
+                    fs = (fs - fs.min()) / (fs.max() - fs.min())
+                else:
+                    fs = torch.zeros_like(fs)
+                srt = torch.zeros_like(srt)
+                srt[hot] = fs
+        elif not bool((srt > 0.0).any()):      # hot_event_sort.max() on an empty selection (:592-594,744-746)
             raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0")
         if q is not None:
             if type(q) == int:

@@ -25,6 +25,9 @@ NAMES = ["acc", "acc_time", "acc_count", "acc_count_pol", "acc_count_only", "acc
          "acc_exp", "acc_time_pol", "acc_intensity"]
 
 
+ARG_PICK = "first"
+
+
 def _import_imagenet():
     mg._install_standins()
     ts = sys.modules["torch_scatter"]
@@ -33,7 +36,16 @@ def _import_imagenet():
         def f(src, index, dim=-1, out=None, dim_size=None):
             assert src.dim() == 1 and out is None
             o = torch.zeros(dim_size, dtype=src.dtype).scatter_reduce_(0, index, src, reduce=kind, include_self=False)
-            return o, torch.full((dim_size,), src.shape[0], dtype=torch.long)  # arg indices: unused by these callers
+            # arg indices as torch_scatter's sequential CPU loop leaves them: the FIRST element attaining the extremum
+            # (strict comparison), src.size for slots nothing was scattered into.  ARG_PICK = "last" flips the
+            # tie-break; main() checks that no golden depends on it.
+            arg = torch.full((dim_size,), src.shape[0], dtype=torch.long)
+            order = range(src.shape[0] - 1, -1, -1) if ARG_PICK == "first" else range(src.shape[0])
+            sv, iv, ov = src.tolist(), index.tolist(), o.tolist()
+            for e in order:                       # later assignments win: walking backwards leaves the first
+                if sv[e] == ov[iv[e]]:
+                    arg[iv[e]] = e
+            return o, arg
         return f
 
     ts.scatter_max, ts.scatter_min = _scatter_ext("amax"), _scatter_ext("amin")
@@ -85,6 +97,23 @@ def main():
         for ck, kw in combos.items():
             g["%s_acc_sort_%s" % (tag, ck)] = ref.reshape_then_acc_sort(
                 torch.from_numpy(ev.copy()), height=H, width=W, **base, **kw).numpy()
+    # strict=True (:563-590,685-748): the dense rank of the per-pixel latest indices; the goldens must not depend
+    # on which of several tied events scatter_max's arg names
+    global ARG_PICK
+    strict_combos = {"t0": dict(global_time=True, neglect_polarity=True, use_image=True, quantize_sort=None),
+                     "t1": dict(global_time=True, neglect_polarity=False, use_image=True, quantize_sort=8),
+                     "t2": dict(global_time=False, neglect_polarity=False, use_image=False, quantize_sort=[4, 16]),
+                     "t3": dict(global_time=False, neglect_polarity=True, use_image=False, quantize_sort=None)}
+    sbase = dict(strict=True, denoise_image=False, denoise_sort=False)
+    for tag, ev, H, W in cases[:3]:
+        for ck, kw in strict_combos.items():
+            outs = []
+            for pick in ("first", "last"):
+                ARG_PICK = pick
+                outs.append(ref.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, **sbase, **kw).numpy())
+            assert np.array_equal(outs[0], outs[1]), (tag, ck)
+            g["%s_acc_sort_%s" % (tag, ck)] = outs[0]
+    ARG_PICK = "first"
     # the empty-tensor substitutions (imagenet.py:258-261,483-486)
     for name in ("acc_count", "acc_time_pol"):
         g["empty_" + name] = getattr(ref, "reshape_then_" + name)(torch.zeros((0, 4), dtype=torch.float64),

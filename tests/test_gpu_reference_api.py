@@ -574,6 +574,24 @@ def test_nimagenet_dist_adj_sort(tag):
 
 
 @pytest.mark.gpu
+def test_nimagenet_acc_sort_strict_single_polarity():
+    """strict=True on a stream with ONE polarity: the absent polarity is the reference's substituted single event at
+    pixel (0, 0) (imagenet.py:647-652) -- an all-zero rank image and, with use_image, that one pixel set."""
+    import torch
+    from event_representation_study_amd import n_imagenet_acc as ni
+    g = _ni_golden()
+    ev, H, W = g["pos_events"], int(g["pos_H"]), int(g["pos_W"])
+    sbase = dict(strict=True, denoise_image=False, denoise_sort=False)
+    combos = {"t0": dict(global_time=True, neglect_polarity=True, use_image=True, quantize_sort=None),
+              "t1": dict(global_time=True, neglect_polarity=False, use_image=True, quantize_sort=8),
+              "t2": dict(global_time=False, neglect_polarity=False, use_image=False, quantize_sort=[4, 16]),
+              "t3": dict(global_time=False, neglect_polarity=True, use_image=False, quantize_sort=None)}
+    for ck, kw in combos.items():
+        got = ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, **sbase, **kw)
+        np.testing.assert_array_equal(got.numpy(), g["pos_acc_sort_" + ck], err_msg=ck)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_nimagenet_acc_sort(tag):
     """reshape_then_acc_sort, strict=False: latest time index per pixel from the HIP builder, for the keyword
@@ -595,9 +613,14 @@ def test_nimagenet_acc_sort(tag):
         np.testing.assert_array_equal(got.numpy(), want, err_msg=ck)
         # the caller's time column now holds the time index, as after the reference call
         assert float(t[:, 2].max()) >= 1.0 and bool((t[:, 2] == t[:, 2].round()).all())
-    with pytest.raises(NotImplementedError):
-        ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, global_time=True, neglect_polarity=True,
-                                 use_image=False, quantize_sort=None, strict=True, denoise_image=False, denoise_sort=False)
+    # strict=True: the dense rank of the per-pixel latest indices (goldens checked to be independent of scatter_max's
+    # arg tie-break, make_golden_nimagenet.py)
+    sbase = dict(strict=True, denoise_image=False, denoise_sort=False)
+    for ck, kw in combos.items():
+        want = g["%s_acc_sort_t%s" % (tag, ck[1:])]
+        got = ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, **sbase, **kw)
+        assert got.dtype == torch.float32 and tuple(got.shape) == want.shape, (ck, got.shape, want.shape)
+        np.testing.assert_array_equal(got.numpy(), want, err_msg="strict " + ck)
     with pytest.raises(NameError):
         ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W, global_time=True, neglect_polarity=True,
                                  use_image=False, quantize_sort=None, strict=False, denoise_image=False, denoise_sort=True)
