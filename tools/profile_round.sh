@@ -15,6 +15,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o pmc_fetch -- python $R/tools/pmc_workload.py > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o pmc_write -- python $R/tools/pmc_workload.py > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -o pmc_sq -- python $R/tools/pmc_workload.py > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/b_sq -o pmc_builders_sq -- python $R/tools/pmc_builders_workload.py > $O/b_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/b_fetch -o pmc_builders_fetch -- python $R/tools/pmc_builders_workload.py > $O/b_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/b_write -o pmc_builders_write -- python $R/tools/pmc_builders_workload.py > $O/b_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gwd_sq -o pmc_gwd -- python $R/tools/gwd_prof.py > $O/gwd_sq.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gw_sq -o pmc_gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gw_kt -o gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_kt.log 2>&1
