@@ -235,11 +235,22 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
             tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
         }
     } else {
-        // dense chunk: one pass per part tile, each segment reduced in the pass of its own part
+        // dense chunk: one pass per part tile, each segment reduced in the pass of its own part.  The segment list is
+        // pixel-ordered, so a part owns the contiguous range [sb, se) of it -- at most kPartPx entries, one per lane,
+        // every lane of the range busy (r02: striding the whole list and skipping the other part's entries left half
+        // of the lanes idle in each of twice as many reduce rounds)
+        int sb = 0;
         for (int part = 0; part * kPartPx < npix; ++part) {
             const int np = min(kPartPx, npix - part * kPartPx);
             if (part) { wave_phase(); tile_fill(w.tile, np, C, bg); wave_phase(); }
-            for (int k = lane; k < nseg; k += kWave) {
+            int se = sb;
+            for (int k0 = sb; k0 < nseg; k0 += kWave) {
+                const int k = k0 + lane;
+                const int c = __popcll(__ballot(k < nseg && (int)w.segs[k].x < (part + 1) * kPartPx));
+                se += c;
+                if (c < kWave) break;
+            }
+            for (int k = sb + lane; k < se; k += kWave) {
                 const uint2 sg = w.segs[k];
                 const int q = (int)sg.x - part * kPartPx;
                 if (q < 0 || q >= np) continue;
@@ -249,6 +260,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
             }
+            sb = se;
             wave_phase();
             tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
         }
