@@ -746,7 +746,7 @@ template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
-                                                                     int nchunk, Rec *__restrict__ sorted2,
+                                                                     int nchunk, int kpr, Rec *__restrict__ sorted2,
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
     extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -761,7 +761,9 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
 #pragma unroll
     for (int r = 0; r <= R; ++r) {
         t[r] = 0;
-        if (lane < nb) t[r] = table[((size_t)b * nblk + lane) * (H + 1) + min(row0 + r, H)];
+        // kpr = keys per row of the run table: 1 after k_block_rowsort; nchunk after k_block_keysort, whose runs hold a
+        // row's records chunk by chunk (time-ordered inside a chunk, which is all the stable column sort below needs)
+        if (lane < nb) t[r] = table[((size_t)b * nblk + lane) * ((size_t)H * kpr + 1) + (size_t)min(row0 + r, H) * kpr];
     }
     if (row0 == 0) {  // this wave also publishes the window's statistics
         BlockStats st;
@@ -909,6 +911,201 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
             }
         }
         wave_phase_lds();  // the next row zeroes the counters
+    }
+}
+
+// =====================================================================================================
+// Key-sorted binning pass (plan->reserved == 2): ONE kernel.  A workgroup orders its 8192 events by the KEY
+// (sensor row, 128-pixel chunk) -- the unit a builder wave owns -- and the builder wave itself gathers its
+// unit's records from the window's block runs and finishes the order by pixel inside its LDS
+// (evrep_builders.hip, unit_records).  The column sort kernel, its launch boundary, and one write + one read of
+// every record disappear from the step; sorted2 / chunk_off are only produced on demand
+// (k_col_sort_runs with kpr = nchunk) for the few consumers that walk the pixel-sorted stream directly.
+//
+// The order inside a key must be the time order.  Instead of per-wave counter tables (16 waves x keys would not
+// fit next to the record stage) the block counts with ONE table of LDS atomics, whose returned values order the
+// arrivals arbitrarily, and then repairs every key group: a record's place inside its group = the number of
+// group members with a smaller rank, read from a 16-bit rank array (groups hold 3-4 records on the headline
+// windows; a group of g records costs g reads per member, so a hot pixel makes its own block slower, never
+// wrong).  Nothing depends on another workgroup.
+// =====================================================================================================
+__host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap) {
+    return (size_t)cap * sizeof(Rec) + (size_t)kBsChunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
+}
+
+// grid (8 * ceil(B/8) * nblk), 1024 threads, dynamic LDS = block_keysort_lds_bytes(H * kpr, cap); cap = records
+// the stage holds (8192, or 4096 on sensors with many keys: the block is then written out in two rounds).
+// table: [B][nblk][H * kpr + 1] exclusive offsets of the block's keys inside its run (last entry = in-frame events).
+__global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+                                                             int B, int H, int W, int kpr, int nblk, int cap,
+                                                             uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
+                                                             Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int NK = H * kpr;
+    Rec *stage = reinterpret_cast<Rec *>(smem_raw);                         // [cap], output order
+    uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kBsChunk] rank inside the block, arrival order
+    uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kBsChunk);      // [NK + 1] counts -> exclusive offsets
+    __shared__ BlockStats wstats[kBsWaves];
+    __shared__ uint32_t tmp[kBsWaves];
+    int b, blk;
+    if (!decode_window_block(B, nblk, b, blk)) return;
+    const int64_t beg = off[b];
+    const int64_t n = off[b + 1] - beg;
+    const int64_t lo = (int64_t)blk * kBsChunk;
+    if (blk == 0 && threadIdx.x == 0) nwin[b] = n;  // for k_window_meta, which is not handed the offsets
+    if (lo >= n) return;  // the builders only read the blocks a window really has
+    const int64_t hi = (lo + kBsChunk < n) ? lo + kBsChunk : n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wlo = lo + (int64_t)wave * (kBsPerLane * kWave);
+    const int64_t whi = (wlo + kBsPerLane * kWave < hi) ? wlo + kBsPerLane * kWave : hi;
+    const int64_t HW = (int64_t)H * W;
+    int4 e[kBsPerLane];
+    int tprev[kBsPerLane];
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        const int64_t r = wlo + i * kWave + lane;
+        e[i] = make_int4(-1, -1, INT32_MAX, 0);
+        tprev[i] = INT32_MIN;
+        if (r < whi) {
+            e[i] = ev[beg + r];
+            if (lane == 0 && r > 0) tprev[i] = ev[beg + r - 1].z;  // other lanes take it from their neighbour
+        }
+    }
+    for (int i = threadIdx.x; i <= NK; i += kBsThreads) base[i] = 0;
+    __syncthreads();
+    const MdesWindows mw = mdes_windows(n);
+    uint32_t full = 0, part = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (mw.lo[i] <= lo && hi <= mw.hi[i]) full |= 1u << i;
+        else if (!(hi <= mw.lo[i] || lo >= mw.hi[i])) part |= 1u << i;
+    }
+    BlockStats st;
+    stats_identity(st);
+    uint32_t ko[kBsPerLane];  // key | arrival << 16, then the record's place in the block; 0xffffffff = not placed
+    uint32_t sneg = 0;
+    bool cut = false;
+    if (part) {
+        const int32_t a0 = (int32_t)wlo, a1 = (int32_t)whi;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) cut |= (mw.lo[q] > a0 && mw.lo[q] < a1) || (mw.hi[q] > a0 && mw.hi[q] < a1);
+    }
+    const uint32_t memb_u = cut ? 0u : (full | (part ? (mdes_membership(mw, (int32_t)wlo) & part) : 0u));
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        const int64_t r = wlo + i * kWave + lane;
+        const bool in = r < whi;
+        const int up = __builtin_amdgcn_update_dpp(0, e[i].z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane != 0) tprev[i] = up;
+        // in-frame test on the flat index x + y*W, as the reference's scatter sees it (see k_block_rowsort)
+        uint32_t row = (uint32_t)e[i].y, col = (uint32_t)e[i].x;
+        bool valid = in && (uint32_t)e[i].x < (uint32_t)W && (uint32_t)e[i].y < (uint32_t)H;
+        if (__any(in && (uint32_t)e[i].x >= (uint32_t)W)) {
+            const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
+            valid = in && key >= 0 && key < HW;
+            if (valid) { row = (uint32_t)key / (uint32_t)W; col = (uint32_t)key - row * (uint32_t)W; }
+        }
+        ko[i] = 0xffffffffu;
+        if (valid) {
+            const uint32_t key = row * (uint32_t)kpr + (col >> 7);
+            ko[i] = key | (atomicAdd(&base[key], 1u) << 16);
+        }
+        if (!cut) {
+            if (__any(in && e[i].w == -1)) sneg |= memb_u;
+        } else if (in && e[i].w == -1) {
+            st.neg_flags |= full | (mdes_membership(mw, (int32_t)r) & part);
+        }
+        if (__any(in && !valid)) {  // rare: out-of-frame events
+            if (in && !valid) {
+                const uint32_t memb = cut ? (full | (mdes_membership(mw, (int32_t)r) & part)) : memb_u;
+                st.status |= EVREP_ST_OOB;
+                const int cls = e[i].w == 1 ? 1 : (e[i].w == -1 ? 2 : (e[i].w == 0 ? 3 : 0));
+                st.oob_flags |= memb | (cls ? (memb << (7 * cls)) : 0u);
+            }
+        }
+        if (in) {
+            if (valid) ++st.n_valid;
+            if (tprev[i] > e[i].z) st.status |= EVREP_ST_UNSORTED;
+            st.tmin = min(st.tmin, e[i].z); st.tmax = max(st.tmax, e[i].z);
+            st.xmin = min(st.xmin, e[i].x); st.xmax = max(st.xmax, e[i].x);
+            st.ymin = min(st.ymin, e[i].y); st.ymax = max(st.ymax, e[i].y);
+        }
+    }
+    st.neg_flags |= sneg;
+    stats_wave_reduce(st);
+    if (lane == 0) wstats[wave] = st;
+    __syncthreads();
+    // exclusive scan over the key counters: `per` consecutive keys per thread
+    const int per = (NK + kBsThreads - 1) / kBsThreads;
+    const int k0 = (int)threadIdx.x * per;
+    uint32_t local = 0;
+    for (int k = 0; k < per; ++k) if (k0 + k < NK) local += base[k0 + k];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<kBsWaves>(local, tmp, &total);
+    for (int k = 0; k < per; ++k)
+        if (k0 + k < NK) { const uint32_t c = base[k0 + k]; base[k0 + k] = run; run += c; }
+    if (threadIdx.x == 0) {
+        base[NK] = total;
+        BlockStats t = wstats[0];
+        for (int w = 1; w < kBsWaves; ++w) stats_merge(t, wstats[w]);
+        stats[(size_t)b * nblk + blk] = t;
+    }
+    __syncthreads();
+    uint32_t *tb = table + ((size_t)b * nblk + blk) * ((size_t)NK + 1);
+    for (int k = threadIdx.x; k <= NK; k += kBsThreads) tb[k] = base[k];
+    // arrival order -> time order inside every key group
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i)
+        if (ko[i] != 0xffffffffu)
+            rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(wave * (kBsPerLane * kWave) + i * kWave + lane);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBsPerLane; ++i) {
+        if (ko[i] == 0xffffffffu) continue;
+        const uint32_t key = ko[i] & 0xffffu;
+        const uint32_t gb = base[key], g = base[key + 1] - gb;
+        const uint32_t mine = (uint32_t)(wave * (kBsPerLane * kWave) + i * kWave + lane);
+        uint32_t smaller = 0;
+        if (g > 1)
+            for (uint32_t j = 0; j < g; ++j) smaller += (uint32_t)rankbuf[gb + j] < mine ? 1u : 0u;
+        ko[i] = gb + smaller;
+    }
+    Rec *dst = sorted1 + beg + lo;
+    for (uint32_t pb = 0; pb < total; pb += (uint32_t)cap) {
+        if (pb) __syncthreads();  // the previous round has left the stage
+#pragma unroll
+        for (int i = 0; i < kBsPerLane; ++i) {
+            const uint32_t pos = ko[i] - pb;  // 0xffffffff - pb >= cap for every pb < 8192
+            if (pos < (uint32_t)cap) {
+                const int64_t r = wlo + i * kWave + lane;
+                stage[pos] = make_int4((int)((int64_t)e[i].x + (int64_t)e[i].y * W), (int)r, e[i].z, e[i].w);
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)cap, total - pb);
+        for (uint32_t t = threadIdx.x; t < cnt; t += kBsThreads) dst[pb + t] = stage[t];
+    }
+}
+
+// grid (B), 64 threads: the window statistics of the key-sorted pass, for the synchronous read-backs only
+// (the builders merge the block statistics they need themselves).
+__global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
+                                                      int nblk, WindowMeta *__restrict__ meta) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t n_win = nwin[b];
+    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    BlockStats st;
+    stats_identity(st);
+    for (int k = lane; k < nb; k += kWave) stats_merge(st, stats[(size_t)b * nblk + k]);
+    stats_wave_reduce(st);
+    if (lane == 0) {
+        WindowMeta m;
+        m.tmin = st.tmin; m.tmax = st.tmax; m.xmin = st.xmin; m.xmax = st.xmax; m.ymin = st.ymin; m.ymax = st.ymax;
+        m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status; m.n_valid = st.n_valid;
+        if (n_win <= 0) m.status |= EVREP_ST_EMPTY;
+        else if (st.tmin == st.tmax) m.status |= EVREP_ST_FLAT_TIME;
+        for (int i = 0; i < 6; ++i) m.pad[i] = 0;
+        meta[b] = m;
     }
 }
 

@@ -152,21 +152,257 @@ struct ChunkGeom {
     uint32_t cs, ce;
 };
 
-// grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks) and
-// its record range.  span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
-__device__ inline ChunkGeom chunk_geom(const uint32_t *__restrict__ chunk_off, int H, int W, int nchunk, int span = 1) {
+// What a builder reads of the binning pass.  Classic (fused == 0): the pixel-sorted stream + its chunk offsets.
+// Key-sorted (fused == 1, k_block_keysort): the window's block runs, ordered by (row, 128-pixel chunk) only, and
+// their offset tables; the builder wave gathers its unit's records and orders them by pixel itself (unit_records).
+struct BinView {
+    const Rec *sorted;          // classic: sorted2; key-sorted: sorted1 (block runs)
+    const uint32_t *chunk_off;  // classic only
+    const uint32_t *table;      // key-sorted: [B][nblk][H * nchunk + 1]
+    const BlockStats *stats;    // key-sorted: [B][nblk]
+    const WindowMeta *meta;     // classic: [B]
+    Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
+    int nblk, fused;
+};
+
+// The records of one unit, pixel-sorted: r0 = record `lane`; records >= kEvStage are read from sorted[cs + j].
+struct UnitRecs {
+    const Rec *sorted;
+    uint32_t cs, ce;
+    Rec r0;
+};
+
+// inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts), no LDS crossbar
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
+}
+
+// grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks).
+// span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
+__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &chunk) {
     ChunkGeom g;
     const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
-    const int chunk = (u % nunit) * span;
+    chunk = (u % nunit) * span;
     g.row = (u / nunit) % H;
     g.b = (u / nunit) / H;
     g.c0 = chunk * kChunkPx;
     g.npix = min(span * kChunkPx, W - g.c0);
-    const uint32_t *co = chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
+    g.cs = 0; g.ce = 0;
+    return g;
+}
+
+// Key-sorted pass: the records of keys [klo, khi) of window b (consecutive chunks of one sensor row; pixel id of the
+// first chunk's first pixel = keybase), gathered from the window's block runs and ordered by pixel, stably (the
+// runs are visited in block = time order and are time-ordered inside a key, so equal pixels stay in time order).
+//   * run k contributes table[k][klo] .. table[k][khi]; record j of the unit lies in the run whose exclusive
+//     length prefix covers j (a chain of conditional sums over <= 16 runs, an LDS search above);
+//   * <= kEvStage records (every unit of a sparse window, for which this pass is chosen): ONE load per lane, a
+//     counting sort over the unit's pixels in the wave's LDS (counters in the not-yet-used segment list), result
+//     in evbuf -- no HBM traffic beyond the one read of the record;
+//   * more: the same counting sort in batches of 64, written to the unit's own slot of the spill stream (its
+//     position = records of the window with a smaller key = sum over the runs of table[k][klo]: disjoint slots,
+//     no atomics, idempotent across builders), then read back like the classic stream.
+template <typename OutT>
+__device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
+                                        int keybase, int npixu, WaveLds<OutT> &w) {
+    const int lane = threadIdx.x;
+    UnitRecs u;
+    u.sorted = bv.spill; u.cs = 0; u.ce = 0;
+    u.r0 = make_int4(INT32_MIN, 0, 0, 0);
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    if (nb <= 0 || khi <= klo) return u;
+    uint32_t a = 0, len = 0;
+    if (lane < nb) {
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+        a = tb[klo];
+        len = tb[khi] - a;
+    }
+    const uint32_t incl = wave_incl_scan(len);
+    const uint32_t pre = incl - len;  // lanes >= nb: pre = nrec, never matched
+    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (nrec == 0) return u;
+    const uint32_t src = (uint32_t)beg + (uint32_t)lane * kBsChunk + a - pre;  // record j of the unit, if in run `lane`: src + j
+    uint32_t *runs = reinterpret_cast<uint32_t *>(w.evbuf);  // [2][64], only when nb > kBsChainBlocks
+    if (nb > kBsChainBlocks) {
+        runs[lane] = pre;
+        runs[64 + lane] = src;
+        wave_phase();
+    }
+    const Rec *__restrict__ s1 = bv.sorted;
+    auto fetch = [&](uint32_t j) -> Rec {
+        if (nb <= kBsChainBlocks) {
+            uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t prev = s;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                s += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return s1[s + j];
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && runs[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return s1[runs[64 + lo] + j];
+    };
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);  // npixu <= segcap counters: the segment list is built later
+    const int nbits = bits_for(npixu);
+    const int per4 = npixu / (4 * kWave) + ((npixu % (4 * kWave)) ? 1 : 0);  // npixu is a multiple of 128: 16-byte vectors per lane
+    uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
+    if (nrec <= (uint32_t)kEvStage) {
+        const bool valid = lane < (int)nrec;
+        Rec r = u.r0;
+        if (valid) r = fetch((uint32_t)lane);
+        u.ce = nrec;
+        if (nrec == 1) { u.r0 = r; return u; }
+        for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
+        wave_phase();
+        const uint32_t px = valid ? (uint32_t)(r.x - keybase) : 0u;
+        if (valid) atomicAdd(&cnt[px], 1u);
+        wave_phase();
+        // exclusive scan over the pixel counters: 16-byte vectors, `per4` consecutive ones per lane
+        {
+            uint32_t local = 0;
+            for (int k = 0; k < per4; ++k) {
+                const int v = lane * per4 + k;
+                if (v * 4 < npixu) { const uint4 c = cnt4[v]; local += c.x + c.y + c.z + c.w; }
+            }
+            uint32_t run = wave_incl_scan(local) - local;
+            for (int k = 0; k < per4; ++k) {
+                const int v = lane * per4 + k;
+                if (v * 4 < npixu) {
+                    const uint4 c = cnt4[v];
+                    uint4 o;
+                    o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
+                    run = o.w + c.w;
+                    cnt4[v] = o;
+                }
+            }
+        }
+        wave_phase();
+        uint32_t rk; bool last;
+        wave_match(px, nbits, valid, lane, rk, last);
+        wave_phase();   // the run table (if any) shares evbuf: every fetch is done
+        if (valid) w.evbuf[cnt[px] + rk] = r;
+        wave_phase();
+        if (valid) r = w.evbuf[lane];
+        wave_phase();
+        u.r0 = r;
+        return u;
+    }
+    // a unit of more than kEvStage records: laid out in its slot of the spill stream
+    const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
+    for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
+    wave_phase();
+    for (uint32_t j0 = 0; j0 < nrec; j0 += kWave)
+        if (j0 + lane < nrec) atomicAdd(&cnt[fetch(j0 + lane).x - keybase], 1u);
+    wave_phase();
+    {
+        uint32_t local = 0;
+        for (int k = 0; k < per4; ++k) {
+            const int v = lane * per4 + k;
+            if (v * 4 < npixu) { const uint4 c = cnt4[v]; local += c.x + c.y + c.z + c.w; }
+        }
+        uint32_t run = wave_incl_scan(local) - local;
+        for (int k = 0; k < per4; ++k) {
+            const int v = lane * per4 + k;
+            if (v * 4 < npixu) {
+                const uint4 c = cnt4[v];
+                uint4 o;
+                o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
+                run = o.w + c.w;
+                cnt4[v] = o;
+            }
+        }
+    }
+    wave_phase();
+    volatile uint32_t *vcnt = cnt;
+    for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
+        const bool valid = j0 + lane < nrec;
+        Rec r = make_int4(0, 0, 0, 0);
+        if (valid) r = fetch(j0 + lane);
+        const uint32_t px = valid ? (uint32_t)(r.x - keybase) : 0u;
+        uint32_t rk; bool last;
+        wave_match(px, nbits, valid, lane, rk, last);
+        uint32_t pos = 0;
+        if (valid) {
+            pos = vcnt[px] + rk;
+            bv.spill[cs + pos] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && last) vcnt[px] = pos + 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the wave reads back what its own lanes stored: same CU, same vector L1 -- workgroup-scope release / acquire
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    u.cs = cs;
+    u.ce = cs + nrec;
+    u.r0 = bv.spill[cs + lane];  // nrec > kEvStage = 64: every lane has one
+    return u;
+}
+
+// The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
+template <typename OutT>
+__device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
+                                      WaveLds<OutT> &w, ChunkGeom &g) {
+    int chunk;
+    g = unit_geom(H, W, nchunk, span, chunk);
+    if (bv.fused) {
+        const int klo = g.row * nchunk + chunk, khi = g.row * nchunk + min(chunk + span, nchunk);
+        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w);
+        g.cs = u.cs; g.ce = u.ce;
+        return u;
+    }
+    const uint32_t *co = bv.chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
     g.cs = co[chunk];
     g.ce = co[min(chunk + span, nchunk)];
-    return g;
+    UnitRecs u;
+    u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce;
+    u.r0 = make_int4(INT32_MIN, 0, 0, 0);
+    if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
+    return u;
+}
+
+// The window statistics a builder needs: the classic passes publish WindowMeta; after the key-sorted pass the wave
+// merges the window's block statistics itself (one lane per block, DPP reductions of the fields actually used).
+__device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__restrict__ off, int b) {
+    if (!bv.fused) return bv.meta[b];
+    const int lane = threadIdx.x;
+    const int64_t n_win = off[b + 1] - off[b];
+    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    BlockStats st;
+    stats_identity(st);
+    if (lane < nb) {
+        const int4 *sp = reinterpret_cast<const int4 *>(bv.stats + (size_t)b * bv.nblk + lane);
+        const int4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+        st.tmin = q0.x; st.tmax = q0.y; st.xmin = q0.z; st.xmax = q0.w;
+        st.ymin = q1.x; st.ymax = q1.y; st.neg_flags = (uint32_t)q1.z; st.oob_flags = (uint32_t)q1.w;
+        st.status = (uint32_t)q2.x; st.n_valid = q2.y;
+    }
+    WindowMeta m;
+    m.tmin = wave_min(st.tmin); m.tmax = wave_max(st.tmax);
+    m.xmin = wave_min(st.xmin); m.xmax = wave_max(st.xmax);
+    m.ymin = wave_min(st.ymin); m.ymax = wave_max(st.ymax);
+    m.neg_flags = wave_or(st.neg_flags); m.oob_flags = wave_or(st.oob_flags);
+    m.status = wave_or(st.status); m.n_valid = wave_sum(st.n_valid);
+    return m;
 }
 
 // The shared back end of every builder.  `reduce(jb, je, get, vals)` turns one pixel's records
@@ -357,22 +593,18 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 
 // grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
 template <typename OutT, typename D>
-__global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
-                                               const int64_t *__restrict__ off, const WindowMeta *__restrict__ meta,
+__global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__restrict__ off,
                                                MdesParams P, int H, int W, int nchunk, int span, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
     WaveLds<OutT> w(smem, C, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
-    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    const int lane = threadIdx.x;
-
+    ChunkGeom g;
     // every independent global load first: the chunk's records, the window's statistics and extent
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if (lane < (int)(g.ce - g.cs)) r0 = sorted[g.cs + lane];
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int64_t n_win = off[g.b + 1] - off[g.b];
-    const WindowMeta m = meta[g.b];
+    const WindowMeta m = window_meta(bv, off, g.b);
 
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
@@ -480,21 +712,20 @@ __global__ __launch_bounds__(kWave) void k_mdes(const Rec *__restrict__ sorted, 
             vals[c] = (OutT)(r * scale);
         }
     };
-    emit_chunk<OutT, D::kMaxC>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, r0, reduce);
+    emit_chunk<OutT, D::kMaxC>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+__global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<float> w(smem, S, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
     int offk[EVREP_MAX_CHANNELS];
@@ -513,7 +744,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(const Rec *__restrict__ s
 #pragma unroll
         for (int l = 0; l < EVREP_MAX_CHANNELS; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -613,16 +844,15 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 }
 
 template <typename OutT>
-__global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+__global__ __launch_bounds__(kWave) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int span,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
     WaveLds<OutT> w(smem, C, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     // the window's cuts, held in registers with compile-time indices only (no scratch)
     const TsCuts *cp = cuts + g.b;
     struct { int idx[kMaxSlices], tcut[kMaxSlices], live[kMaxSlices]; } cu;
@@ -674,7 +904,7 @@ __global__ __launch_bounds__(kWave) void k_time_surface(const Rec *__restrict__ 
             vals[2 * q + 1] = v1;
         }
     };
-    emit_chunk<OutT, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, r0, reduce);
+    emit_chunk<OutT, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -684,9 +914,8 @@ constexpr int kMaxToreK = 8;
 
 // grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
-__global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
-                                               const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
-                                               const WindowMeta *__restrict__ meta, const int32_t *__restrict__ sample_times,
+__global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+                                               const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
                                                int H, int W, int nchunk, int span, int K, int frame_mode, float scale,
                                                float *__restrict__ out) {
@@ -702,7 +931,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     // full-frame modes still owe the caller the empty-FIFO background in every element of the window's slice
     const bool empty = n_win <= 0;
     if (empty && frame_mode == 0) return;
-    const WindowMeta m = meta[b];
+    const WindowMeta m = window_meta(bv, off, b);
     int x0 = 0, y0 = 0, Hf = H, Wf = W;
     if (!empty && (frame_mode == 0 || frame_mode == 1)) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
     if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
@@ -717,14 +946,21 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
     // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
     uint32_t cs = 0, ce = 0;
     const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
+    const Rec *sorted = bv.sorted;
+    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
     if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
-        const uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-        cs = co[ch_lo];
-        ce = co[ch_hi + 1];
+        if (bv.fused) {
+            const UnitRecs ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
+                                             row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w);
+            sorted = ur.sorted; cs = ur.cs; ce = ur.ce; r0 = ur.r0;
+        } else {
+            const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+            cs = co[ch_lo];
+            ce = co[ch_hi + 1];
+            if ((int)threadIdx.x < (int)(ce - cs)) r0 = sorted[cs + threadIdx.x];
+        }
     }
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if ((int)threadIdx.x < (int)(ce - cs)) r0 = sorted[cs + threadIdx.x];
     // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
     const double log_min = log(151.0);
     const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
@@ -784,16 +1020,14 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, con
 //         52-108): the bilinear weight is taken from the INTEGER bin (:74), so the lower bin receives p
 //         and the upper bin an exact zero -- a signed event count per (time bin, y, x).
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
-                                                const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, int span, int bins, int mode, double scale,
                                                 const int64_t *__restrict__ t_range, double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<double> w(smem, bins, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const int64_t beg = off[g.b];
     const int64_t n_win = off[g.b + 1] - beg;
     double t0 = 0.0, den = 1.0;
@@ -842,7 +1076,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, co
             for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
         }
     };
-    emit_chunk<double, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, r0, reduce);
+    emit_chunk<double, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -857,18 +1091,17 @@ struct PolStatParams {
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
 // (6 waves per SIMD asked for: 110 -> 80 VGPRs with 52 bytes of scratch, 81 -> 64 us at 32 x 50 000 events, 640x480x6;
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
-__global__ __launch_bounds__(kWave, 6) void k_polstats(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+__global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, int span,
                                                    float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = P.C;
     WaveLds<float> w(smem, C, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if (lane < (int)(g.ce - g.cs)) r0 = sorted[g.cs + lane];
     const double *tw = tnorm + off[g.b];
     // empty pixels: 0, except EXP channels = exp(-(1 - 0)/tau)  (imagenet.py:463,466)
     bool any_bg = false;
@@ -920,7 +1153,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(const Rec *__restrict__ s
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -947,17 +1180,16 @@ __device__ inline float est_value(float u, const double *__restrict__ seg, const
 }
 
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's float32 t / t.max().
-__global__ __launch_bounds__(kWave) void k_est(const Rec *__restrict__ sorted, const uint32_t *__restrict__ chunk_off,
+__global__ __launch_bounds__(kWave) void k_est(BinView bv,
                                               const int64_t *__restrict__ off, const float *__restrict__ tnorm,
                                               const double *__restrict__ seg, const uint32_t *__restrict__ bucket,
                                               EstParams P, int H, int W, int nchunk, int span, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C2 = 2 * P.C;
     WaveLds<float> w(smem, C2, span * kChunkPx);
-    const ChunkGeom g = chunk_geom(chunk_off, H, W, nchunk, span);
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
-    if ((int)threadIdx.x < (int)(g.ce - g.cs)) r0 = sorted[g.cs + threadIdx.x];
     const float *tw = tnorm + off[g.b];
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
         float lo_half[kEstMaxBins], hi_half[kEstMaxBins];
@@ -986,7 +1218,7 @@ __global__ __launch_bounds__(kWave) void k_est(const Rec *__restrict__ sorted, c
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, u.r0, reduce);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -153,9 +153,23 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     plan->nblk = (int32_t)nblk;
     plan->nchunk = (W + kChunkPx - 1) / kChunkPx;
     plan->reserved = two_kernel ? 1 : 0;
+    // the key-sorted pass (k_block_keysort alone; the builder waves finish the order): sparse windows -- a builder
+    // unit holds <= 30 records on average, so practically every unit is ordered in one 64-lane batch -- on sensors
+    // whose key table fits next to the record stage
+    const int64_t NK = (int64_t)H * plan->nchunk;
+    const bool key_sorted = two_kernel && NK < 65535 &&
+                            block_keysort_lds_bytes((int)NK, 4096) + 1024 <= 160 * 1024 &&
+                            ((double)max_events_per_window <= 30.0 * (double)NK || getenv("EVREP_BIN_KEY_SORTED")) &&
+                            !getenv("EVREP_BIN_CLASSIC") &&
+                            !getenv("EVREP_BIN_THREE_KERNEL");
+    size_t table_words = (size_t)B * nblk * (H + 1);
+    if (key_sorted) {
+        plan->reserved = 2;
+        table_words = (size_t)B * nblk * ((size_t)NK + 1);
+    }
     size_t o = 0;
     plan->off_meta = o;    o += up256((size_t)B * sizeof(WindowMeta));
-    plan->off_table = o;   o += up256((size_t)B * nblk * (H + 1) * sizeof(uint32_t));
+    plan->off_table = o;   o += up256(table_words * sizeof(uint32_t));
     plan->off_stats = o;   o += up256((size_t)B * nblk * sizeof(BlockStats));
     plan->off_rowoff = o;  o += up256((size_t)B * (H + 1) * sizeof(uint32_t));
     plan->off_chunkoff = o; o += up256((size_t)B * H * (plan->nchunk + 1) * sizeof(uint32_t));
@@ -193,6 +207,23 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     Rec *s2 = WS(Rec, off_sorted2);
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
+    if (plan->reserved == 2) {
+        if (chunk != kBsChunk || nblk > kBsMaxBlocks) return EVREP_EINVAL;
+        const int NK = H * plan->nchunk;
+        const int cap = block_keysort_lds_bytes(NK, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096;
+        static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
+        if (!attr_set) {
+            int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
+                                "hipFuncSetAttribute(k_block_keysort)");
+            if (rc2) return rc2;
+            attr_set = true;
+        }
+        k_block_keysort<<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap), stream>>>(
+            ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+        LAUNCH_CHECK("k_block_keysort");
+        return EVREP_OK;
+    }
     if (plan->reserved == 1) {
         if (chunk != kBsChunk || nblk > kBsMaxBlocks) return EVREP_EINVAL;
         const size_t lds = block_rowsort_lds_bytes(H);
@@ -209,7 +240,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
         k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
-            s1, offsets, table, stats, H, W, nblk, plan->nchunk, s2, WS(uint32_t, off_chunkoff), meta);
+            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
     }
@@ -232,6 +263,33 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
 }
 
 #define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
+
+// what the builders read of the binning pass (see BinView in evrep_builders.hip)
+static BinView bin_view(const evrep_plan *plan, void *workspace) {
+    BinView bv;
+    bv.fused = plan->reserved == 2 ? 1 : 0;
+    bv.sorted = bv.fused ? CWS(Rec, off_sorted1) : CWS(Rec, off_sorted2);
+    bv.chunk_off = CWS(uint32_t, off_chunkoff);
+    bv.table = CWS(uint32_t, off_table);
+    bv.stats = CWS(BlockStats, off_stats);
+    bv.meta = CWS(WindowMeta, off_meta);
+    bv.spill = WS(Rec, off_sorted2);
+    bv.nblk = plan->nblk;
+    return bv;
+}
+
+// After the key-sorted pass: the pixel-sorted stream + chunk offsets + WindowMeta, for the consumers that walk
+// them directly (k_voxel_subpixel).  The column sort of the two-kernel pass, reading a row's runs chunk by chunk.
+static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
+    if (plan->reserved != 2) return EVREP_OK;
+    constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
+    k_col_sort_runs<kCsRowsPerWave><<<dim3((plan->H + rows_per_wg - 1) / rows_per_wg, plan->B), kCsWaves * kWave,
+                                      (size_t)kCsWaves * col_sort_wave_words(plan->W) * 4, stream>>>(
+        CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
+        plan->nchunk, plan->nchunk, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
+    LAUNCH_CHECK("k_col_sort_runs");
+    return EVREP_OK;
+}
 
 // 128-pixel chunks one builder wave takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on sparse windows (<= 30 records per
 // chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel fast path), else 1.
@@ -261,7 +319,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     const int span = builder_span(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
 #define MDES_LAUNCH(T, DESC)                                                                                          \
     k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx), stream>>>(                              \
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, CWS(WindowMeta, off_meta), P, plan->H, plan->W,  \
+        bin_view(plan, workspace), offsets, P, plan->H, plan->W,  \
         plan->nchunk, span, scale, static_cast<T *>(out))
 #define MDES_RUNTIME(T)                                     \
     do {                                                    \
@@ -296,7 +354,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)stack_size * 4);
     k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx), stream>>>(
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
+        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
         premap, scale, out);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
@@ -315,12 +373,12 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
         k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8, kChunkPx), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
+            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
         const int span = builder_span(plan, (size_t)2 * slices * 4);
         k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4, span * kChunkPx), stream>>>(
-            CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
+            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
             premap, scale, static_cast<float *>(out));
     }
     LAUNCH_CHECK("k_time_surface");
@@ -342,8 +400,8 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)2 * k * 4);
     k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx), stream>>>(
-        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets,
-        CWS(WindowMeta, off_meta), sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, span, k, frame_mode,
+        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets,
+        sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, span, k, frame_mode,
         scale, out);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
@@ -363,7 +421,7 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)bins * 8);
     k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx), stream>>>(
-        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, plan->H,
+        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, plan->H,
         plan->W, plan->nchunk, span, bins, mode, scale, t_range, out);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
@@ -376,6 +434,8 @@ int evrep_voxel_subpixel(const evrep_plan *plan, const int32_t *events, const in
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || !out || (plan->total_events > 0 && !xy)) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const dim3 grid((unsigned)(((size_t)plan->H * plan->W + kThreads - 1) / kThreads), (unsigned)plan->B);
+    rc = ensure_column_sorted(plan, offsets, workspace, stream);
+    if (rc) return rc;
     k_voxel_subpixel<<<grid, kThreads, 0, stream>>>(reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2),
                                                    CWS(uint32_t, off_chunkoff), offsets, xy, plan->H, plan->W, plan->nchunk,
                                                    bins, t_range, out);
@@ -403,7 +463,7 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)C * 4);
     k_polstats<<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx), stream>>>(
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, span, out);
+        bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, span, out);
     LAUNCH_CHECK("k_polstats");
     return EVREP_OK;
 }
@@ -423,7 +483,7 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int span = builder_span(plan, (size_t)2 * C * 4);
     k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx), stream>>>(
-        CWS(Rec, off_sorted2), CWS(uint32_t, off_chunkoff), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
+        bin_view(plan, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, span, out);
     LAUNCH_CHECK("k_est");
     return EVREP_OK;
@@ -433,6 +493,14 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
 static int read_meta_field(const evrep_plan *plan, const void *workspace, size_t field_off, size_t field_bytes,
                            void *dst, hipStream_t stream) {
     const char *meta = static_cast<const char *>(workspace) + plan->off_meta;
+    if (plan->reserved == 2) {  // the key-sorted pass leaves the block statistics unmerged: merge them now
+        char *ws = const_cast<char *>(static_cast<const char *>(workspace));
+        k_window_meta<<<plan->B, kWave, 0, stream>>>(reinterpret_cast<const int64_t *>(ws + plan->off_rowoff),
+                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk,
+                                                     reinterpret_cast<WindowMeta *>(ws + plan->off_meta));
+        int rc0 = hip_check(hipGetLastError(), "k_window_meta");
+        if (rc0) return rc0;
+    }
     int rc = hip_check(hipMemcpy2DAsync(dst, field_bytes, meta + field_off, sizeof(WindowMeta), field_bytes,
                                         (size_t)plan->B, hipMemcpyDeviceToHost, stream), "hipMemcpy2DAsync(meta)");
     if (rc) return rc;

@@ -93,11 +93,13 @@ def test_window_sizes_around_partition_blocks(oracle):
 
 @pytest.mark.parametrize("sizes", [(8191, 8192, 8193), (16 * 8192, 16 * 8192 + 1), (17 * 8192 - 5, 40000),
                                    (64 * 8192, 3), (64 * 8192 + 1, 9000)])
-def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes):
+def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes, monkeypatch):
     """The two-kernel binning pass: 8192-event workgroup blocks, <= 16 block runs per row found by a readlane chain,
     17..64 by the LDS search, more than 64 x 8192 events per window -> the three-kernel pass.  Every size next to a
-    short window in the same batch; ERGO-12 / EventStack / voxel bit-exact vs the oracle."""
+    short window in the same batch; ERGO-12 / EventStack / voxel bit-exact vs the oracle.
+    (EVREP_BIN_CLASSIC keeps the key-sorted pass, tests/test_gpu_key_sorted.py, out of the choice.)"""
     from event_representation_study_amd import engine as eng
+    monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
     H, W = 36, 200
     wins = [make_events(n, W, H, seed=n % 1000 + 3) for n in sizes]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -112,10 +114,11 @@ def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes):
 
 
 @pytest.mark.parametrize("H", [880, 882, 1200])
-def test_tall_sensors_around_the_lds_limit_of_the_row_sort(oracle, H):
+def test_tall_sensors_around_the_lds_limit_of_the_row_sort(oracle, H, monkeypatch):
     """k_block_rowsort keeps 16 x H packed row counters next to its 128 KB record stage: sensors of up to ~881 rows
     take the two-kernel pass, taller ones the three-kernel pass; same tensors either way."""
     from event_representation_study_amd import engine as eng
+    monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
     W = 70
     wins = [make_events(30000, W, H, seed=H), make_events(100, W, H, seed=H + 1)]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -131,6 +134,7 @@ def test_three_kernel_binning_pass_still_agrees(oracle, monkeypatch):
     from event_representation_study_amd import engine as eng
     H, W = 120, 160
     wins = [make_events(20000, W, H, seed=5), make_events(9000, W, H, seed=6, polarity="01")]
+    monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
     a = eng.EventBatch.from_numpy(wins, H, W)
     monkeypatch.setenv("EVREP_BIN_THREE_KERNEL", "1")
     b = eng.EventBatch.from_numpy(wins, H, W)

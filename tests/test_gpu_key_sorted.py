@@ -1,0 +1,200 @@
+"""The key-sorted binning pass (plan.reserved == 2: k_block_keysort alone, the builder waves gather their unit's records
+from the block runs and finish the order by pixel, evrep_bin.hip / evrep_builders.hip unit_records) against the oracle
+and against the classic passes (EVREP_BIN_CLASSIC), bit for bit.
+
+EVREP_BIN_KEY_SORTED forces the pass for windows denser than the 30-records-per-unit average it is chosen for, which
+exercises the spill layout (units of more than 64 records) on every builder."""
+import numpy as np
+import pytest
+import torch
+
+from event_representation_study_amd.synthetic import make_events
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_bit_equal(a, b, msg):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, "%s: %s %s vs %s %s" % (msg, a.shape, a.dtype, b.shape, b.dtype)
+    assert np.array_equal(a, b, equal_nan=True), "%s: %d elements differ" % (msg, int((a != b).sum()))
+
+
+def _batches(eng, wins, H, W, monkeypatch, force=True):
+    """the same windows under the key-sorted pass and under the classic pass"""
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    if force:
+        monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
+    ks = eng.EventBatch.from_numpy(wins, H, W)
+    monkeypatch.delenv("EVREP_BIN_KEY_SORTED", raising=False)
+    monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
+    cl = eng.EventBatch.from_numpy(wins, H, W)
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    assert ks.plan.reserved == 2 and cl.plan.reserved in (0, 1)
+    return ks, cl
+
+
+def _builders(eb, rng_seed=0):
+    g = torch.Generator(device="cpu").manual_seed(rng_seed)
+    tn = torch.rand(eb.total, dtype=torch.float64, generator=g).to("cuda:0")
+    out = {
+        "ergo12": eb.optimized(),
+        "ergo12_f32": eb.optimized(dtype=torch.float32),
+        "mdes": eb.mdes([0, 3, 5, 1, 6], [0, 6, 1, 3, 4], [1, 0, 3, 2, 3]),
+        "event_stack": eb.event_stack(),
+        "time_surface": eb.time_surface(),
+        "time_surface_f32": eb.time_surface(dtype=torch.float32),
+        "tore_full": eb.tore(6, frame_mode=2),
+        "tore_shift": eb.tore(4, frame_mode=1),
+        "voxel5": eb.voxel(5),
+        "voxel_evl": eb.voxel(7, mode=2),
+        "polstats": eb.polstats(tn, [1, 2, 1, 2, 0, 0], [0, 0, 1, 2, 4, 5]),
+    }
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    out["tore_bbox"] = [t.cpu().numpy() for t in eb.tore(6, frame_mode=0)]
+    return out
+
+
+def _same(a, b, tag):
+    for k in a:
+        if isinstance(a[k], list):
+            for i, (x, y) in enumerate(zip(a[k], b[k])):
+                assert_bit_equal(x, y, "%s %s[%d]" % (tag, k, i))
+        else:
+            assert_bit_equal(a[k], b[k], "%s %s" % (tag, k))
+
+
+@pytest.mark.parametrize("geom", [(48, 64, (3000, 900, 1)), (30, 200, (20000, 64, 65)), (480, 640, (50000, 49999, 12345)),
+                                  (240, 304, (10000, 70000)), (5, 129, (4000, 130))])
+def test_every_builder_matches_the_classic_pass(geom, monkeypatch):
+    from event_representation_study_amd import engine as eng
+    H, W, sizes = geom
+    wins = [make_events(n, W, H, seed=11 * i + n % 97, polarity="pm1" if i % 2 == 0 else "01", dup_last=(3 if n > 10 else 0))
+            for i, n in enumerate(sizes)]
+    ks, cl = _batches(eng, wins, H, W, monkeypatch)
+    _same(_builders(ks), _builders(cl), "%dx%d" % (W, H))
+    np.testing.assert_array_equal(ks.status(), cl.status())
+    np.testing.assert_array_equal(ks.bbox(), cl.bbox())
+
+
+def test_the_pass_is_chosen_for_the_headline_windows_and_matches_the_oracle(oracle, monkeypatch):
+    """640x480, 50 000 events per window (BASELINE config 2): chosen without being forced; ERGO-12, EventStack, voxel
+    bit-exact vs the oracle."""
+    from event_representation_study_amd import engine as eng
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    monkeypatch.delenv("EVREP_BIN_KEY_SORTED", raising=False)
+    H, W = 480, 640
+    wins = [make_events(50000, W, H, seed=900 + i, polarity="pm1" if i else "01") for i in range(3)]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    assert eb.plan.reserved == 2
+    got, es, vx = eb.optimized().cpu().numpy(), eb.event_stack().cpu().numpy(), eb.voxel(5).cpu().numpy()
+    for b, ev in enumerate(wins):
+        assert_bit_equal(got[b], oracle.ergo12(ev, H, W), "ergo12 w%d" % b)
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event stack w%d" % b)
+        assert_bit_equal(vx[b], oracle.voxel(ev, H, W, 5), "voxel w%d" % b)
+    assert not eb.status().any()
+    # a dense window of the same sensor keeps the classic pass
+    assert eng.EventBatch.from_numpy([make_events(200000, W, H, seed=1)], H, W).plan.reserved == 1
+
+
+def test_gen4_sensor_two_round_stage(oracle, monkeypatch):
+    """1280x720 (BASELINE config 3): 7200 keys leave room for a 4096-record stage, the block is written in two rounds."""
+    from event_representation_study_amd import engine as eng
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    H, W = 720, 1280
+    wins = [make_events(200000, W, H, seed=31), make_events(8000, W, H, seed=32, polarity="01")]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    assert eb.plan.reserved == 2
+    got, es = eb.optimized().cpu().numpy(), eb.event_stack().cpu().numpy()
+    tf = eb.tore(6, frame_mode=2).cpu().numpy()
+    for b, ev in enumerate(wins):
+        assert_bit_equal(got[b], oracle.ergo12(ev, H, W), "ergo12 w%d" % b)
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event stack w%d" % b)
+        want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
+        np.testing.assert_allclose(tf[b], want, rtol=1e-6, atol=1e-6)
+
+
+def test_hot_pixels(oracle, monkeypatch):
+    """A pixel that fires thousands of times: one key group of the block sort holds most of a block (its members are
+    put in time order by counting smaller ranks), the builder unit spills; a second hot pixel sits in the last chunk."""
+    from event_representation_study_amd import engine as eng
+    H, W = 60, 300
+    rng = np.random.default_rng(5)
+    wins = []
+    for n, hot in ((30000, 9000), (9000, 8500)):
+        ev = make_events(n, W, H, seed=n)
+        idx = np.sort(rng.choice(n, hot, replace=False))
+        ev[idx[: hot // 2], 0], ev[idx[: hot // 2], 1] = 17, 33
+        ev[idx[hot // 2:], 0], ev[idx[hot // 2:], 1] = W - 1, H - 1
+        wins.append(ev)
+    ks, cl = _batches(eng, wins, H, W, monkeypatch)
+    a, b = _builders(ks), _builders(cl)
+    _same(a, b, "hot")
+    for i, ev in enumerate(wins):
+        assert_bit_equal(a["ergo12"][i], oracle.ergo12(ev, H, W), "hot ergo12 w%d" % i)
+        assert_bit_equal(a["event_stack"][i], oracle.event_stack(ev, H, W), "hot event stack w%d" % i)
+
+
+@pytest.mark.parametrize("n", [17 * 8192 - 3, 40 * 8192 + 11, 64 * 8192])
+def test_many_block_runs(oracle, n, monkeypatch):
+    """More than 16 block runs per window: the builder waves find a record's run by the LDS search."""
+    from event_representation_study_amd import engine as eng
+    H, W = 100, 260
+    wins = [make_events(n, W, H, seed=n % 1000), make_events(500, W, H, seed=3)]
+    ks, cl = _batches(eng, wins, H, W, monkeypatch)
+    for b, ev in enumerate(wins):
+        assert_bit_equal(ks.optimized()[b].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))
+    assert_bit_equal(ks.event_stack().cpu().numpy(), cl.event_stack().cpu().numpy(), "event stack")
+    assert_bit_equal(ks.tore(6, frame_mode=1).cpu().numpy(), cl.tore(6, frame_mode=1).cpu().numpy(), "tore")
+    # one event more than 64 blocks: the three-kernel pass, forced or not
+    monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
+    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 0
+
+
+def test_status_bbox_and_failed_channels(monkeypatch):
+    """Out-of-frame events (zeroed MDES channels, OOB status), an unsorted window, an empty one, flat time: the block
+    statistics merged by the builder waves / k_window_meta say what WindowMeta of the classic passes says."""
+    from event_representation_study_amd import engine as eng
+    H, W = 40, 150
+    a = make_events(5000, W, H, seed=1)
+    a[100, 0] = W + 7            # in-frame flat index, column outside [0, W)
+    a[4000, 1] = H + 3           # out of frame
+    a[4500, 0] = -5
+    b = make_events(3000, W, H, seed=2)
+    b[10, 2] = b[11, 2] + 5      # unsorted pair
+    c = make_events(700, W, H, seed=3)
+    c[:, 2] = 77                 # flat time
+    d = np.zeros((0, 4), dtype=np.int32)
+    e = make_events(2500, W, H, seed=4, polarity="01")
+    wins = [a, b, c, d, e]
+    ks, cl = _batches(eng, wins, H, W, monkeypatch)
+    np.testing.assert_array_equal(ks.status(), cl.status())
+    np.testing.assert_array_equal(ks.bbox(), cl.bbox())
+    assert_bit_equal(ks.optimized().cpu().numpy(), cl.optimized().cpu().numpy(), "ergo12 with failed channels")
+    assert_bit_equal(ks.event_stack().cpu().numpy(), cl.event_stack().cpu().numpy(), "event stack")
+    assert_bit_equal(ks.tore(6, frame_mode=2).cpu().numpy(), cl.tore(6, frame_mode=2).cpu().numpy(), "tore")
+
+
+def test_subpixel_voxel_gets_its_column_sorted_stream(monkeypatch):
+    """k_voxel_subpixel walks the pixel-sorted stream: after the key-sorted pass the column sort runs on demand."""
+    from event_representation_study_amd import engine as eng
+    H, W = 60, 200
+    wins = [make_events(6000, W, H, seed=8), make_events(300, W, H, seed=9)]
+    ks, cl = _batches(eng, wins, H, W, monkeypatch)
+    rng = np.random.default_rng(0)
+    xy = torch.from_numpy(np.concatenate([w[:, :2] for w in wins]).astype(np.float64) + rng.random((6300, 2)) * 0.99).to("cuda:0")
+    assert_bit_equal(ks.voxel_subpixel(xy, 5).cpu().numpy(), cl.voxel_subpixel(xy, 5).cpu().numpy(), "sub-pixel voxel")
+    # and the builders still read the key-sorted runs afterwards
+    assert_bit_equal(ks.optimized().cpu().numpy(), cl.optimized().cpu().numpy(), "ergo12 after the on-demand column sort")
+
+
+def test_rebinning_is_idempotent_and_deterministic(monkeypatch):
+    from event_representation_study_amd import engine as eng
+    H, W = 480, 640
+    wins = [make_events(50000, W, H, seed=40 + i) for i in range(4)]
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    assert eb.plan.reserved == 2
+    first = eb.optimized().clone()
+    for _ in range(20):
+        eb.rebin()
+        assert torch.equal(eb.optimized(), first)
