@@ -746,7 +746,7 @@ template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
-                                                                     int nchunk, int kpr, Rec *__restrict__ sorted2,
+                                                                     int nchunk, int kpr, int chunk, Rec *__restrict__ sorted2,
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
     extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
     uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);  // <= kBsMaxBlocks: one lane per block run
+    const int nb = (int)((n_win + chunk - 1) / chunk);  // <= kBsMaxBlocks: one lane per block run (chunk = events per block)
     // run k of row r = sorted1[beg + k*8192 + t_k[r], ... + t_k[r+1]); records of earlier rows = sum_k t_k[r]
     uint32_t t[R + 1];
 #pragma unroll
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }  // full wave
         pre[r] = incl - len;                                                            // this row's records in earlier blocks
         rs[r + 1] = rs[r] + (uint32_t)__builtin_amdgcn_readlane((int)incl, kBsMaxBlocks - 1);  // rows are contiguous in sorted2
-        src[r] = (uint32_t)beg + (uint32_t)lane * kBsChunk + t[r] - pre[r];            // record j of the row: src_k + j
+        src[r] = (uint32_t)beg + (uint32_t)lane * (uint32_t)chunk + t[r] - pre[r];            // record j of the row: src_k + j
     }
     // record j of row r lies in the run k with pre_k <= j < pre_{k+1}: a sum of conditional steps over the runs
     // (lanes >= nb hold pre = n, so they never match a j < n)
@@ -929,32 +929,39 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
 // windows; a group of g records costs g reads per member, so a hot pixel makes its own block slower, never
 // wrong).  Nothing depends on another workgroup.
 // =====================================================================================================
-__host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap) {
-    return (size_t)cap * sizeof(Rec) + (size_t)kBsChunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
+#ifndef KS_DEBUG
+#define KS_DEBUG 0  // timing experiments only (tools/ab): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
+#endif
+__host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int chunk) {
+    return (size_t)cap * sizeof(Rec) + (size_t)chunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
 }
 
-// grid (8 * ceil(B/8) * nblk), 1024 threads, dynamic LDS = block_keysort_lds_bytes(H * kpr, cap); cap = records
-// the stage holds (8192, or 4096 on sensors with many keys: the block is then written out in two rounds).
+// grid (8 * ceil(B/8) * nblk), TPB threads = TPB * 8 events per workgroup (1024 -> 8192, 512 -> 4096: windows of up to
+// 16 x 4096 events take the smaller block -- twice the workgroups, two or three resident per CU, half-size key
+// groups to repair), dynamic LDS = block_keysort_lds_bytes(H * kpr, cap, TPB * 8); cap = records the stage holds
+// (the block is written out in rounds of cap records).
 // table: [B][nblk][H * kpr + 1] exclusive offsets of the block's keys inside its run (last entry = in-frame events).
-__global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int kpr, int nblk, int cap,
                                                              uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
                                                              Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int kChunk = TPB * kBsPerLane, kNW = TPB / kWave;
     const int NK = H * kpr;
     Rec *stage = reinterpret_cast<Rec *>(smem_raw);                         // [cap], output order
-    uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kBsChunk] rank inside the block, arrival order
-    uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kBsChunk);      // [NK + 1] counts -> exclusive offsets
-    __shared__ BlockStats wstats[kBsWaves];
-    __shared__ uint32_t tmp[kBsWaves];
+    uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kChunk] rank inside the block, arrival order
+    uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kChunk);      // [NK + 1] counts -> exclusive offsets
+    __shared__ BlockStats wstats[kNW];
+    __shared__ uint32_t tmp[kNW];
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
     const int64_t n = off[b + 1] - beg;
-    const int64_t lo = (int64_t)blk * kBsChunk;
+    const int64_t lo = (int64_t)blk * kChunk;
     if (blk == 0 && threadIdx.x == 0) nwin[b] = n;  // for k_window_meta, which is not handed the offsets
     if (lo >= n) return;  // the builders only read the blocks a window really has
-    const int64_t hi = (lo + kBsChunk < n) ? lo + kBsChunk : n;
+    const int64_t hi = (lo + kChunk < n) ? lo + kChunk : n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wlo = lo + (int64_t)wave * (kBsPerLane * kWave);
     const int64_t whi = (wlo + kBsPerLane * kWave < hi) ? wlo + kBsPerLane * kWave : hi;
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__rest
             if (lane == 0 && r > 0) tprev[i] = ev[beg + r - 1].z;  // other lanes take it from their neighbour
         }
     }
-    for (int i = threadIdx.x; i <= NK; i += kBsThreads) base[i] = 0;
+    for (int i = threadIdx.x; i <= NK; i += TPB) base[i] = 0;
     __syncthreads();
     const MdesWindows mw = mdes_windows(n);
     uint32_t full = 0, part = 0;
@@ -1010,6 +1017,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__rest
             const uint32_t key = row * (uint32_t)kpr + (col >> 7);
             ko[i] = key | (atomicAdd(&base[key], 1u) << 16);
         }
+        if (KS_DEBUG & 4) continue;
         if (!cut) {
             if (__any(in && e[i].w == -1)) sneg |= memb_u;
         } else if (in && e[i].w == -1) {
@@ -1036,42 +1044,60 @@ __global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__rest
     if (lane == 0) wstats[wave] = st;
     __syncthreads();
     // exclusive scan over the key counters: `per` consecutive keys per thread
-    const int per = (NK + kBsThreads - 1) / kBsThreads;
+    const int per = (NK + TPB - 1) / TPB;
     const int k0 = (int)threadIdx.x * per;
     uint32_t local = 0;
     for (int k = 0; k < per; ++k) if (k0 + k < NK) local += base[k0 + k];
     uint32_t total;
-    uint32_t run = block_exclusive_scan<kBsWaves>(local, tmp, &total);
+    uint32_t run = block_exclusive_scan<kNW>(local, tmp, &total);
     for (int k = 0; k < per; ++k)
         if (k0 + k < NK) { const uint32_t c = base[k0 + k]; base[k0 + k] = run; run += c; }
     if (threadIdx.x == 0) {
         base[NK] = total;
         BlockStats t = wstats[0];
-        for (int w = 1; w < kBsWaves; ++w) stats_merge(t, wstats[w]);
+        for (int w = 1; w < kNW; ++w) stats_merge(t, wstats[w]);
         stats[(size_t)b * nblk + blk] = t;
     }
     __syncthreads();
     uint32_t *tb = table + ((size_t)b * nblk + blk) * ((size_t)NK + 1);
-    for (int k = threadIdx.x; k <= NK; k += kBsThreads) tb[k] = base[k];
+    if (!(KS_DEBUG & 8))
+        for (int k = threadIdx.x; k <= NK; k += TPB) tb[k] = base[k];
     // arrival order -> time order inside every key group
 #pragma unroll
     for (int i = 0; i < kBsPerLane; ++i)
         if (ko[i] != 0xffffffffu)
             rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(wave * (kBsPerLane * kWave) + i * kWave + lane);
     __syncthreads();
+    {
+        // the eight group walks of a lane advance together: eight independent LDS reads in flight per step instead of
+        // one dependent read per step (the walk is latency-bound: 8 -> 2 us per block on the headline windows)
+        uint32_t gb[kBsPerLane], g[kBsPerLane], sm[kBsPerLane];
+        uint32_t gmax = 0;
 #pragma unroll
-    for (int i = 0; i < kBsPerLane; ++i) {
-        if (ko[i] == 0xffffffffu) continue;
-        const uint32_t key = ko[i] & 0xffffu;
-        const uint32_t gb = base[key], g = base[key + 1] - gb;
-        const uint32_t mine = (uint32_t)(wave * (kBsPerLane * kWave) + i * kWave + lane);
-        uint32_t smaller = 0;
-        if (g > 1)
-            for (uint32_t j = 0; j < g; ++j) smaller += (uint32_t)rankbuf[gb + j] < mine ? 1u : 0u;
-        ko[i] = gb + smaller;
+        for (int i = 0; i < kBsPerLane; ++i) {
+            gb[i] = 0; g[i] = 0; sm[i] = 0;
+            if (ko[i] != 0xffffffffu) {
+                const uint32_t key = ko[i] & 0xffffu;
+                gb[i] = base[key];
+                g[i] = base[key + 1] - gb[i];
+                if (KS_DEBUG & 1) { sm[i] = ko[i] >> 16; g[i] = 0; }
+                if (g[i] == 1) g[i] = 0;  // alone in its group
+                gmax = max(gmax, g[i]);
+            }
+        }
+        gmax = (uint32_t)wave_max((int)gmax);
+        const uint32_t mine0 = (uint32_t)(wave * (kBsPerLane * kWave) + lane);
+        for (uint32_t j = 0; j < gmax; ++j) {
+#pragma unroll
+            for (int i = 0; i < kBsPerLane; ++i)
+                if (j < g[i]) sm[i] += (uint32_t)rankbuf[gb[i] + j] < mine0 + (uint32_t)(i * kWave) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < kBsPerLane; ++i)
+            if (ko[i] != 0xffffffffu) ko[i] = gb[i] + sm[i];
     }
     Rec *dst = sorted1 + beg + lo;
-    for (uint32_t pb = 0; pb < total; pb += (uint32_t)cap) {
+    for (uint32_t pb = 0; pb < total && !(KS_DEBUG & 2); pb += (uint32_t)cap) {
         if (pb) __syncthreads();  // the previous round has left the stage
 #pragma unroll
         for (int i = 0; i < kBsPerLane; ++i) {
@@ -1083,17 +1109,17 @@ __global__ __launch_bounds__(kBsThreads) void k_block_keysort(const int4 *__rest
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)cap, total - pb);
-        for (uint32_t t = threadIdx.x; t < cnt; t += kBsThreads) dst[pb + t] = stage[t];
+        for (uint32_t t = threadIdx.x; t < cnt; t += TPB) dst[pb + t] = stage[t];
     }
 }
 
 // grid (B), 64 threads: the window statistics of the key-sorted pass, for the synchronous read-backs only
 // (the builders merge the block statistics they need themselves).
 __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
-                                                      int nblk, WindowMeta *__restrict__ meta) {
+                                                      int nblk, int chunk, WindowMeta *__restrict__ meta) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t n_win = nwin[b];
-    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    const int nb = (int)((n_win + chunk - 1) / chunk);
     BlockStats st;
     stats_identity(st);
     for (int k = lane; k < nb; k += kWave) stats_merge(st, stats[(size_t)b * nblk + k]);

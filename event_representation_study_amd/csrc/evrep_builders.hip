@@ -162,7 +162,7 @@ struct BinView {
     const BlockStats *stats;    // key-sorted: [B][nblk]
     const WindowMeta *meta;     // classic: [B]
     Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
-    int nblk, fused;
+    int nblk, fused, chunk;     // chunk = events per block run
 };
 
 // The records of one unit, pixel-sorted: r0 = record `lane`; records >= kEvStage are read from sorted[cs + j].
@@ -219,7 +219,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    const int nb = (int)((n_win + bv.chunk - 1) / bv.chunk);
     if (nb <= 0 || khi <= klo) return u;
     uint32_t a = 0, len = 0;
     if (lane < nb) {
@@ -231,7 +231,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const uint32_t pre = incl - len;  // lanes >= nb: pre = nrec, never matched
     const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (nrec == 0) return u;
-    const uint32_t src = (uint32_t)beg + (uint32_t)lane * kBsChunk + a - pre;  // record j of the unit, if in run `lane`: src + j
+    const uint32_t src = (uint32_t)beg + (uint32_t)lane * (uint32_t)bv.chunk + a - pre;  // record j of the unit, if in run `lane`: src + j
     uint32_t *runs = reinterpret_cast<uint32_t *>(w.evbuf);  // [2][64], only when nb > kBsChainBlocks
     if (nb > kBsChainBlocks) {
         runs[lane] = pre;
@@ -386,7 +386,7 @@ __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__res
     if (!bv.fused) return bv.meta[b];
     const int lane = threadIdx.x;
     const int64_t n_win = off[b + 1] - off[b];
-    const int nb = (int)((n_win + kBsChunk - 1) / kBsChunk);
+    const int nb = (int)((n_win + bv.chunk - 1) / bv.chunk);
     BlockStats st;
     stats_identity(st);
     if (lane < nb) {

@@ -158,13 +158,22 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     // whose key table fits next to the record stage
     const int64_t NK = (int64_t)H * plan->nchunk;
     const bool key_sorted = two_kernel && NK < 65535 &&
-                            block_keysort_lds_bytes((int)NK, 4096) + 1024 <= 160 * 1024 &&
+                            block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
                             ((double)max_events_per_window <= 30.0 * (double)NK || getenv("EVREP_BIN_KEY_SORTED")) &&
                             !getenv("EVREP_BIN_CLASSIC") &&
                             !getenv("EVREP_BIN_THREE_KERNEL");
     size_t table_words = (size_t)B * nblk * (H + 1);
     if (key_sorted) {
         plan->reserved = 2;
+        // windows of <= 16 x 4096 events: 4096-event blocks (the builder waves still find a record's run by the
+        // 16-step readlane chain), twice the workgroups of the 8192-event blocks
+        if (max_events_per_window <= (int64_t)kBsChainBlocks * 4096 && !getenv("EVREP_KS_BIG_BLOCKS")) {
+            chunk = 4096;
+            nblk = (max_events_per_window + chunk - 1) / chunk;
+            if (nblk < 1) nblk = 1;
+            plan->chunk = (int32_t)chunk;
+            plan->nblk = (int32_t)nblk;
+        }
         table_words = (size_t)B * nblk * ((size_t)NK + 1);
     }
     size_t o = 0;
@@ -208,19 +217,29 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
     if (plan->reserved == 2) {
-        if (chunk != kBsChunk || nblk > kBsMaxBlocks) return EVREP_EINVAL;
+        if ((chunk != kBsChunk && chunk != 4096) || nblk > kBsMaxBlocks) return EVREP_EINVAL;
         const int NK = H * plan->nchunk;
-        const int cap = block_keysort_lds_bytes(NK, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096;
         static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
         if (!attr_set) {
-            int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort),
+            int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort<1024>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
                                 "hipFuncSetAttribute(k_block_keysort)");
+            if (!rc2) rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort<512>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
+                                      "hipFuncSetAttribute(k_block_keysort)");
             if (rc2) return rc2;
             attr_set = true;
         }
-        k_block_keysort<<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap), stream>>>(
-            ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+        if (chunk == 4096) {
+            // a 2048-record stage (two rounds) keeps the workgroup under 53 KB where the key table allows: three per CU
+            const int cap = block_keysort_lds_bytes(NK, 2048, 4096) <= 52 * 1024 ? 2048 : 4096;
+            k_block_keysort<512><<<xgrid, 512, block_keysort_lds_bytes(NK, cap, 4096), stream>>>(
+                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+        } else {
+            const int cap = block_keysort_lds_bytes(NK, kBsChunk, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096;
+            k_block_keysort<1024><<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap, kBsChunk), stream>>>(
+                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+        }
         LAUNCH_CHECK("k_block_keysort");
         return EVREP_OK;
     }
@@ -240,7 +259,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
         k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
-            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, s2, WS(uint32_t, off_chunkoff), meta);
+            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, kBsChunk, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
     }
@@ -275,6 +294,7 @@ static BinView bin_view(const evrep_plan *plan, void *workspace) {
     bv.meta = CWS(WindowMeta, off_meta);
     bv.spill = WS(Rec, off_sorted2);
     bv.nblk = plan->nblk;
+    bv.chunk = plan->chunk;
     return bv;
 }
 
@@ -286,7 +306,7 @@ static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, 
     k_col_sort_runs<kCsRowsPerWave><<<dim3((plan->H + rows_per_wg - 1) / rows_per_wg, plan->B), kCsWaves * kWave,
                                       (size_t)kCsWaves * col_sort_wave_words(plan->W) * 4, stream>>>(
         CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
-        plan->nchunk, plan->nchunk, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
+        plan->nchunk, plan->nchunk, plan->chunk, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
     LAUNCH_CHECK("k_col_sort_runs");
     return EVREP_OK;
 }
@@ -496,7 +516,7 @@ static int read_meta_field(const evrep_plan *plan, const void *workspace, size_t
     if (plan->reserved == 2) {  // the key-sorted pass leaves the block statistics unmerged: merge them now
         char *ws = const_cast<char *>(static_cast<const char *>(workspace));
         k_window_meta<<<plan->B, kWave, 0, stream>>>(reinterpret_cast<const int64_t *>(ws + plan->off_rowoff),
-                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk,
+                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk, plan->chunk,
                                                      reinterpret_cast<WindowMeta *>(ws + plan->off_meta));
         int rc0 = hip_check(hipGetLastError(), "k_window_meta");
         if (rc0) return rc0;
