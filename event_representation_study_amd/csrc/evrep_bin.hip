@@ -746,7 +746,7 @@ template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
-                                                                     int nchunk, int kpr, int chunk, Rec *__restrict__ sorted2,
+                                                                     int nchunk, int kpr, int chunk_shift, Rec *__restrict__ sorted2,
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
     extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
     uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)((n_win + chunk - 1) / chunk);  // <= kBsMaxBlocks: one lane per block run (chunk = events per block)
+    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);  // <= kBsMaxBlocks: one lane per block run of 1 << chunk_shift events
     // run k of row r = sorted1[beg + k*8192 + t_k[r], ... + t_k[r+1]); records of earlier rows = sum_k t_k[r]
     uint32_t t[R + 1];
 #pragma unroll
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }  // full wave
         pre[r] = incl - len;                                                            // this row's records in earlier blocks
         rs[r + 1] = rs[r] + (uint32_t)__builtin_amdgcn_readlane((int)incl, kBsMaxBlocks - 1);  // rows are contiguous in sorted2
-        src[r] = (uint32_t)beg + (uint32_t)lane * (uint32_t)chunk + t[r] - pre[r];            // record j of the row: src_k + j
+        src[r] = (uint32_t)beg + ((uint32_t)lane << chunk_shift) + t[r] - pre[r];            // record j of the row: src_k + j
     }
     // record j of row r lies in the run k with pre_k <= j < pre_{k+1}: a sum of conditional steps over the runs
     // (lanes >= nb hold pre = n, so they never match a j < n)
@@ -1116,10 +1116,10 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
 // grid (B), 64 threads: the window statistics of the key-sorted pass, for the synchronous read-backs only
 // (the builders merge the block statistics they need themselves).
 __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
-                                                      int nblk, int chunk, WindowMeta *__restrict__ meta) {
+                                                      int nblk, int chunk_shift, WindowMeta *__restrict__ meta) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t n_win = nwin[b];
-    const int nb = (int)((n_win + chunk - 1) / chunk);
+    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);
     BlockStats st;
     stats_identity(st);
     for (int k = lane; k < nb; k += kWave) stats_merge(st, stats[(size_t)b * nblk + k]);

@@ -35,9 +35,6 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #ifndef EVREP_XCD_MAP
 #define EVREP_XCD_MAP 1
 #endif
-#ifndef EVREP_SORT_EXPERIMENT
-#define EVREP_SORT_EXPERIMENT 0
-#endif
 #ifndef EVREP_NT_STORES
 #define EVREP_NT_STORES 1  // non-temporal output stores (the tensor is written once and never re-read by the step): -3 us on
                            // the ERGO-12 launch and -3 us on the next binning pass, whose loads find less of L2 evicted (r02)
@@ -45,6 +42,9 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
+// units wider than one chunk (two-chunk float32 units, TORE's shifted frame) hold ~65 records on the sparse windows
+// they are chosen for: their stage takes 128, so that the key-sorted front end orders them inside LDS
+__host__ __device__ inline int ev_stage(int segcap) { return segcap > kChunkPx ? 2 * kEvStage : kEvStage; }
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
 // average record count per chunk, see builder_span() in evrep_capi.hip.
@@ -55,13 +55,13 @@ struct WaveLds {
     OutT *tile;   // kPartPx * C elements, output layout (pixel-major, channel-minor)
     OutT *bg;     // EVREP_MAX_CHANNELS background values (the empty-pixel value of every channel)
     uint2 *segs;  // (pixel offset inside the chunk, first record index); entry nseg = sentinel
-    Rec *evbuf;   // the chunk's first kEvStage records
+    Rec *evbuf;   // the unit's first ev_stage(segcap) records (the classic front end fills the first kEvStage)
     int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
     __device__ WaveLds(unsigned char *smem, int C, int segcap_) : segcap(segcap_) {
         size_t o = 0;
         tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)kPartPx * C * sizeof(OutT));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
-        evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)kEvStage * sizeof(Rec);
+        evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)ev_stage(segcap_) * sizeof(Rec);
         segs = reinterpret_cast<uint2 *>(smem + o);
     }
 };
@@ -69,7 +69,7 @@ struct WaveLds {
 // segcap = pixels one unit can touch: span * kChunkPx (+ kChunkPx for TORE's shifted frame)
 __host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap) {
     return align16((size_t)kPartPx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
-           (size_t)kEvStage * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
+           (size_t)ev_stage(segcap) * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
 }
 
 // Ordering point between LDS phases of a ONE-WAVE workgroup.  LDS operations of a wave execute in
@@ -162,13 +162,15 @@ struct BinView {
     const BlockStats *stats;    // key-sorted: [B][nblk]
     const WindowMeta *meta;     // classic: [B]
     Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
-    int nblk, fused, chunk;     // chunk = events per block run
+    int nblk, fused, chunk_shift;  // events per block run = 1 << chunk_shift (a runtime 64-bit division costs ~130 scalar instructions)
 };
 
-// The records of one unit, pixel-sorted: r0 = record `lane`; records >= kEvStage are read from sorted[cs + j].
+// The records of one unit, pixel-sorted: r0 = record `lane`; records [0, nstaged) are in the wave's evbuf, later
+// ones are read from sorted[cs + j].
 struct UnitRecs {
     const Rec *sorted;
     uint32_t cs, ce;
+    int nstaged;
     Rec r0;
 };
 
@@ -181,6 +183,17 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
+}
+
+__device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
+    int x = (int)v;  // values are small non-negative run indices: signed max is fine, identity 0
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
     return (uint32_t)x;
 }
 
@@ -204,9 +217,11 @@ __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &c
 // runs are visited in block = time order and are time-ordered inside a key, so equal pixels stay in time order).
 //   * run k contributes table[k][klo] .. table[k][khi]; record j of the unit lies in the run whose exclusive
 //     length prefix covers j (a chain of conditional sums over <= 16 runs, an LDS search above);
-//   * <= kEvStage records (every unit of a sparse window, for which this pass is chosen): ONE load per lane, a
-//     counting sort over the unit's pixels in the wave's LDS (counters in the not-yet-used segment list), result
-//     in evbuf -- no HBM traffic beyond the one read of the record;
+//   * <= 64 records (practically every one-chunk unit of a sparse window, for which this pass is chosen): ONE load per
+//     lane, records grouped by pixel with a ballot match (emit_core does not need the groups in pixel order);
+//   * <= 128 records in a unit wider than one chunk: two loads per lane, a counting sort over the unit's pixels in
+//     the wave's LDS (counters in the not-yet-used segment list), result in evbuf -- in both cases no HBM traffic
+//     beyond the one read of the record;
 //   * more: the same counting sort in batches of 64, written to the unit's own slot of the spill stream (its
 //     position = records of the window with a smaller key = sum over the runs of table[k][klo]: disjoint slots,
 //     no atomics, idempotent across builders), then read back like the classic stream.
@@ -215,23 +230,27 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                                         int keybase, int npixu, WaveLds<OutT> &w) {
     const int lane = threadIdx.x;
     UnitRecs u;
-    u.sorted = bv.spill; u.cs = 0; u.ce = 0;
+    u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    const int64_t beg = off[b];
-    const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)((n_win + bv.chunk - 1) / bv.chunk);
-    if (nb <= 0 || khi <= klo) return u;
+    if (khi <= klo) return u;
+    // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
+    // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
     uint32_t a = 0, len = 0;
-    if (lane < nb) {
+    if (lane < bv.nblk) {
         const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
         a = tb[klo];
         len = tb[khi] - a;
     }
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const int nb = (int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift);
+    if (nb <= 0) return u;
+    if (lane >= nb) { a = 0; len = 0; }
     const uint32_t incl = wave_incl_scan(len);
     const uint32_t pre = incl - len;  // lanes >= nb: pre = nrec, never matched
     const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (nrec == 0) return u;
-    const uint32_t src = (uint32_t)beg + (uint32_t)lane * (uint32_t)bv.chunk + a - pre;  // record j of the unit, if in run `lane`: src + j
+    const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;  // record j of the unit, if in run `lane`: src + j
     uint32_t *runs = reinterpret_cast<uint32_t *>(w.evbuf);  // [2][64], only when nb > kBsChainBlocks
     if (nb > kBsChainBlocks) {
         runs[lane] = pre;
@@ -261,19 +280,68 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         return s1[runs[64 + lo] + j];
     };
     uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);  // npixu <= segcap counters: the segment list is built later
-    const int nbits = bits_for(npixu);
+    const int nbits = 32 - __builtin_clz((unsigned)npixu - 1u);  // npixu >= 128
     const int per4 = npixu / (4 * kWave) + ((npixu % (4 * kWave)) ? 1 : 0);  // npixu is a multiple of 128: 16-byte vectors per lane
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
-    if (nrec <= (uint32_t)kEvStage) {
-        const bool valid = lane < (int)nrec;
-        Rec r = u.r0;
-        if (valid) r = fetch((uint32_t)lane);
+    const int nstage = ev_stage(w.segcap);
+    if (nrec <= (uint32_t)nstage) {
+        // the whole unit is ordered inside LDS: up to two batches of 64 records, held in registers between the count
+        // and the placement
+        const bool two = nrec > (uint32_t)kWave;  // uniform
+        const bool v0 = lane < (int)nrec, v1 = lane + kWave < (int)nrec;
+        Rec r = u.r0, r1 = u.r0;
+        {
+            // the run of record j: every non-empty run writes its index at the position of its first record, an
+            // inclusive max-scan over the positions spreads it (a dozen LDS / DPP operations instead of a 3-instruction
+            // step per run and record)
+            uint32_t *head = cnt + w.segcap;                            // [128], behind the pixel counters
+            uint32_t *srcs = reinterpret_cast<uint32_t *>(w.evbuf);     // [64]
+            head[lane] = 0u;
+            if (two) head[lane + kWave] = 0u;
+            srcs[lane] = src;
+            wave_phase();
+            if (lane < nb && len > 0u && pre < (uint32_t)nstage) head[pre] = (uint32_t)lane;
+            wave_phase();
+            const uint32_t k0 = wave_incl_max_scan(head[lane]);
+            if (v0) r = s1[srcs[k0] + (uint32_t)lane];
+            if (two) {
+                const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k0, 63);
+                const uint32_t k1 = max(carry, wave_incl_max_scan(head[lane + kWave]));
+                if (v1) r1 = s1[srcs[k1] + (uint32_t)(lane + kWave)];
+            }
+            wave_phase();   // srcs lives in evbuf: read before the placement below writes it
+        }
         u.ce = nrec;
-        if (nrec == 1) { u.r0 = r; return u; }
+        u.nstaged = (int)nrec;
+        if (nrec == 1) { if (lane == 0) w.evbuf[0] = r; u.r0 = r; return u; }
+        const uint32_t px = v0 ? (uint32_t)(r.x - keybase) : 0u;
+        if (!two) {
+            // one batch: the records only have to be GROUPED by pixel, in time order inside a pixel -- emit_core gives a
+            // unit of <= 64 segments one lane per segment whatever their order.  The ballot match yields every record's
+            // group (the lanes holding its pixel); a group's place = the sizes of the groups whose first lane comes
+            // earlier (one DPP scan over the first lanes, fetched by the others through the LDS crossbar).  No counters.
+            uint64_t mask = __ballot(v0);
+            for (int bit = 0; bit < nbits; ++bit) {
+                const bool on = (px >> bit) & 1u;
+                const uint64_t bal = __ballot(on);
+                mask &= on ? bal : ~bal;
+            }
+            const uint32_t rk = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t size = (v0 && rk == 0u) ? (uint32_t)__popcll(mask) : 0u;
+            const uint32_t goff = wave_incl_scan(size) - size;
+            const int first = v0 ? (int)__builtin_ctzll(mask) : lane;
+            const uint32_t pos = (uint32_t)__shfl((int)goff, first, 64) + rk;
+            if (v0) w.evbuf[pos] = r;
+            wave_phase();
+            if (v0) r = w.evbuf[lane];
+            u.r0 = r;
+            return u;
+        }
         for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
         wave_phase();
-        const uint32_t px = valid ? (uint32_t)(r.x - keybase) : 0u;
-        if (valid) atomicAdd(&cnt[px], 1u);
+        const uint32_t px1 = v1 ? (uint32_t)(r1.x - keybase) : 0u;
+        if (v0) atomicAdd(&cnt[px], 1u);
+        if (v1) atomicAdd(&cnt[px1], 1u);
         wave_phase();
         // exclusive scan over the pixel counters: 16-byte vectors, `per4` consecutive ones per lane
         {
@@ -296,16 +364,20 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
         wave_phase();
         uint32_t rk; bool last;
-        wave_match(px, nbits, valid, lane, rk, last);
-        wave_phase();   // the run table (if any) shares evbuf: every fetch is done
-        if (valid) w.evbuf[cnt[px] + rk] = r;
+        wave_match(px, nbits, v0, lane, rk, last);
+        uint32_t pos = 0;
+        if (v0) { pos = cnt[px] + rk; w.evbuf[pos] = r; }
+        wave_phase();   // the second batch goes behind the first inside every pixel
+        if (v0 && last) cnt[px] = pos + 1;
         wave_phase();
-        if (valid) r = w.evbuf[lane];
+        wave_match(px1, nbits, v1, lane, rk, last);
+        if (v1) w.evbuf[cnt[px1] + rk] = r1;
         wave_phase();
+        if (v0) r = w.evbuf[lane];
         u.r0 = r;
         return u;
     }
-    // a unit of more than kEvStage records: laid out in its slot of the spill stream
+    // a unit of more records than the stage holds: laid out in its slot of the spill stream
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase();
@@ -354,7 +426,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     u.cs = cs;
     u.ce = cs + nrec;
-    u.r0 = bv.spill[cs + lane];  // nrec > kEvStage = 64: every lane has one
+    u.r0 = bv.spill[cs + lane];  // nrec > 64: every lane has one
     return u;
 }
 
@@ -374,7 +446,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     g.cs = co[chunk];
     g.ce = co[min(chunk + span, nchunk)];
     UnitRecs u;
-    u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce;
+    u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
     return u;
@@ -386,7 +458,7 @@ __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__res
     if (!bv.fused) return bv.meta[b];
     const int lane = threadIdx.x;
     const int64_t n_win = off[b + 1] - off[b];
-    const int nb = (int)((n_win + bv.chunk - 1) / bv.chunk);
+    const int nb = (int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift);
     BlockStats st;
     stats_identity(st);
     if (lane < nb) {
@@ -503,45 +575,18 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
     }
 }
 
-// emit_core over a chunk of the column-sorted stream: `r0` = record `lane` of the chunk, loaded by the
-// caller before its own independent loads; the first kEvStage records are staged in LDS.
+// emit_core over a unit's pixel-sorted records: u.r0 = record `lane`, records [0, u.nstaged) come from the wave's LDS
+// stage, later ones from u.sorted[u.cs + j].
 template <typename OutT, int CMAX, typename Reduce>
-__device__ inline void emit_chunk(const Rec *__restrict__ sorted, uint32_t cs, uint32_t ce, int key0, int npix, int C,
-                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Rec r0, Reduce reduce) {
-    const uint32_t nrec = ce - cs;
-#if EVREP_SORT_EXPERIMENT
-    // cost probe (r02): what an in-wave stable sort of the chunk's <= 64 records by pixel would add to every builder
-    // wave if the column level of the binning pass were dropped (the records ARE sorted here, so the result is the same)
-    if (nrec && nrec <= (uint32_t)kWave) {
-        const int lane = threadIdx.x;
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(w.tile);   // 256 words of the not-yet-filled tile
-        reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        wave_phase();
-        const bool valid = lane < (int)nrec;
-        const uint32_t px = valid ? (uint32_t)(r0.x - key0) & 255u : 0u;
-        if (valid) atomicAdd(&cnt[px], 1u);
-        wave_phase();
-        const uint4 c4 = reinterpret_cast<uint4 *>(cnt)[lane];
-        const uint32_t local = c4.x + c4.y + c4.z + c4.w;
-        uint32_t incl = local;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        uint4 o4;
-        o4.x = incl - local; o4.y = o4.x + c4.x; o4.z = o4.y + c4.y; o4.w = o4.z + c4.z;
-        reinterpret_cast<uint4 *>(cnt)[lane] = o4;
-        wave_phase();
-        uint32_t rk; bool last;
-        wave_match(px, 8, valid, lane, rk, last);
-        if (valid) w.evbuf[cnt[px] + rk] = r0;
-        wave_phase();
-        if (valid) r0 = w.evbuf[lane];
-        wave_phase();
-    }
-#endif
-    if (nrec) w.evbuf[threadIdx.x] = r0;
+__device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
+                                  const OutT *bg, Reduce reduce) {
+    const uint32_t nrec = u.ce - u.cs, cs = u.cs, nstaged = (uint32_t)u.nstaged;
+    const Rec r0 = u.r0;
+    const Rec *__restrict__ sorted = u.sorted;
+    if (nrec) w.evbuf[threadIdx.x] = r0;  // (the key-sorted front end has already staged the unit: the same values)
     const Rec *evbuf = w.evbuf;
-    auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : sorted[cs + j].x; };
-    auto get = [&](uint32_t j) -> Rec { return j < (uint32_t)kEvStage ? evbuf[j] : sorted[cs + j]; };
+    auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nstaged ? evbuf[j].x : sorted[cs + j].x); };
+    auto get = [&](uint32_t j) -> Rec { return j < nstaged ? evbuf[j] : sorted[cs + j]; };
     emit_core<OutT, CMAX>(nrec, key_at, get, key0, npix, C, dst, w, bg, reduce);
 }
 
@@ -712,7 +757,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
             vals[c] = (OutT)(r * scale);
         }
     };
-    emit_chunk<OutT, D::kMaxC>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, u.r0, reduce);
+    emit_chunk<OutT, D::kMaxC>(u, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -744,7 +789,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
 #pragma unroll
         for (int l = 0; l < EVREP_MAX_CHANNELS; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, u.r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -844,7 +889,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 }
 
 template <typename OutT>
-__global__ __launch_bounds__(kWave) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int span,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -904,7 +949,7 @@ __global__ __launch_bounds__(kWave) void k_time_surface(BinView bv, const int64_
             vals[2 * q + 1] = v1;
         }
     };
-    emit_chunk<OutT, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, u.r0, reduce);
+    emit_chunk<OutT, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -944,21 +989,20 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
     const double *tw = tf ? tf + beg : nullptr;
     const double Td = (tf && !empty) ? (sample_times_f ? sample_times_f[b] : tw[n_win - 1]) : 0.0;
     // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
-    uint32_t cs = 0, ce = 0;
     const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
-    const Rec *sorted = bv.sorted;
-    Rec r0 = make_int4(INT32_MIN, 0, 0, 0);
+    UnitRecs ur;
+    ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
+    ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
     if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
         if (bv.fused) {
-            const UnitRecs ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
-                                             row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w);
-            sorted = ur.sorted; cs = ur.cs; ce = ur.ce; r0 = ur.r0;
+            ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
+                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w);
         } else {
             const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-            cs = co[ch_lo];
-            ce = co[ch_hi + 1];
-            if ((int)threadIdx.x < (int)(ce - cs)) r0 = sorted[cs + threadIdx.x];
+            ur.cs = co[ch_lo];
+            ur.ce = co[ch_hi + 1];
+            if ((int)threadIdx.x < (int)(ur.ce - ur.cs)) ur.r0 = ur.sorted[ur.cs + threadIdx.x];
         }
     }
     // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
@@ -1010,7 +1054,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
             }
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(sorted, cs, ce, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(ur, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1076,7 +1120,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
             for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
         }
     };
-    emit_chunk<double, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, u.r0, reduce);
+    emit_chunk<double, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1153,7 +1197,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C, dst, w, bg, u.r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1218,7 +1262,7 @@ __global__ __launch_bounds__(kWave) void k_est(BinView bv,
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u.sorted, g.cs, g.ce, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, u.r0, reduce);
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------

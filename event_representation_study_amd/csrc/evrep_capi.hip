@@ -259,7 +259,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
         k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
-            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, kBsChunk, s2, WS(uint32_t, off_chunkoff), meta);
+            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
     }
@@ -294,7 +294,7 @@ static BinView bin_view(const evrep_plan *plan, void *workspace) {
     bv.meta = CWS(WindowMeta, off_meta);
     bv.spill = WS(Rec, off_sorted2);
     bv.nblk = plan->nblk;
-    bv.chunk = plan->chunk;
+    bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
     return bv;
 }
 
@@ -306,7 +306,7 @@ static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, 
     k_col_sort_runs<kCsRowsPerWave><<<dim3((plan->H + rows_per_wg - 1) / rows_per_wg, plan->B), kCsWaves * kWave,
                                       (size_t)kCsWaves * col_sort_wave_words(plan->W) * 4, stream>>>(
         CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
-        plan->nchunk, plan->nchunk, plan->chunk, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
+        plan->nchunk, plan->nchunk, plan->chunk == 4096 ? 12 : 13, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
     LAUNCH_CHECK("k_col_sort_runs");
     return EVREP_OK;
 }
@@ -516,7 +516,7 @@ static int read_meta_field(const evrep_plan *plan, const void *workspace, size_t
     if (plan->reserved == 2) {  // the key-sorted pass leaves the block statistics unmerged: merge them now
         char *ws = const_cast<char *>(static_cast<const char *>(workspace));
         k_window_meta<<<plan->B, kWave, 0, stream>>>(reinterpret_cast<const int64_t *>(ws + plan->off_rowoff),
-                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk, plan->chunk,
+                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk, plan->chunk == 4096 ? 12 : 13,
                                                      reinterpret_cast<WindowMeta *>(ws + plan->off_meta));
         int rc0 = hip_check(hipGetLastError(), "k_window_meta");
         if (rc0) return rc0;
