@@ -947,12 +947,12 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
                                                              uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
                                                              Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    constexpr int kChunk = TPB * kBsPerLane, kNW = TPB / kWave;
+    constexpr int kChunk = TPB * kBsPerLane, kNW = TPB / kWave, kPerWave = kBsPerLane * kWave;
     const int NK = H * kpr;
     Rec *stage = reinterpret_cast<Rec *>(smem_raw);                         // [cap], output order
     uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kChunk] rank inside the block, arrival order
-    uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kChunk);      // [NK + 1] counts -> exclusive offsets
-    __shared__ BlockStats wstats[kNW];
+    uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kChunk);        // [NK + 1] counts -> exclusive offsets
+    __shared__ int bstats[12];  // the block's statistics, merged by one LDS atomic per wave and field (BlockStats order)
     __shared__ uint32_t tmp[kNW];
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
@@ -961,47 +961,52 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
     const int64_t lo = (int64_t)blk * kChunk;
     if (blk == 0 && threadIdx.x == 0) nwin[b] = n;  // for k_window_meta, which is not handed the offsets
     if (lo >= n) return;  // the builders only read the blocks a window really has
-    const int64_t hi = (lo + kChunk < n) ? lo + kChunk : n;
+    const int nblock = (int)((lo + kChunk < n) ? kChunk : n - lo);  // events of this block; everything below is 32-bit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wlo = lo + (int64_t)wave * (kBsPerLane * kWave);
-    const int64_t whi = (wlo + kBsPerLane * kWave < hi) ? wlo + kBsPerLane * kWave : hi;
-    const int64_t HW = (int64_t)H * W;
+    const int w0 = wave * kPerWave;                       // first block-local index of the wave
+    const int lo32 = (int)lo;
+    const int4 *evb = ev + beg + lo;
     int4 e[kBsPerLane];
     int tprev[kBsPerLane];
 #pragma unroll
     for (int i = 0; i < kBsPerLane; ++i) {
-        const int64_t r = wlo + i * kWave + lane;
+        const int li = w0 + i * kWave + lane;
         e[i] = make_int4(-1, -1, INT32_MAX, 0);
         tprev[i] = INT32_MIN;
-        if (r < whi) {
-            e[i] = ev[beg + r];
-            if (lane == 0 && r > 0) tprev[i] = ev[beg + r - 1].z;  // other lanes take it from their neighbour
+        if (li < nblock) {
+            e[i] = evb[li];
+            if (lane == 0 && (li > 0 || lo > 0)) tprev[i] = evb[li - 1].z;  // other lanes take it from their neighbour
         }
     }
     for (int i = threadIdx.x; i <= NK; i += TPB) base[i] = 0;
+    if (threadIdx.x < 12) {
+        const int f = threadIdx.x;  // tmin, tmax, xmin, xmax, ymin, ymax, neg, oob, status, n_valid, pad, pad
+        bstats[f] = (f == 0 || f == 2 || f == 4) ? INT32_MAX : ((f == 1 || f == 3 || f == 5) ? INT32_MIN : 0);
+    }
     __syncthreads();
     const MdesWindows mw = mdes_windows(n);
     uint32_t full = 0, part = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        if (mw.lo[i] <= lo && hi <= mw.hi[i]) full |= 1u << i;
-        else if (!(hi <= mw.lo[i] || lo >= mw.hi[i])) part |= 1u << i;
+        if (mw.lo[i] <= lo32 && lo32 + nblock <= mw.hi[i]) full |= 1u << i;
+        else if (!(lo32 + nblock <= mw.lo[i] || lo32 >= mw.hi[i])) part |= 1u << i;
     }
     BlockStats st;
     stats_identity(st);
     uint32_t ko[kBsPerLane];  // key | arrival << 16, then the record's place in the block; 0xffffffff = not placed
     uint32_t sneg = 0;
     bool cut = false;
+    const int a0 = lo32 + w0, a1 = min(lo32 + w0 + kPerWave, lo32 + nblock);  // the wave's rank range
     if (part) {
-        const int32_t a0 = (int32_t)wlo, a1 = (int32_t)whi;
 #pragma unroll
         for (int q = 0; q < 7; ++q) cut |= (mw.lo[q] > a0 && mw.lo[q] < a1) || (mw.hi[q] > a0 && mw.hi[q] < a1);
     }
-    const uint32_t memb_u = cut ? 0u : (full | (part ? (mdes_membership(mw, (int32_t)wlo) & part) : 0u));
+    const uint32_t memb_u = cut ? 0u : (full | (part ? (mdes_membership(mw, a0) & part) : 0u));
+    const int HW = H * W;  // < 2^30
 #pragma unroll
     for (int i = 0; i < kBsPerLane; ++i) {
-        const int64_t r = wlo + i * kWave + lane;
-        const bool in = r < whi;
+        const int li = w0 + i * kWave + lane;
+        const bool in = li < nblock;
         const int up = __builtin_amdgcn_update_dpp(0, e[i].z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         if (lane != 0) tprev[i] = up;
         // in-frame test on the flat index x + y*W, as the reference's scatter sees it (see k_block_rowsort)
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
         bool valid = in && (uint32_t)e[i].x < (uint32_t)W && (uint32_t)e[i].y < (uint32_t)H;
         if (__any(in && (uint32_t)e[i].x >= (uint32_t)W)) {
             const int64_t key = (int64_t)e[i].x + (int64_t)e[i].y * W;
-            valid = in && key >= 0 && key < HW;
+            valid = in && key >= 0 && key < (int64_t)HW;
             if (valid) { row = (uint32_t)key / (uint32_t)W; col = (uint32_t)key - row * (uint32_t)W; }
         }
         ko[i] = 0xffffffffu;
@@ -1021,11 +1026,11 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
         if (!cut) {
             if (__any(in && e[i].w == -1)) sneg |= memb_u;
         } else if (in && e[i].w == -1) {
-            st.neg_flags |= full | (mdes_membership(mw, (int32_t)r) & part);
+            st.neg_flags |= full | (mdes_membership(mw, lo32 + li) & part);
         }
         if (__any(in && !valid)) {  // rare: out-of-frame events
             if (in && !valid) {
-                const uint32_t memb = cut ? (full | (mdes_membership(mw, (int32_t)r) & part)) : memb_u;
+                const uint32_t memb = cut ? (full | (mdes_membership(mw, lo32 + li) & part)) : memb_u;
                 st.status |= EVREP_ST_OOB;
                 const int cls = e[i].w == 1 ? 1 : (e[i].w == -1 ? 2 : (e[i].w == 0 ? 3 : 0));
                 st.oob_flags |= memb | (cls ? (memb << (7 * cls)) : 0u);
@@ -1041,7 +1046,15 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
     }
     st.neg_flags |= sneg;
     stats_wave_reduce(st);
-    if (lane == 0) wstats[wave] = st;
+    if (lane == 0) {
+        atomicMin(&bstats[0], st.tmin); atomicMax(&bstats[1], st.tmax);
+        atomicMin(&bstats[2], st.xmin); atomicMax(&bstats[3], st.xmax);
+        atomicMin(&bstats[4], st.ymin); atomicMax(&bstats[5], st.ymax);
+        atomicOr(reinterpret_cast<uint32_t *>(&bstats[6]), st.neg_flags);
+        atomicOr(reinterpret_cast<uint32_t *>(&bstats[7]), st.oob_flags);
+        atomicOr(reinterpret_cast<uint32_t *>(&bstats[8]), st.status);
+        atomicAdd(&bstats[9], st.n_valid);
+    }
     __syncthreads();
     // exclusive scan over the key counters: `per` consecutive keys per thread
     const int per = (NK + TPB - 1) / TPB;
@@ -1052,21 +1065,17 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
     uint32_t run = block_exclusive_scan<kNW>(local, tmp, &total);
     for (int k = 0; k < per; ++k)
         if (k0 + k < NK) { const uint32_t c = base[k0 + k]; base[k0 + k] = run; run += c; }
-    if (threadIdx.x == 0) {
-        base[NK] = total;
-        BlockStats t = wstats[0];
-        for (int w = 1; w < kNW; ++w) stats_merge(t, wstats[w]);
-        stats[(size_t)b * nblk + blk] = t;
-    }
+    if (threadIdx.x == 0) base[NK] = total;
+    if (threadIdx.x < 12) reinterpret_cast<int *>(stats + (size_t)b * nblk + blk)[threadIdx.x] = bstats[threadIdx.x];
     __syncthreads();
     uint32_t *tb = table + ((size_t)b * nblk + blk) * ((size_t)NK + 1);
     if (!(KS_DEBUG & 8))
         for (int k = threadIdx.x; k <= NK; k += TPB) tb[k] = base[k];
     // arrival order -> time order inside every key group
+    const uint32_t mine0 = (uint32_t)(w0 + lane);
 #pragma unroll
     for (int i = 0; i < kBsPerLane; ++i)
-        if (ko[i] != 0xffffffffu)
-            rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(wave * (kBsPerLane * kWave) + i * kWave + lane);
+        if (ko[i] != 0xffffffffu) rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
     __syncthreads();
     {
         // the eight group walks of a lane advance together: eight independent LDS reads in flight per step instead of
@@ -1086,7 +1095,6 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
             }
         }
         gmax = (uint32_t)wave_max((int)gmax);
-        const uint32_t mine0 = (uint32_t)(wave * (kBsPerLane * kWave) + lane);
         for (uint32_t j = 0; j < gmax; ++j) {
 #pragma unroll
             for (int i = 0; i < kBsPerLane; ++i)
@@ -1102,10 +1110,8 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
 #pragma unroll
         for (int i = 0; i < kBsPerLane; ++i) {
             const uint32_t pos = ko[i] - pb;  // 0xffffffff - pb >= cap for every pb < 8192
-            if (pos < (uint32_t)cap) {
-                const int64_t r = wlo + i * kWave + lane;
-                stage[pos] = make_int4((int)((int64_t)e[i].x + (int64_t)e[i].y * W), (int)r, e[i].z, e[i].w);
-            }
+            if (pos < (uint32_t)cap)  // placed records are in frame: x + y*W is their 32-bit pixel id
+                stage[pos] = make_int4(e[i].x + e[i].y * W, lo32 + w0 + i * kWave + lane, e[i].z, e[i].w);
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)cap, total - pb);
