@@ -578,16 +578,23 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
 // emit_core over a unit's pixel-sorted records: u.r0 = record `lane`, records [0, u.nstaged) come from the wave's LDS
 // stage, later ones from u.sorted[u.cs + j].
 template <typename OutT, int CMAX, typename Reduce>
-__device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
-                                  const OutT *bg, Reduce reduce) {
+__device__ inline void emit_chunk(const UnitRecs &u, const Rec &stage0, int key0, int npix, int C, OutT *__restrict__ dst,
+                                  WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const uint32_t nrec = u.ce - u.cs, cs = u.cs, nstaged = (uint32_t)u.nstaged;
     const Rec r0 = u.r0;
     const Rec *__restrict__ sorted = u.sorted;
-    if (nrec) w.evbuf[threadIdx.x] = r0;  // (the key-sorted front end has already staged the unit: the same values)
+    // stage0 = what the builder wants get(j) to return for j = lane < 64: record `lane` itself, or a builder-specific
+    // digest of it (per-event divisions done once, one record per lane, instead of inside the divergent segment walks)
+    if (nrec) w.evbuf[threadIdx.x] = stage0;
     const Rec *evbuf = w.evbuf;
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nstaged ? evbuf[j].x : sorted[cs + j].x); };
     auto get = [&](uint32_t j) -> Rec { return j < nstaged ? evbuf[j] : sorted[cs + j]; };
     emit_core<OutT, CMAX>(nrec, key_at, get, key0, npix, C, dst, w, bg, reduce);
+}
+template <typename OutT, int CMAX, typename Reduce>
+__device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
+                                  const OutT *bg, Reduce reduce) {
+    emit_chunk<OutT, CMAX>(u, u.r0, key0, npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -682,13 +689,19 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
         }
     }
 
-    // Float64 divisions are the expensive instructions of this kernel (dense windows are VALU-bound), and two thirds
-    // of them can go without changing one bit of the result:
-    //  * `max` of the normalised timestamp: the quotient (t - tmin) / interval is monotone in t, so the maximum is
-    //    taken over the INTEGER timestamps and divided once per pixel instead of once per event;
+    // Float64 divisions are the expensive instructions of this kernel, and the segment walks are divergent (one step per
+    // event of the longest segment among the 64 lanes).  So the normalised timestamp t_s = (t - tmin) / interval of the
+    // unit's first 64 records is formed BEFORE the walks, one record per lane, all lanes at once, and staged in place of
+    // the fields the walks do not need: {t_s lo, t_s hi, rank, p}.  Bit for bit the same quotient the reference forms
+    // per event (mixed_density_event_stack.py:112-114).  Further:
+    //  * `max` of the normalised timestamp is the maximum of the quotients themselves (the reference's own order);
     //  * a count of 1 (the usual case: most pixels see one event of a window): x / 1.0 == x exactly, so mean and
-    //    variance skip their divisions;
-    //  * the per-event quotient is only formed for events that some sum / mean / variance timestamp channel takes.
+    //    variance skip their divisions.
+    Rec st0 = u.r0;
+    if ((int)threadIdx.x < (int)(u.ce - u.cs)) {
+        const double ts = (double)((int64_t)u.r0.z - (int64_t)tmin) / interval;  // exact numerator: |t - tmin| < 2^32
+        st0 = make_int4(__double2loint(ts), __double2hiint(ts), u.r0.y, u.r0.w);
+    }
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[D::kMaxC]) {
         double s[D::kMaxC], s2[D::kMaxC];
         int cnt[D::kMaxC];
@@ -696,21 +709,11 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
         for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
         for (uint32_t j = jb; j < je; ++j) {
             const Rec e = get(j);
-            const int rank = e.y, p = e.w;
-            const double trel = (double)((int64_t)e.z - (int64_t)tmin);  // exact: |t - tmin| < 2^32
+            int rank, p;
+            double tn;
+            if (j < (uint32_t)kWave) { rank = e.z; p = e.w; tn = __hiloint2double(e.y, e.x); }
+            else { rank = e.y; p = e.w; tn = (double)((int64_t)e.z - (int64_t)tmin) / interval; }  // beyond the staged 64
             const double pv = (double)p;
-            bool need_tn = false;
-#pragma unroll
-            for (int c = 0; c < D::kMaxC; ++c) {
-                if (c < C && active[c]) {
-                    const int f = D::func(P, c), a = D::agg(P, c);
-                    const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
-                    if (is_t && a != EVREP_A_MAX)
-                        need_tn |= rank >= lo[c] && rank < hi[c] && (want[c] == kWantAny || p == want[c]);
-                }
-            }
-            double tn = 0.0;
-            if (need_tn) tn = trel / interval;
 #pragma unroll
             for (int c = 0; c < D::kMaxC; ++c) {
                 if (c < C && active[c]) {
@@ -719,8 +722,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
                     const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
                     if (hit) {
                         if (a == EVREP_A_MAX) {
-                            // timestamp channels keep the running maximum of t - tmin (an exact integer) in s[c]
-                            const double v = is_t ? trel : ((f == EVREP_F_POLARITY) ? pv : 1.0);
+                            const double v = is_t ? tn : ((f == EVREP_F_POLARITY) ? pv : 1.0);
                             if (cnt[c] == 0 || v > s[c]) s[c] = v;
                         } else if (is_count_func(f)) {
                             // src = ones: sum, sum of squares and count coincide (exact small integers)
@@ -739,7 +741,6 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
             double r = 0.0;
             if (c < C && active[c]) {
                 const int f = D::func(P, c), a = D::agg(P, c);
-                const bool is_t = !(f == EVREP_F_POLARITY) && !is_count_func(f);
                 const double n = (double)cnt[c];
                 const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
                 if (is_count_func(f) && a != EVREP_A_MAX) {
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
                     r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
                 } else if (a == EVREP_A_SUM) r = s[c];
                 else if (a == EVREP_A_MEAN) r = cnt[c] > 1 ? s[c] / d : s[c];
-                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? (is_t ? s[c] / interval : s[c]) : 0.0;
+                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
                 else {
                     const double mean = cnt[c] > 1 ? s[c] / d : s[c], mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
                     const double mm = mean * mean;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
             vals[c] = (OutT)(r * scale);
         }
     };
-    emit_chunk<OutT, D::kMaxC>(u, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
+    emit_chunk<OutT, D::kMaxC>(u, st0, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1078,6 +1079,30 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
     if (n_win > 0) { t0 = (double)ev[beg].z; den = (double)ev[beg + n_win - 1].z - t0; }
     // explicit [t0_us, t1_us] of ev-licious' events_to_voxel_grid (utils.py:60-63), mode 2 only
     if (t_range) { t0 = (double)t_range[2 * g.b]; den = (double)(t_range[2 * g.b + 1] - t_range[2 * g.b]); }
+    // the fractional bin position of an event: one float64 division
+    auto bin_pos = [&](int t) -> double {
+        if (mode == 2) {
+            // t_norm = (num_bins - 1) * (t - t0) / deltaT: int64 product, one float64 division
+            const int64_t num = (int64_t)(bins - 1) * ((int64_t)t - (int64_t)t0);
+            return (double)num / (den == 0.0 ? 1.0 : den);
+        }
+        if (mode == 0) {
+            const double tn = ((double)t - t0) / den;
+            return (double)(bins - 1) * tn;
+        }
+        const double num = (double)bins * ((double)t - t0);
+        return num / den;
+    };
+    // The divisions of the unit's first 64 records are done here, one record per lane, all lanes at once; the result
+    // rides in the (rank, t) fields of the staged record, which the segment walks below do not need.  Both np.add.at
+    // passes of every segment then run without a division (they were the bulk of this kernel's VALU work: the walks are
+    // divergent, one division per step and lane).
+    Rec st0 = u.r0;
+    if ((int)threadIdx.x < (int)(u.ce - u.cs)) {
+        const double bp = bin_pos(u.r0.z);
+        st0.y = __double2loint(bp);
+        st0.z = __double2hiint(bp);
+    }
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[EVREP_MAX_CHANNELS]) {
 #pragma unroll
         for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
@@ -1086,19 +1111,8 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
             for (uint32_t j = jb; j < je; ++j) {
                 const Rec e = get(j);
                 double p = (double)e.w;
-                double bpos;
-                if (mode == 2) {
-                    // t_norm = (num_bins - 1) * (t - t0) / deltaT: int64 product, one float64 division
-                    const int64_t num = (int64_t)(bins - 1) * ((int64_t)e.z - (int64_t)t0);
-                    bpos = (double)num / (den == 0.0 ? 1.0 : den);
-                } else if (mode == 0) {
-                    const double tn = ((double)e.z - t0) / den;
-                    bpos = (double)(bins - 1) * tn;
-                } else {
-                    const double num = (double)bins * ((double)e.z - t0);
-                    bpos = num / den;
-                    if (e.w == 0) p = -1.0;
-                }
+                if (mode == 1 && e.w == 0) p = -1.0;
+                const double bpos = j < (uint32_t)kWave ? __hiloint2double(e.z, e.y) : bin_pos(e.z);
                 // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
                 // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
                 if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
@@ -1120,7 +1134,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
             for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
         }
     };
-    emit_chunk<double, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
+    emit_chunk<double, EVREP_MAX_CHANNELS>(u, st0, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
