@@ -561,7 +561,7 @@ constexpr int kBsThreads = 1024;
 constexpr int kBsWaves = kBsThreads / kWave;     // 16
 constexpr int kBsPerLane = 8;
 constexpr int kBsChunk = kBsThreads * kBsPerLane;  // 8192 events per workgroup
-constexpr int kBsMaxBlocks = 64;                 // runs one k_col_sort_runs wave gathers (one lane each): 524 288 events / window
+constexpr int kBsMaxBlocks = 64;                 // block runs a builder wave of the key-sorted pass gathers (one lane each)
 constexpr int kBsChainBlocks = 16;               // up to here the run of a record is found by a readlane chain, above by an LDS search
 
 __host__ __device__ inline int bs_hp(int H) { return (H + 1) & ~1; }
@@ -729,18 +729,20 @@ __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__rest
         for (uint32_t t = threadIdx.x; t < total; t += kBsThreads) dst[t] = stage[t];
 }
 
-// grid (ceil(H / (kCsWaves * R)), B), 256 threads = kCsWaves independent waves (no block barrier), each wave R
-// consecutive rows; dynamic LDS = kCsWaves * W * 4.  The run table of all R rows is loaded first and the record
-// fetches of all R rows are in flight together (R x 4 loads per lane) before the first row is ordered: one
-// memory latency chain per R rows instead of one per row.
+// grid (ceil(H / kCsWaves), B), 256 threads = kCsWaves independent waves (no block barrier), one sensor row each;
+// dynamic LDS = kCsWaves * col_sort_wave_words(W) * 4.  A lane reads the row's offsets in TWO block runs (lane and
+// lane + 64): up to kCsMaxRuns = 128 runs per window, 1 048 576 events with 8192-event blocks.
+// (Several rows per wave, with all their fetches in flight together, were slower: R = 2, 4 measured in round 2.)
 constexpr int kCsWaves = 4;
+constexpr int kCsMaxRuns = 128;
 __host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / kWave + 3) / 4; }
 __host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
-__host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_words(W) + 128; }   // + the run table (pre, src)
+__host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_words(W) + 2 * kCsMaxRuns; }   // + the run table (pre, src)
 #ifndef EVREP_CS_ROWS
 #define EVREP_CS_ROWS 1
 #endif
 constexpr int kCsRowsPerWave = EVREP_CS_ROWS;
+static_assert(kCsRowsPerWave == 1, "k_col_sort_runs takes one row per wave");
 
 template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
@@ -750,30 +752,39 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
     extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, row0 = (blockIdx.x * kCsWaves + wave) * R;
-    if (row0 >= H) return;
+    const int b = blockIdx.y, row = blockIdx.x * kCsWaves + wave;
+    if (row >= H) return;
     uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);  // <= kBsMaxBlocks: one lane per block run of 1 << chunk_shift events
-    // run k of row r = sorted1[beg + k*8192 + t_k[r], ... + t_k[r+1]); records of earlier rows = sum_k t_k[r]
-    uint32_t t[R + 1];
+    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);  // <= kCsMaxRuns block runs of 1 << chunk_shift events
+    // run k of the row = sorted1[beg + (k << chunk_shift) + t_k[row], ... + t_k[row + 1]); records of earlier rows = sum_k t_k[row]
+    // kpr = keys per row of the run table: 1 after k_block_rowsort; nchunk after k_block_keysort, whose runs hold a
+    // row's records chunk by chunk (time-ordered inside a chunk, which is all the stable column sort below needs)
+    uint32_t ta[2] = {0u, 0u}, tb[2] = {0u, 0u};  // [0]: run `lane`, [1]: run `lane + 64`; a = offset of the row, b = of the next row
 #pragma unroll
-    for (int r = 0; r <= R; ++r) {
-        t[r] = 0;
-        // kpr = keys per row of the run table: 1 after k_block_rowsort; nchunk after k_block_keysort, whose runs hold a
-        // row's records chunk by chunk (time-ordered inside a chunk, which is all the stable column sort below needs)
-        if (lane < nb) t[r] = table[((size_t)b * nblk + lane) * ((size_t)H * kpr + 1) + (size_t)min(row0 + r, H) * kpr];
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + h * kWave;
+        if (k < nb) {
+            const uint32_t *tk = table + ((size_t)b * nblk + k) * ((size_t)H * kpr + 1);
+            ta[h] = tk[(size_t)row * kpr];
+            tb[h] = tk[(size_t)(row + 1) * kpr];
+        }
     }
-    if (row0 == 0) {  // this wave also publishes the window's statistics
+    if (row == 0) {  // this wave also publishes the window's statistics
         BlockStats st;
         stats_identity(st);
-        if (lane < nb) {  // three 16-byte loads, fields assigned one by one (a struct copy would go through scratch)
-            const int4 *sp = reinterpret_cast<const int4 *>(stats + (size_t)b * nblk + lane);
-            const int4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
-            st.tmin = q0.x; st.tmax = q0.y; st.xmin = q0.z; st.xmax = q0.w;
-            st.ymin = q1.x; st.ymax = q1.y; st.neg_flags = (uint32_t)q1.z; st.oob_flags = (uint32_t)q1.w;
-            st.status = (uint32_t)q2.x; st.n_valid = q2.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = lane + h * kWave;
+            if (k < nb) {  // three 16-byte loads, fields merged one by one (a struct copy would go through scratch)
+                const int4 *sp = reinterpret_cast<const int4 *>(stats + (size_t)b * nblk + k);
+                const int4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+                st.tmin = min(st.tmin, q0.x); st.tmax = max(st.tmax, q0.y); st.xmin = min(st.xmin, q0.z); st.xmax = max(st.xmax, q0.w);
+                st.ymin = min(st.ymin, q1.x); st.ymax = max(st.ymax, q1.y);
+                st.neg_flags |= (uint32_t)q1.z; st.oob_flags |= (uint32_t)q1.w;
+                st.status |= (uint32_t)q2.x; st.n_valid += q2.y;
+            }
         }
         stats_wave_reduce(st);
         if (lane == 0) {
@@ -787,130 +798,121 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         }
     }
     constexpr uint32_t kSuper = 4 * kWave;  // records of a row held in registers (longer rows are walked twice)
-    uint32_t rs[R + 1], pre[R], src[R];
-    rs[0] = (uint32_t)beg + (uint32_t)wave_sum((int)t[0]);
+    const uint32_t rbeg = (uint32_t)beg + (uint32_t)wave_sum((int)(ta[0] + ta[1]));
+    // exclusive prefix of the run lengths over the <= 128 runs: two wave scans, the second carried by the first's total
+    const uint32_t len0 = tb[0] - ta[0], len1 = tb[1] - ta[1];
+    uint32_t incl0 = len0, incl1 = len1;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t len = t[r + 1] - t[r];
-        uint32_t incl = len;
-#pragma unroll
-        for (int d = 1; d < kBsMaxBlocks; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }  // full wave
-        pre[r] = incl - len;                                                            // this row's records in earlier blocks
-        rs[r + 1] = rs[r] + (uint32_t)__builtin_amdgcn_readlane((int)incl, kBsMaxBlocks - 1);  // rows are contiguous in sorted2
-        src[r] = (uint32_t)beg + ((uint32_t)lane << chunk_shift) + t[r] - pre[r];            // record j of the row: src_k + j
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o0 = __shfl_up(incl0, d, 64), o1 = __shfl_up(incl1, d, 64);
+        if (lane >= d) { incl0 += o0; incl1 += o1; }
     }
-    // record j of row r lies in the run k with pre_k <= j < pre_{k+1}: a sum of conditional steps over the runs
-    // (lanes >= nb hold pre = n, so they never match a j < n)
-    // (more than kBsChainBlocks runs: pre / src of the row go through 2 x 64 words of the wave's LDS and every lane
-    // finds its run by a 6-step binary search -- pre is non-decreasing, the LAST k with pre_k <= j holds record j)
-    uint32_t *runs = cnt + col_sort_words(W);  // [2][64], only used when nb > kBsChainBlocks
-    int runs_row = -1;
-    auto fetch = [&](int r, uint32_t j) -> Rec {
+    const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+    incl1 += tot0;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);  // records of the row
+    const uint32_t pre0 = incl0 - len0, pre1 = incl1 - len1;                   // the row's records in earlier runs
+    const uint32_t src0 = (uint32_t)beg + ((uint32_t)lane << chunk_shift) + ta[0] - pre0;             // record j of the row, if in this run: src + j
+    const uint32_t src1 = (uint32_t)beg + ((uint32_t)(lane + kWave) << chunk_shift) + ta[1] - pre1;
+    const uint32_t rend = rbeg + n;
+    // record j lies in the run k with pre_k <= j < pre_{k+1}: <= kBsChainBlocks runs: a sum of conditional steps over the
+    // runs (lanes >= nb hold pre = n, so they never match a j < n); more: pre / src go through 2 x 128 words of the wave's
+    // LDS and every lane finds its run by a 7-step binary search -- pre is non-decreasing, the LAST k with pre_k <= j
+    // holds record j
+    uint32_t *runs = cnt + col_sort_words(W);  // [2][128], only used when nb > kBsChainBlocks
+    if (nb > kBsChainBlocks) {
+        runs[lane] = pre0;
+        runs[kWave + lane] = pre1;
+        runs[kCsMaxRuns + lane] = src0;
+        runs[kCsMaxRuns + kWave + lane] = src1;
+        wave_phase_lds();
+    }
+    auto fetch = [&](uint32_t j) -> Rec {
         if (nb <= kBsChainBlocks) {
-            uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src[r], 0);
+            uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
             uint32_t prev = s;
             for (int k = 1; k < nb; ++k) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre[r], k);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src[r], k);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre0, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src0, k);
                 s += (j >= pk) ? sk - prev : 0u;
                 prev = sk;
             }
             return sorted1[s + j];
         }
-        if (runs_row != r) {  // uniform
-            wave_phase_lds();
-            runs[lane] = pre[r];
-            runs[64 + lane] = src[r];
-            wave_phase_lds();
-            runs_row = r;
-        }
         uint32_t lo = 0, hi = (uint32_t)nb;
 #pragma unroll
-        for (int step = 0; step < 6; ++step) {
+        for (int step = 0; step < 7; ++step) {
             const uint32_t mid = (lo + hi) >> 1;
             const bool go = hi - lo > 1 && runs[mid] <= j;
             if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
         }
-        return sorted1[runs[64 + lo] + j];
+        return sorted1[runs[kCsMaxRuns + lo] + j];
     };
-    Rec e[R][4];
+    Rec e[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t n = rs[r + 1] - rs[r];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t j = i * kWave + lane;
-            e[r][i] = make_int4(0, 0, 0, 0);
-            if (row0 + r < H && j < n) e[r][i] = fetch(r, j);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t j = i * kWave + lane;
+        e[i] = make_int4(0, 0, 0, 0);
+        if (j < n) e[i] = fetch(j);
     }
     const int nbits = bits_for(W);
     const int per4 = col_sort_per4(W);  // 16-byte vectors of column counters per lane (the array is padded to 64 * per4 * 4)
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt) + (size_t)lane * per4;
     volatile uint32_t *vcnt = cnt;
+    uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+    if (n == 0) {
+        for (int c = lane; c <= nchunk; c += kWave) co[c] = rbeg;
+        return;
+    }
+    const int rowbase = row * W;
+    const uint32_t nsuper = (n + kSuper - 1) / kSuper;
+    for (int k = 0; k < per4; ++k) cnt4[k] = make_uint4(0u, 0u, 0u, 0u);
+    wave_phase_lds();
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int row = row0 + r;
-        if (row >= H) break;  // uniform
-        const uint32_t n = rs[r + 1] - rs[r];
-        const uint32_t rbeg = rs[r], rend = rs[r + 1];
-        uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-        if (n == 0) {
-            for (int c = lane; c <= nchunk; c += kWave) co[c] = rbeg;
-            continue;
+    for (int i = 0; i < 4; ++i)
+        if ((uint32_t)(i * kWave + lane) < n) atomicAdd(&cnt[e[i].x - rowbase], 1u);
+    for (uint32_t sb = 1; sb < nsuper; ++sb)  // a row longer than the register batch
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j = sb * kSuper + i * kWave + lane;
+            if (j < n) atomicAdd(&cnt[fetch(j).x - rowbase], 1u);
         }
-        const int rowbase = row * W;
-        const uint32_t nsuper = (n + kSuper - 1) / kSuper;
-        for (int k = 0; k < per4; ++k) cnt4[k] = make_uint4(0u, 0u, 0u, 0u);
-        wave_phase_lds();
+    wave_phase_lds();
+    // exclusive scan over the W column counters: `per` consecutive columns per lane
+    uint32_t local = 0;
+    for (int k = 0; k < per4; ++k) { const uint4 v = cnt4[k]; local += v.x + v.y + v.z + v.w; }
+    uint32_t inc2 = local;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if ((uint32_t)(i * kWave + lane) < n) atomicAdd(&cnt[e[r][i].x - rowbase], 1u);
-        for (uint32_t sb = 1; sb < nsuper; ++sb)  // a row longer than the register batch
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t j = sb * kSuper + i * kWave + lane;
-                if (j < n) atomicAdd(&cnt[fetch(r, j).x - rowbase], 1u);
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc2, d, 64); if (lane >= d) inc2 += o; }
+    uint32_t run = inc2 - local;
+    for (int k = 0; k < per4; ++k) {
+        const uint4 v = cnt4[k];
+        uint4 o;
+        o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+        run = o.w + v.w;
+        cnt4[k] = o;
+    }
+    wave_phase_lds();
+    for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rbeg + cnt[c * kChunkPx] : rend;
+    wave_phase_lds();
+    for (uint32_t sb = 0; sb < nsuper; ++sb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t j0 = sb * kSuper + i * kWave;
+            if (j0 >= n) break;  // uniform
+            const bool valid = j0 + lane < n;
+            Rec rec = e[i];
+            if (sb > 0) { rec = make_int4(0, 0, 0, 0); if (valid) rec = fetch(j0 + lane); }
+            const uint32_t col = valid ? (uint32_t)(rec.x - rowbase) : 0u;
+            uint32_t rk; bool last;
+            wave_match(col, nbits, valid, lane, rk, last);
+            uint32_t pos = 0;
+            if (valid) {
+                pos = vcnt[col] + rk;
+                sorted2[rbeg + pos] = rec;
             }
-        wave_phase_lds();
-        // exclusive scan over the W column counters: `per` consecutive columns per lane
-        uint32_t local = 0;
-        for (int k = 0; k < per4; ++k) { const uint4 v = cnt4[k]; local += v.x + v.y + v.z + v.w; }
-        uint32_t inc2 = local;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc2, d, 64); if (lane >= d) inc2 += o; }
-        uint32_t run = inc2 - local;
-        for (int k = 0; k < per4; ++k) {
-            const uint4 v = cnt4[k];
-            uint4 o;
-            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
-            run = o.w + v.w;
-            cnt4[k] = o;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && last) vcnt[col] = pos + 1;
+            __builtin_amdgcn_wave_barrier();
         }
-        wave_phase_lds();
-        for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rbeg + cnt[c * kChunkPx] : rend;
-        wave_phase_lds();
-        for (uint32_t sb = 0; sb < nsuper; ++sb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t j0 = sb * kSuper + i * kWave;
-                if (j0 >= n) break;  // uniform
-                const bool valid = j0 + lane < n;
-                Rec rec = e[r][i];
-                if (sb > 0) { rec = make_int4(0, 0, 0, 0); if (valid) rec = fetch(r, j0 + lane); }
-                const uint32_t col = valid ? (uint32_t)(rec.x - rowbase) : 0u;
-                uint32_t rk; bool last;
-                wave_match(col, nbits, valid, lane, rk, last);
-                uint32_t pos = 0;
-                if (valid) {
-                    pos = vcnt[col] + rk;
-                    sorted2[rbeg + pos] = rec;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (valid && last) vcnt[col] = pos + 1;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        wave_phase_lds();  // the next row zeroes the counters
     }
 }
 

@@ -142,7 +142,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     }
     // the two-kernel pass (k_block_rowsort + k_col_sort_runs): windows of <= 64 blocks of 8192 events on sensors
     // whose per-wave row counters fit next to the 128 KB record stage in one workgroup's LDS (H <= ~900)
-    const bool two_kernel = max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk &&
+    const bool two_kernel = max_events_per_window <= (int64_t)kCsMaxRuns * kBsChunk &&
                             block_rowsort_lds_bytes(H) + 1024 <= 160 * 1024 && !getenv("EVREP_BIN_THREE_KERNEL");
     if (two_kernel) {
         chunk = kBsChunk;
@@ -157,7 +157,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     // unit holds <= 30 records on average, so practically every unit is ordered in one 64-lane batch -- on sensors
     // whose key table fits next to the record stage
     const int64_t NK = (int64_t)H * plan->nchunk;
-    const bool key_sorted = two_kernel && NK < 65535 &&
+    const bool key_sorted = two_kernel && max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk && NK < 65535 &&
                             block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
                             ((double)max_events_per_window <= 30.0 * (double)NK || getenv("EVREP_BIN_KEY_SORTED")) &&
                             !getenv("EVREP_BIN_CLASSIC") &&
@@ -244,7 +244,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         return EVREP_OK;
     }
     if (plan->reserved == 1) {
-        if (chunk != kBsChunk || nblk > kBsMaxBlocks) return EVREP_EINVAL;
+        if (chunk != kBsChunk || nblk > kCsMaxRuns) return EVREP_EINVAL;
         const size_t lds = block_rowsort_lds_bytes(H);
         static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
         if (!attr_set) {

@@ -92,10 +92,10 @@ def test_window_sizes_around_partition_blocks(oracle):
 
 
 @pytest.mark.parametrize("sizes", [(8191, 8192, 8193), (16 * 8192, 16 * 8192 + 1), (17 * 8192 - 5, 40000),
-                                   (64 * 8192, 3), (64 * 8192 + 1, 9000)])
+                                   (64 * 8192, 3), (64 * 8192 + 1, 9000), (128 * 8192, 70 * 8192 + 7), (128 * 8192 + 1, 100)])
 def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes, monkeypatch):
     """The two-kernel binning pass: 8192-event workgroup blocks, <= 16 block runs per row found by a readlane chain,
-    17..64 by the LDS search, more than 64 x 8192 events per window -> the three-kernel pass.  Every size next to a
+    17..128 by the LDS search (two runs per lane), more than 128 x 8192 events per window -> the three-kernel pass.  Every size next to a
     short window in the same batch; ERGO-12 / EventStack / voxel bit-exact vs the oracle.
     (EVREP_BIN_CLASSIC keeps the key-sorted pass, tests/test_gpu_key_sorted.py, out of the choice.)"""
     from event_representation_study_amd import engine as eng
@@ -103,7 +103,7 @@ def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes, monkeypatc
     H, W = 36, 200
     wins = [make_events(n, W, H, seed=n % 1000 + 3) for n in sizes]
     eb = eng.EventBatch.from_numpy(wins, H, W)
-    assert eb.plan.reserved == (1 if max(sizes) <= 64 * 8192 else 0)
+    assert eb.plan.reserved == (1 if max(sizes) <= 128 * 8192 else 0)
     got, es, vx = eb.optimized().cpu().numpy(), eb.event_stack().cpu().numpy(), eb.voxel(5).cpu().numpy()
     for b, ev in enumerate(wins):
         assert_bit_equal(got[b], oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))

@@ -145,9 +145,9 @@ def test_many_block_runs(oracle, n, monkeypatch):
         assert_bit_equal(ks.optimized()[b].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))
     assert_bit_equal(ks.event_stack().cpu().numpy(), cl.event_stack().cpu().numpy(), "event stack")
     assert_bit_equal(ks.tore(6, frame_mode=1).cpu().numpy(), cl.tore(6, frame_mode=1).cpu().numpy(), "tore")
-    # one event more than 64 blocks: the three-kernel pass, forced or not
+    # one event more than 64 blocks: a builder wave has one lane per run -- the two-kernel pass, forced or not
     monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
-    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 0
+    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 1
 
 
 def test_status_bbox_and_failed_channels(monkeypatch):
