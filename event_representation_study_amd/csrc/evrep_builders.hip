@@ -42,9 +42,13 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
-// units wider than one chunk (two-chunk float32 units, TORE's shifted frame) hold ~65 records on the sparse windows
-// they are chosen for: their stage takes 128, so that the key-sorted front end orders them inside LDS
-__host__ __device__ inline int ev_stage(int segcap) { return segcap > kChunkPx ? 2 * kEvStage : kEvStage; }
+// The stage size is chosen per launch (unit_cfg() in evrep_capi.hip): 64 records for one-chunk units, 128 for wider ones
+// (two-chunk float32 units and TORE's shifted frame hold ~65 records on the sparse windows they are chosen for: the
+// key-sorted front end orders them inside LDS).
+struct UnitCfg {
+    int span;   // 128-pixel chunks per unit
+    int stage;  // records the wave's LDS stage holds (a multiple of 64)
+};
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
 // average record count per chunk, see builder_span() in evrep_capi.hip.
@@ -55,21 +59,22 @@ struct WaveLds {
     OutT *tile;   // kPartPx * C elements, output layout (pixel-major, channel-minor)
     OutT *bg;     // EVREP_MAX_CHANNELS background values (the empty-pixel value of every channel)
     uint2 *segs;  // (pixel offset inside the chunk, first record index); entry nseg = sentinel
-    Rec *evbuf;   // the unit's first ev_stage(segcap) records (the classic front end fills the first kEvStage)
+    Rec *evbuf;   // `nstage` records of the unit (the classic front end fills the first kEvStage)
     int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
-    __device__ WaveLds(unsigned char *smem, int C, int segcap_) : segcap(segcap_) {
+    int nstage;
+    __device__ WaveLds(unsigned char *smem, int C, int segcap_, int nstage_) : segcap(segcap_), nstage(nstage_) {
         size_t o = 0;
         tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)kPartPx * C * sizeof(OutT));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
-        evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)ev_stage(segcap_) * sizeof(Rec);
+        evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)nstage_ * sizeof(Rec);
         segs = reinterpret_cast<uint2 *>(smem + o);
     }
 };
 
 // segcap = pixels one unit can touch: span * kChunkPx (+ kChunkPx for TORE's shifted frame)
-__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap) {
+__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap, int nstage) {
     return align16((size_t)kPartPx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
-           (size_t)ev_stage(segcap) * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
+           (size_t)nstage * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
 }
 
 // Ordering point between LDS phases of a ONE-WAVE workgroup.  LDS operations of a wave execute in
@@ -283,7 +288,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const int nbits = 32 - __builtin_clz((unsigned)npixu - 1u);  // npixu >= 128
     const int per4 = npixu / (4 * kWave) + ((npixu % (4 * kWave)) ? 1 : 0);  // npixu is a multiple of 128: 16-byte vectors per lane
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
-    const int nstage = ev_stage(w.segcap);
+    const int nstage = min(w.nstage, 2 * kEvStage);  // two register batches
     if (nrec <= (uint32_t)nstage) {
         // the whole unit is ordered inside LDS: up to two batches of 64 records, held in registers between the count
         // and the placement
@@ -482,9 +487,10 @@ __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__res
 // pixels without records keep the background.  `r0` = record `lane` of the chunk, loaded by the
 // caller before its own independent loads.  Pixel offsets outside [0, npix) (TORE's straddle)
 // are ignored.
-template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename Reduce>
-__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key0, int npix, int C,
-                                 OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+// `post_heads()` runs once the segment heads are listed (the stage may then be rewritten).
+template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename PostHeads, typename Reduce>
+__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHeads post_heads, int key0, int npix,
+                                 int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     // a zero tile is filled at once (it overlaps the record load); a background that had to be
     // loaded is filled after the segment heads are listed, when it has arrived behind the records
@@ -520,6 +526,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
     }
     if (bg) tile_fill(w.tile, min(kPartPx, npix), C, bg);
     wave_phase();
+    post_heads();
 
     if (nseg <= kWave) {
         // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
@@ -575,26 +582,39 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, int key
     }
 }
 
-// emit_core over a unit's pixel-sorted records: u.r0 = record `lane`, records [0, u.nstaged) come from the wave's LDS
-// stage, later ones from u.sorted[u.cs + j].
-template <typename OutT, int CMAX, typename Reduce>
-__device__ inline void emit_chunk(const UnitRecs &u, const Rec &stage0, int key0, int npix, int C, OutT *__restrict__ dst,
+// emit_core over a unit's pixel-sorted records.  u.r0 = record `lane`; records [64, u.nstaged) sit in the wave's LDS stage
+// (the key-sorted front end put them there), later ones are read from u.sorted[u.cs + j].
+// `digest(rec)` = the form in which the builder's reduce wants a record (identity, or with the per-event float64
+// division done: MDES' normalised timestamp, the voxel bin position).  reduce() only ever sees digests:
+//   * the staged records are digested here, one record per lane, all lanes at once -- not inside the divergent segment
+//     walks, where every step of the longest segment costs the whole wave a division;
+//   * whatever is not staged is fetched and digested on the fly.
+// (Re-staging the record range of every part tile of a dense chunk the same way was measured in round 2: the extra LDS
+// round trips cost more than the divergent loads and divisions they replace, for every builder but the voxel grid.)
+template <typename OutT, int CMAX, typename Digest, typename Reduce>
+__device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
                                   WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
-    const uint32_t nrec = u.ce - u.cs, cs = u.cs, nstaged = (uint32_t)u.nstaged;
+    const int lane = threadIdx.x;
+    const uint32_t nrec = u.ce - u.cs, cs = u.cs, nraw = (uint32_t)u.nstaged;
     const Rec r0 = u.r0;
     const Rec *__restrict__ sorted = u.sorted;
-    // stage0 = what the builder wants get(j) to return for j = lane < 64: record `lane` itself, or a builder-specific
-    // digest of it (per-event divisions done once, one record per lane, instead of inside the divergent segment walks)
-    if (nrec) w.evbuf[threadIdx.x] = stage0;
-    const Rec *evbuf = w.evbuf;
-    auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nstaged ? evbuf[j].x : sorted[cs + j].x); };
-    auto get = [&](uint32_t j) -> Rec { return j < nstaged ? evbuf[j] : sorted[cs + j]; };
-    emit_core<OutT, CMAX>(nrec, key_at, get, key0, npix, C, dst, w, bg, reduce);
+    Rec *evbuf = w.evbuf;
+    if (lane < (int)nrec) evbuf[lane] = digest(r0);
+    const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
+    auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nraw ? evbuf[j].x : sorted[cs + j].x); };
+    auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest(sorted[cs + j]); };
+    auto post_heads = [&]() {
+        if (nraw > (uint32_t)kWave) {  // uniform: the second staged batch is still raw (key_at read its pixel ids)
+            if (lane + kWave < (int)nraw) evbuf[lane + kWave] = digest(evbuf[lane + kWave]);
+            wave_phase();
+        }
+    };
+    emit_core<OutT, CMAX>(nrec, key_at, get, post_heads, key0, npix, C, dst, w, bg, reduce);
 }
 template <typename OutT, int CMAX, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
                                   const OutT *bg, Reduce reduce) {
-    emit_chunk<OutT, CMAX>(u, u.r0, key0, npix, C, dst, w, bg, reduce);
+    emit_chunk<OutT, CMAX>(u, [](const Rec &r) -> Rec { return r; }, key0, npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -646,14 +666,14 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 // grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
 template <typename OutT, typename D>
 __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__restrict__ off,
-                                               MdesParams P, int H, int W, int nchunk, int span, double scale,
+                                               MdesParams P, int H, int W, int nchunk, UnitCfg uc, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
-    WaveLds<OutT> w(smem, C, span * kChunkPx);
+    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
     // every independent global load first: the chunk's records, the window's statistics and extent
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int64_t n_win = off[g.b + 1] - off[g.b];
     const WindowMeta m = window_meta(bv, off, g.b);
@@ -691,28 +711,25 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
 
     // Float64 divisions are the expensive instructions of this kernel, and the segment walks are divergent (one step per
     // event of the longest segment among the 64 lanes).  So the normalised timestamp t_s = (t - tmin) / interval of the
-    // unit's first 64 records is formed BEFORE the walks, one record per lane, all lanes at once, and staged in place of
-    // the fields the walks do not need: {t_s lo, t_s hi, rank, p}.  Bit for bit the same quotient the reference forms
+    // staged records is formed BEFORE the walks (emit_chunk's digest), one record per lane, all lanes at once, and
+    // staged in place of the fields the walks do not need: {t_s lo, t_s hi, rank, p}.  Bit for bit the same quotient the reference forms
     // per event (mixed_density_event_stack.py:112-114).  Further:
     //  * `max` of the normalised timestamp is the maximum of the quotients themselves (the reference's own order);
     //  * a count of 1 (the usual case: most pixels see one event of a window): x / 1.0 == x exactly, so mean and
     //    variance skip their divisions.
-    Rec st0 = u.r0;
-    if ((int)threadIdx.x < (int)(u.ce - u.cs)) {
-        const double ts = (double)((int64_t)u.r0.z - (int64_t)tmin) / interval;  // exact numerator: |t - tmin| < 2^32
-        st0 = make_int4(__double2loint(ts), __double2hiint(ts), u.r0.y, u.r0.w);
-    }
+    auto digest = [&](const Rec &r) -> Rec {
+        const double ts = (double)((int64_t)r.z - (int64_t)tmin) / interval;  // exact numerator: |t - tmin| < 2^32
+        return make_int4(__double2loint(ts), __double2hiint(ts), r.y, r.w);
+    };
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[D::kMaxC]) {
         double s[D::kMaxC], s2[D::kMaxC];
         int cnt[D::kMaxC];
 #pragma unroll
         for (int c = 0; c < D::kMaxC; ++c) { s[c] = 0.0; s2[c] = 0.0; cnt[c] = 0; }
         for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);
-            int rank, p;
-            double tn;
-            if (j < (uint32_t)kWave) { rank = e.z; p = e.w; tn = __hiloint2double(e.y, e.x); }
-            else { rank = e.y; p = e.w; tn = (double)((int64_t)e.z - (int64_t)tmin) / interval; }  // beyond the staged 64
+            const Rec e = get(j);  // digest: {t_s lo, t_s hi, rank, p}
+            const int rank = e.z, p = e.w;
+            const double tn = __hiloint2double(e.y, e.x);
             const double pv = (double)p;
 #pragma unroll
             for (int c = 0; c < D::kMaxC; ++c) {
@@ -758,19 +775,19 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
             vals[c] = (OutT)(r * scale);
         }
     };
-    emit_chunk<OutT, D::kMaxC>(u, st0, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
+    emit_chunk<OutT, D::kMaxC>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
-                                                      const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
+                                                      const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<float> w(smem, S, span * kChunkPx);
+    WaveLds<float> w(smem, S, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
     const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
@@ -891,13 +908,13 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 
 template <typename OutT>
 __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
-                                                       const TsCuts *__restrict__ cuts, int H, int W, int nchunk, int span,
+                                                       const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
-    WaveLds<OutT> w(smem, C, span * kChunkPx);
+    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     // the window's cuts, held in registers with compile-time indices only (no scratch)
     const TsCuts *cp = cuts + g.b;
@@ -963,11 +980,12 @@ constexpr int kMaxToreK = 8;
 __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
-                                               int H, int W, int nchunk, int span, int K, int frame_mode, float scale,
+                                               int H, int W, int nchunk, UnitCfg uc, int K, int frame_mode, float scale,
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * K;
-    WaveLds<float> w(smem, C, (span + 1) * kChunkPx);
+    const int span = uc.span;
+    WaveLds<float> w(smem, C, (span + 1) * kChunkPx, uc.stage);
     const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
     const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
@@ -1066,12 +1084,12 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
 //         and the upper bin an exact zero -- a signed event count per (time bin, y, x).
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
-                                                int H, int W, int nchunk, int span, int bins, int mode, double scale,
+                                                int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
                                                 const int64_t *__restrict__ t_range, double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<double> w(smem, bins, span * kChunkPx);
+    WaveLds<double> w(smem, bins, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
     const int64_t beg = off[g.b];
     const int64_t n_win = off[g.b + 1] - beg;
@@ -1093,16 +1111,14 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
         const double num = (double)bins * ((double)t - t0);
         return num / den;
     };
-    // The divisions of the unit's first 64 records are done here, one record per lane, all lanes at once; the result
-    // rides in the (rank, t) fields of the staged record, which the segment walks below do not need.  Both np.add.at
-    // passes of every segment then run without a division (they were the bulk of this kernel's VALU work: the walks are
-    // divergent, one division per step and lane).
-    Rec st0 = u.r0;
-    if ((int)threadIdx.x < (int)(u.ce - u.cs)) {
-        const double bp = bin_pos(u.r0.z);
-        st0.y = __double2loint(bp);
-        st0.z = __double2hiint(bp);
-    }
+    // emit_chunk digests the staged records -- one record per lane, all lanes at once: the bin position rides in the
+    // (rank, t) fields, which the segment walks below do not need.  Both np.add.at passes of every segment then run
+    // without a division (they were the bulk of this kernel's VALU work: the walks are divergent, one division per step
+    // and lane).
+    auto digest = [&](const Rec &r) -> Rec {
+        const double bp = bin_pos(r.z);
+        return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
+    };
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[EVREP_MAX_CHANNELS]) {
 #pragma unroll
         for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
@@ -1112,7 +1128,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
                 const Rec e = get(j);
                 double p = (double)e.w;
                 if (mode == 1 && e.w == 0) p = -1.0;
-                const double bpos = j < (uint32_t)kWave ? __hiloint2double(e.z, e.y) : bin_pos(e.z);
+                const double bpos = __hiloint2double(e.z, e.y);
                 // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
                 // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
                 if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
@@ -1134,7 +1150,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
             for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
         }
     };
-    emit_chunk<double, EVREP_MAX_CHANNELS>(u, st0, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
+    emit_chunk<double, EVREP_MAX_CHANNELS>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1151,13 +1167,13 @@ struct PolStatParams {
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
 __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
-                                                   PolStatParams P, int H, int W, int nchunk, int span,
+                                                   PolStatParams P, int H, int W, int nchunk, UnitCfg uc,
                                                    float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = P.C;
-    WaveLds<float> w(smem, C, span * kChunkPx);
+    WaveLds<float> w(smem, C, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     const int lane = threadIdx.x;
     const double *tw = tnorm + off[g.b];
@@ -1241,12 +1257,12 @@ __device__ inline float est_value(float u, const double *__restrict__ seg, const
 __global__ __launch_bounds__(kWave) void k_est(BinView bv,
                                               const int64_t *__restrict__ off, const float *__restrict__ tnorm,
                                               const double *__restrict__ seg, const uint32_t *__restrict__ bucket,
-                                              EstParams P, int H, int W, int nchunk, int span, float *__restrict__ out) {
+                                              EstParams P, int H, int W, int nchunk, UnitCfg uc, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C2 = 2 * P.C;
-    WaveLds<float> w(smem, C2, span * kChunkPx);
+    WaveLds<float> w(smem, C2, uc.span * kChunkPx, uc.stage);
     ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, span, w, g);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
     const float *tw = tnorm + off[g.b];
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {

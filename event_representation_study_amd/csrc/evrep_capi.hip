@@ -311,13 +311,18 @@ static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, 
     return EVREP_OK;
 }
 
-// 128-pixel chunks one builder wave takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on sparse windows (<= 30 records per
-// chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel fast path), else 1.
-static int builder_span(const evrep_plan *plan, size_t pixel_bytes) {
-    if (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) return 1;  // a 128-pixel chunk is already >= 8 KB
+// The unit of one builder wave.  span = 128-pixel chunks it takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on
+// sparse windows (<= 30 records per chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel
+// fast path), else 1.  stage = records its LDS stage holds: 64 for one-chunk units, 128 for wider ones (they hold ~65
+// records on the sparse windows they are chosen for).
+static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_chunks = 0) {
+    UnitCfg uc;
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
-    return per_chunk <= 30.0 ? 2 : 1;
+    uc.span = (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) ? 1 : (per_chunk <= 30.0 ? 2 : 1);  // a 128-pixel chunk of >= 8 KB stays alone
+    uc.stage = (uc.span + extra_chunks > 1) ? 128 : 64;
+    return uc;
 }
+static int builder_span(const evrep_plan *plan, size_t pixel_bytes) { return unit_cfg(plan, pixel_bytes).span; }
 #define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
 
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
@@ -336,11 +341,12 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     bool ergo = C == Ergo12Table::kC;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
-    const int span = builder_span(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+    const UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+    const int span = uc.span;
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx), stream>>>(                              \
+    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx, uc.stage), stream>>>(                    \
         bin_view(plan, workspace), offsets, P, plan->H, plan->W,  \
-        plan->nchunk, span, scale, static_cast<T *>(out))
+        plan->nchunk, uc, scale, static_cast<T *>(out))
 #define MDES_RUNTIME(T)                                     \
     do {                                                    \
         if (C <= 4) MDES_LAUNCH(T, RuntimeDesc<4>);         \
@@ -372,9 +378,10 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, (size_t)stack_size * 4);
-    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx), stream>>>(
-        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, span, stack_size,
+    const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4);
+    const int span = uc.span;
+    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage), stream>>>(
+        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size,
         premap, scale, out);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
@@ -392,13 +399,15 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
-        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8, kChunkPx), stream>>>(
-            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, 1, slices, tau,
+        const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20);  // one-chunk units whatever the slice count
+        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8, kChunkPx, uc.stage), stream>>>(
+            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau,
             premap, scale, static_cast<double *>(out));
     } else {
-        const int span = builder_span(plan, (size_t)2 * slices * 4);
-        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4, span * kChunkPx), stream>>>(
-            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, span, slices, tau,
+        const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4);
+        const int span = uc.span;
+        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4, span * kChunkPx, uc.stage), stream>>>(
+            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau,
             premap, scale, static_cast<float *>(out));
     }
     LAUNCH_CHECK("k_time_surface");
@@ -418,10 +427,11 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     if (sample_times_f && !tf) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, (size_t)2 * k * 4);
-    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx), stream>>>(
+    const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
+    const int span = uc.span;
+    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(
         reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets,
-        sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, span, k, frame_mode,
+        sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, uc, k, frame_mode,
         scale, out);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
@@ -439,10 +449,11 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
     if (t_range && mode != 2) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, (size_t)bins * 8);
-    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx), stream>>>(
+    const UnitCfg uc = unit_cfg(plan, (size_t)bins * 8);
+    const int span = uc.span;
+    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(
         reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, plan->H,
-        plan->W, plan->nchunk, span, bins, mode, scale, t_range, out);
+        plan->W, plan->nchunk, uc, bins, mode, scale, t_range, out);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }
@@ -481,9 +492,10 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
         P.stat[c] = stat[c];
     }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, (size_t)C * 4);
-    k_polstats<<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx), stream>>>(
-        bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, span, out);
+    const UnitCfg uc = unit_cfg(plan, (size_t)C * 4);
+    const int span = uc.span;
+    k_polstats<<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage), stream>>>(
+        bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
     LAUNCH_CHECK("k_polstats");
     return EVREP_OK;
 }
@@ -501,10 +513,11 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     P.lo = lo; P.inv_width = (double)nbucket / (hi - lo);
     for (int i = 0; i < C; ++i) P.shift[i] = (float)((double)i / (double)(C - 1));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int span = builder_span(plan, (size_t)2 * C * 4);
-    k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx), stream>>>(
+    const UnitCfg uc = unit_cfg(plan, (size_t)2 * C * 4);
+    const int span = uc.span;
+    k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, uc.stage), stream>>>(
         bin_view(plan, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
-        plan->nchunk, span, out);
+        plan->nchunk, uc, out);
     LAUNCH_CHECK("k_est");
     return EVREP_OK;
 }
