@@ -1083,6 +1083,8 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
 //         52-108): the bilinear weight is taken from the INTEGER bin (:74), so the lower bin receives p
 //         and the upper bin an exact zero -- a signed event count per (time bin, y, x).
 // --------------------------------------------------------------------------------------------
+// CM = compile-time channel capacity (8 or 16): the register arrays of a <= 8-bin grid are half the size
+template <int CM>
 __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
                                                 const int64_t *__restrict__ t_range, double *__restrict__ out) {
@@ -1119,9 +1121,9 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
         const double bp = bin_pos(r.z);
         return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
     };
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[EVREP_MAX_CHANNELS]) {
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[CM]) {
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = 0.0;
+        for (int c = 0; c < CM; ++c) vals[c] = 0.0;
         // two np.add.at passes: lower bin for every event, then upper bin for every event
         for (int pass = 0; pass < (mode == 2 ? 1 : 2); ++pass) {
             for (uint32_t j = jb; j < je; ++j) {
@@ -1141,16 +1143,16 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
                     else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
                     const double wp = wgt * p;
 #pragma unroll
-                    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c == blim) vals[c] = vals[c] + wp;
+                    for (int c = 0; c < CM; ++c) if (c == blim) vals[c] = vals[c] + wp;
                 }
             }
         }
         if (scale != 1.0) {
 #pragma unroll
-            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = vals[c] * scale;
+            for (int c = 0; c < CM; ++c) vals[c] = vals[c] * scale;
         }
     };
-    emit_chunk<double, EVREP_MAX_CHANNELS>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
+    emit_chunk<double, CM>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1165,6 +1167,7 @@ struct PolStatParams {
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
 // (6 waves per SIMD asked for: 110 -> 80 VGPRs with 52 bytes of scratch, 81 -> 64 us at 32 x 50 000 events, 640x480x6;
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
+template <int CM>
 __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, UnitCfg uc,
@@ -1180,9 +1183,9 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
     // empty pixels: 0, except EXP channels = exp(-(1 - 0)/tau)  (imagenet.py:463,466)
     bool any_bg = false;
 #pragma unroll
-    for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
+    for (int c = 0; c < CM; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
     if (any_bg) {
-        if (lane < EVREP_MAX_CHANNELS) {
+        if (lane < CM) {
             float v = 0.0f;
             if (lane < C && P.stat[lane] == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - 0.0) / P.tau);
             w.bg[lane] = v;
@@ -1190,7 +1193,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
         wave_phase();
     }
     const float *bg = any_bg ? w.bg : nullptr;
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
         int n_any = 0, n_pos = 0, n_neg = 0;
         double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
         for (uint32_t j = jb; j < je; ++j) {
@@ -1210,7 +1213,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
             }
         }
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+        for (int c = 0; c < CM; ++c) {
             float v = 0.0f;
             if (c < C) {
                 const int k = P.pol[c], st = P.stat[c];
@@ -1227,7 +1230,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    emit_chunk<float, CM>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------

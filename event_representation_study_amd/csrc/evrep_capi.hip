@@ -451,9 +451,12 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)bins * 8);
     const int span = uc.span;
-    k_voxel<<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(
-        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, plan->H,
-        plan->W, plan->nchunk, uc, bins, mode, scale, t_range, out);
+#define VOXEL_LAUNCH(CM)                                                                                         \
+    k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(              \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
+        bins, mode, scale, t_range, out)
+    if (bins <= 8) VOXEL_LAUNCH(8); else VOXEL_LAUNCH(16);
+#undef VOXEL_LAUNCH
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }
@@ -494,8 +497,12 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)C * 4);
     const int span = uc.span;
-    k_polstats<<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage), stream>>>(
-        bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
+    if (C <= 8)
+        k_polstats<8><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage), stream>>>(
+            bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
+    else
+        k_polstats<16><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage), stream>>>(
+            bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
     LAUNCH_CHECK("k_polstats");
     return EVREP_OK;
 }
