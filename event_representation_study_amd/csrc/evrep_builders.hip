@@ -781,6 +781,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
+template <int CM>  // compile-time channel capacity (8, 12 or 16)
 __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
                                                       int S, int premap, float scale, float *__restrict__ out) {
@@ -791,13 +792,13 @@ __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
     const int64_t n_win = off[g.b + 1] - off[g.b];
     // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
-    int offk[EVREP_MAX_CHANNELS];
+    int offk[CM];
     {
         int cur = (int)n_win, o = 0;
 #pragma unroll
-        for (int k = 0; k < EVREP_MAX_CHANNELS; ++k) { offk[k] = o; cur /= 2; o += cur; }
+        for (int k = 0; k < CM; ++k) { offk[k] = o; cur /= 2; o += cur; }
     }
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
         const Rec e = get(je - 1);  // ndarray.put is last-write-wins (event_stack.py:125)
         int p = e.w;
         if (premap == 1) p = (p + 1) >> 1;                   // (p + 1) // 2   (gen1_transforms.py:34)
@@ -805,9 +806,9 @@ __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
         // formed it, negated for the reversed "future" half, event_stack.py:35)
         const float v = (float)(int8_t)(premap == 2 ? p : 2 * p - 1) * scale;
 #pragma unroll
-        for (int l = 0; l < EVREP_MAX_CHANNELS; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
+        for (int l = 0; l < CM; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, reduce);
+    emit_chunk<float, CM>(u, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -906,7 +907,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
     }
 }
 
-template <typename OutT>
+template <typename OutT, int CM>  // CM = compile-time channel capacity, 2 * slices <= CM (12 or 16)
 __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
@@ -918,29 +919,29 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     // the window's cuts, held in registers with compile-time indices only (no scratch)
     const TsCuts *cp = cuts + g.b;
-    struct { int idx[kMaxSlices], tcut[kMaxSlices], live[kMaxSlices]; } cu;
+    struct { int idx[(CM / 2)], tcut[(CM / 2)], live[(CM / 2)]; } cu;
 #pragma unroll
-    for (int q = 0; q < kMaxSlices; ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
+    for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
     // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
     // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
     const double inv_tau = 1.0 / tau;
     // the background of every slice was computed once per window by k_ts_cuts
-    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
+    if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
     wave_phase();
     const OutT *bg = w.bg;
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[EVREP_MAX_CHANNELS]) {
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
         // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it.  INT32_MIN =
         // never written.  Slices cut strictly before an event see the memory as it stands before it.
-        int snap0[kMaxSlices], snap1[kMaxSlices];
+        int snap0[(CM / 2)], snap1[(CM / 2)];
 #pragma unroll
-        for (int q = 0; q < kMaxSlices; ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
+        for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
         int cur0 = INT32_MIN, cur1 = INT32_MIN;
         uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
         for (uint32_t j = jb; j <= je; ++j) {
             int rank = INT32_MAX, t = 0, p = 0;
             if (j < je) { const Rec e = get(j); rank = e.y; t = e.z; p = e.w; }
 #pragma unroll
-            for (int q = 0; q < kMaxSlices; ++q) {
+            for (int q = 0; q < (CM / 2); ++q) {
                 if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
             }
             if (j < je) {
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
         }
         // pass 2: one straight-line batch of exponentials, the same for every lane of the wave
 #pragma unroll
-        for (int q = 0; q < kMaxSlices; ++q) {
+        for (int q = 0; q < (CM / 2); ++q) {
             OutT v0 = bg[2 * q], v1 = bg[2 * q + 1];
             if (q < S && cu.live[q]) {
                 const double tc = (double)cu.tcut[q];
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
             vals[2 * q + 1] = v1;
         }
     };
-    emit_chunk<OutT, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    emit_chunk<OutT, CM>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -977,6 +978,7 @@ constexpr int kMaxToreK = 8;
 
 // grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
+template <int CM>  // compile-time channel capacity, 2 * K <= CM (12 or 16)
 __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
@@ -1027,14 +1029,14 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
     // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
     const double log_min = log(151.0);
     const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
-    if ((int)threadIdx.x < EVREP_MAX_CHANNELS) w.bg[threadIdx.x] = bgv;
+    if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = bgv;
     wave_phase();
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
-        int fp[kMaxToreK], fn[kMaxToreK];
+    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
+        int fp[(CM / 2)], fn[(CM / 2)];
         int np_ = 0, nn_ = 0;
 #pragma unroll
-        for (int q = 0; q < kMaxToreK; ++q) { fp[q] = 0; fn[q] = 0; }
+        for (int q = 0; q < (CM / 2); ++q) { fp[q] = 0; fn[q] = 0; }
         for (uint32_t j = jb; j < je; ++j) {
             const Rec e = get(j);
             // ts < currentSampleTime (tore.py:17): events at T are dropped
@@ -1042,18 +1044,18 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
             const int held = tw ? e.y : e.z;
             if (e.w > 0) {
 #pragma unroll
-                for (int q = kMaxToreK - 1; q > 0; --q) fp[q] = fp[q - 1];
+                for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
                 fp[0] = held; ++np_;
             } else {
 #pragma unroll
-                for (int q = kMaxToreK - 1; q > 0; --q) fn[q] = fn[q - 1];
+                for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
                 fn[0] = held; ++nn_;
             }
         }
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) vals[c] = bgv;
+        for (int c = 0; c < CM; ++c) vals[c] = bgv;
 #pragma unroll
-        for (int q = 0; q < kMaxToreK; ++q) {
+        for (int q = 0; q < (CM / 2); ++q) {
             float vp = bgv, vn = bgv;
             if (q < np_) {
                 float v = tw ? (float)(Td - tw[fp[q]]) : (float)(double)((int64_t)T - (int64_t)fp[q]);
@@ -1067,13 +1069,13 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
             }
             // channel layout: positives [0, K), negatives [K, 2K)
 #pragma unroll
-            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+            for (int c = 0; c < CM; ++c) {
                 if (q < K && c == q) vals[c] = vp;
                 if (q < K && c == K + q) vals[c] = vn;
             }
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(ur, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
+    emit_chunk<float, CM>(ur, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------

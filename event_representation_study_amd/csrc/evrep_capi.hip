@@ -380,9 +380,11 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4);
     const int span = uc.span;
-    k_event_stack<<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage), stream>>>(
-        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size,
-        premap, scale, out);
+#define ES_LAUNCH(CM)                                                                                              \
+    k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage), stream>>>(   \
+        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out)
+    if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
+#undef ES_LAUNCH
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
 }
@@ -400,16 +402,17 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     LAUNCH_CHECK("k_ts_cuts");
     if (out_dtype == EVREP_F64) {
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20);  // one-chunk units whatever the slice count
-        k_time_surface<double><<<BUILDER_GRID, kWave, chunk_lds_bytes(2 * slices, 8, kChunkPx, uc.stage), stream>>>(
-            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau,
-            premap, scale, static_cast<double *>(out));
+#define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
+    k_time_surface<T, CM><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(               \
+        bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
+        static_cast<T *>(out))
+        if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
     } else {
         const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4);
         const int span = uc.span;
-        k_time_surface<float><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * slices, 4, span * kChunkPx, uc.stage), stream>>>(
-            bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau,
-            premap, scale, static_cast<float *>(out));
+        if (slices <= 6) TS_LAUNCH(float, 12, SPAN_GRID(span), span * kChunkPx); else TS_LAUNCH(float, 16, SPAN_GRID(span), span * kChunkPx);
     }
+#undef TS_LAUNCH
     LAUNCH_CHECK("k_time_surface");
     return EVREP_OK;
 }
@@ -429,10 +432,12 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
     const int span = uc.span;
-    k_tore<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(
-        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets,
-        sample_times, tf, sample_times_f, plan->H, plan->W, plan->nchunk, uc, k, frame_mode,
-        scale, out);
+#define TORE_LAUNCH(CM)                                                                                             \
+    k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, sample_times, tf, sample_times_f,    \
+        plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out)
+    if (k <= 6) TORE_LAUNCH(12); else TORE_LAUNCH(16);
+#undef TORE_LAUNCH
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
 }
