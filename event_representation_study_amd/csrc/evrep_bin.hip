@@ -748,13 +748,20 @@ template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
-                                                                     int nchunk, int kpr, int chunk_shift, Rec *__restrict__ sorted2,
+                                                                     int nchunk, int kpr, int chunk_shift, int by_key,
+                                                                     Rec *__restrict__ sorted2,
                                                                      uint32_t *__restrict__ chunk_off, WindowMeta *__restrict__ meta) {
-    extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(W)]
+    // by_key (runs of k_block_keysort, kpr = nchunk): the wave's unit is one KEY = (row, 128-pixel chunk) instead of a
+    // whole sensor row -- nchunk times the waves, each with a register-resident unit and 128 column counters; what dense
+    // windows want (a 1280-pixel row of a 10^6-event window holds ~1400 records: six register batches walked twice).
+    extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(unit width)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, row = blockIdx.x * kCsWaves + wave;
-    if (row >= H) return;
-    uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(W);
+    const int b = blockIdx.y, unit = blockIdx.x * kCsWaves + wave;
+    if (unit >= (by_key ? H * kpr : H)) return;
+    const int row = by_key ? unit / kpr : unit;
+    const int ck = by_key ? unit - row * kpr : 0;
+    const int Wu = by_key ? min(kChunkPx, W - ck * kChunkPx) : W;  // columns of the unit
+    uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(by_key ? kChunkPx : W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
     const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);  // <= kCsMaxRuns block runs of 1 << chunk_shift events
@@ -767,11 +774,11 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         const int k = lane + h * kWave;
         if (k < nb) {
             const uint32_t *tk = table + ((size_t)b * nblk + k) * ((size_t)H * kpr + 1);
-            ta[h] = tk[(size_t)row * kpr];
-            tb[h] = tk[(size_t)(row + 1) * kpr];
+            ta[h] = tk[by_key ? (size_t)unit : (size_t)row * kpr];
+            tb[h] = tk[by_key ? (size_t)unit + 1 : (size_t)(row + 1) * kpr];
         }
     }
-    if (row == 0) {  // this wave also publishes the window's statistics
+    if (unit == 0) {  // this wave also publishes the window's statistics
         BlockStats st;
         stats_identity(st);
 #pragma unroll
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
     // runs (lanes >= nb hold pre = n, so they never match a j < n); more: pre / src go through 2 x 128 words of the wave's
     // LDS and every lane finds its run by a 7-step binary search -- pre is non-decreasing, the LAST k with pre_k <= j
     // holds record j
-    uint32_t *runs = cnt + col_sort_words(W);  // [2][128], only used when nb > kBsChainBlocks
+    uint32_t *runs = cnt + col_sort_words(by_key ? kChunkPx : W);  // [2][128], only used when nb > kBsChainBlocks
     if (nb > kBsChainBlocks) {
         runs[lane] = pre0;
         runs[kWave + lane] = pre1;
@@ -854,16 +861,20 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         e[i] = make_int4(0, 0, 0, 0);
         if (j < n) e[i] = fetch(j);
     }
-    const int nbits = bits_for(W);
-    const int per4 = col_sort_per4(W);  // 16-byte vectors of column counters per lane (the array is padded to 64 * per4 * 4)
+    const int nbits = bits_for(Wu);
+    const int per4 = col_sort_per4(Wu);  // 16-byte vectors of column counters per lane (the array is padded to 64 * per4 * 4)
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt) + (size_t)lane * per4;
     volatile uint32_t *vcnt = cnt;
     uint32_t *co = chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+    if (by_key && lane == 0) {  // the unit IS one chunk: its offset, and the row's end behind the last chunk
+        co[ck] = rbeg;
+        if (ck == kpr - 1) co[kpr] = rend;
+    }
     if (n == 0) {
-        for (int c = lane; c <= nchunk; c += kWave) co[c] = rbeg;
+        if (!by_key) for (int c = lane; c <= nchunk; c += kWave) co[c] = rbeg;
         return;
     }
-    const int rowbase = row * W;
+    const int rowbase = row * W + ck * kChunkPx;
     const uint32_t nsuper = (n + kSuper - 1) / kSuper;
     for (int k = 0; k < per4; ++k) cnt4[k] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase_lds();
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         cnt4[k] = o;
     }
     wave_phase_lds();
-    for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rbeg + cnt[c * kChunkPx] : rend;
+    if (!by_key) for (int c = lane; c <= nchunk; c += kWave) co[c] = (c * kChunkPx < W) ? rbeg + cnt[c * kChunkPx] : rend;
     wave_phase_lds();
     for (uint32_t sb = 0; sb < nsuper; ++sb) {
 #pragma unroll

@@ -162,7 +162,16 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
                             ((double)max_events_per_window <= 30.0 * (double)NK || getenv("EVREP_BIN_KEY_SORTED")) &&
                             !getenv("EVREP_BIN_CLASSIC") &&
                             !getenv("EVREP_BIN_THREE_KERNEL");
+    // dense windows on the same sensors: k_block_keysort + the column sort run per KEY (k_col_sort_runs, by_key),
+    // then the classic builders on the pixel-sorted stream
+    const bool key_dense = !key_sorted && two_kernel && NK < 65535 &&
+                           block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
+                           !getenv("EVREP_BIN_CLASSIC") && !getenv("EVREP_BIN_THREE_KERNEL");
     size_t table_words = (size_t)B * nblk * (H + 1);
+    if (key_dense) {
+        plan->reserved = 3;
+        table_words = (size_t)B * nblk * ((size_t)NK + 1);
+    }
     if (key_sorted) {
         plan->reserved = 2;
         // windows of <= 16 x 4096 events: 4096-event blocks (the builder waves still find a record's run by the
@@ -202,6 +211,18 @@ static int check_common(const evrep_plan *plan, const void *events, const void *
 #define WS(type, field) reinterpret_cast<type *>(static_cast<char *>(workspace) + plan->field)
 #define CWS(type, field) reinterpret_cast<const type *>(static_cast<const char *>(workspace) + plan->field)
 
+// The pixel-sorted stream + chunk offsets + WindowMeta from the runs of k_block_keysort: the column sort, one wave per key.
+static int column_sort_keys(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
+    const int NK = plan->H * plan->nchunk;
+    k_col_sort_runs<kCsRowsPerWave><<<dim3((NK + kCsWaves - 1) / kCsWaves, plan->B), kCsWaves * kWave,
+                                      (size_t)kCsWaves * col_sort_wave_words(kChunkPx) * 4, stream>>>(
+        CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
+        plan->nchunk, plan->nchunk, plan->chunk == 4096 ? 12 : 13, 1, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff),
+        WS(WindowMeta, off_meta));
+    LAUNCH_CHECK("k_col_sort_runs");
+    return EVREP_OK;
+}
+
 int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                      void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
@@ -216,8 +237,8 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     Rec *s2 = WS(Rec, off_sorted2);
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
-    if (plan->reserved == 2) {
-        if ((chunk != kBsChunk && chunk != 4096) || nblk > kBsMaxBlocks) return EVREP_EINVAL;
+    if (plan->reserved == 2 || plan->reserved == 3) {
+        if ((chunk != kBsChunk && chunk != 4096) || nblk > (plan->reserved == 2 ? kBsMaxBlocks : kCsMaxRuns)) return EVREP_EINVAL;
         const int NK = H * plan->nchunk;
         static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
         if (!attr_set) {
@@ -241,6 +262,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
                 ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
         }
         LAUNCH_CHECK("k_block_keysort");
+        if (plan->reserved == 3) return column_sort_keys(plan, offsets, workspace, stream);
         return EVREP_OK;
     }
     if (plan->reserved == 1) {
@@ -259,7 +281,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
         k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
-            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, s2, WS(uint32_t, off_chunkoff), meta);
+            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, 0, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
     }
@@ -302,13 +324,7 @@ static BinView bin_view(const evrep_plan *plan, void *workspace) {
 // them directly (k_voxel_subpixel).  The column sort of the two-kernel pass, reading a row's runs chunk by chunk.
 static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
     if (plan->reserved != 2) return EVREP_OK;
-    constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
-    k_col_sort_runs<kCsRowsPerWave><<<dim3((plan->H + rows_per_wg - 1) / rows_per_wg, plan->B), kCsWaves * kWave,
-                                      (size_t)kCsWaves * col_sort_wave_words(plan->W) * 4, stream>>>(
-        CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
-        plan->nchunk, plan->nchunk, plan->chunk == 4096 ? 12 : 13, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff), WS(WindowMeta, off_meta));
-    LAUNCH_CHECK("k_col_sort_runs");
-    return EVREP_OK;
+    return column_sort_keys(plan, offsets, workspace, stream);
 }
 
 // The unit of one builder wave.  span = 128-pixel chunks it takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on

@@ -92,8 +92,8 @@ def test_the_pass_is_chosen_for_the_headline_windows_and_matches_the_oracle(orac
         assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event stack w%d" % b)
         assert_bit_equal(vx[b], oracle.voxel(ev, H, W, 5), "voxel w%d" % b)
     assert not eb.status().any()
-    # a dense window of the same sensor keeps the classic pass
-    assert eng.EventBatch.from_numpy([make_events(200000, W, H, seed=1)], H, W).plan.reserved == 1
+    # a dense window of the same sensor: k_block_keysort + the per-key column sort, then the classic builders
+    assert eng.EventBatch.from_numpy([make_events(200000, W, H, seed=1)], H, W).plan.reserved == 3
 
 
 def test_gen4_sensor_two_round_stage(oracle, monkeypatch):
@@ -145,9 +145,9 @@ def test_many_block_runs(oracle, n, monkeypatch):
         assert_bit_equal(ks.optimized()[b].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))
     assert_bit_equal(ks.event_stack().cpu().numpy(), cl.event_stack().cpu().numpy(), "event stack")
     assert_bit_equal(ks.tore(6, frame_mode=1).cpu().numpy(), cl.tore(6, frame_mode=1).cpu().numpy(), "tore")
-    # one event more than 64 blocks: a builder wave has one lane per run -- the two-kernel pass, forced or not
+    # one event more than 64 blocks: a builder wave has one lane per run -- the column sort runs as a kernel, forced or not
     monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
-    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 1
+    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 3
 
 
 def test_status_bbox_and_failed_channels(monkeypatch):

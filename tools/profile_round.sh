@@ -28,6 +28,6 @@ python tools/gwd_matrix.py > $O/gwd_matrix.log 2>&1
 python tools/est_bench.py > $O/est_bench.json 2>/dev/null
 python tools/gw_bench.py > $O/gw_bench_f64.json 2>/dev/null
 python tools/gw_bench.py --precision f32 > $O/gw_bench_f32.json 2>/dev/null
-python tools/precompute_reps.py --samples 256 2>/dev/null | grep "^{" > $O/precompute.json
+python tools/precompute_reps.py --samples 1024 2>/dev/null | grep "^{" > $O/precompute.json
 find $O -name "*.csv" | head -40
 tail -c 900 $O/bench.json
