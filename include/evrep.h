@@ -62,7 +62,8 @@ typedef struct evrep_plan {
     int32_t chunk, nblk;           /* row-partition geometry (derived) */
     int32_t nchunk, reserved;      /* 128-pixel column chunks per row (derived); reserved = the binning pass chosen:
                                       2 = key-sorted (k_block_keysort alone; the builder waves finish the order by pixel),
-                                      1 = two kernels (k_block_rowsort + k_col_sort_runs), 0 = the three-kernel pass */
+                                      3 = k_block_keysort + the column sort per (row, chunk) key (dense windows),
+                                      1 = k_block_rowsort + the column sort per row, 0 = the three-kernel pass */
     size_t off_meta, off_table, off_stats, off_rowoff, off_chunkoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
     size_t workspace_bytes;
 } evrep_plan;
