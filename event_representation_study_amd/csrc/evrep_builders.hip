@@ -591,9 +591,12 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
 //   * whatever is not staged is fetched and digested on the fly.
 // (Re-staging the record range of every part tile of a dense chunk the same way was measured in round 2: the extra LDS
 // round trips cost more than the divergent loads and divisions they replace, for every builder but the voxel grid.)
-template <typename OutT, int CMAX, typename Digest, typename Reduce>
-__device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
-                                  WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+// `digest_fly(rec)` = what get(j) returns for a record that is NOT staged (read inside a walk): the same digest by
+// default; a builder whose digest is expensive and not needed by every reader of a record passes something cheaper and
+// tells the two forms apart by the index (staged: j < max(64, u.nstaged)).
+template <typename OutT, int CMAX, typename Digest, typename DigestFly, typename Reduce>
+__device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly digest_fly, int key0, int npix, int C,
+                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const uint32_t nrec = u.ce - u.cs, cs = u.cs, nraw = (uint32_t)u.nstaged;
     const Rec r0 = u.r0;
@@ -602,7 +605,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, in
     if (lane < (int)nrec) evbuf[lane] = digest(r0);
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nraw ? evbuf[j].x : sorted[cs + j].x); };
-    auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest(sorted[cs + j]); };
+    auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest_fly(sorted[cs + j]); };
     auto post_heads = [&]() {
         if (nraw > (uint32_t)kWave) {  // uniform: the second staged batch is still raw (key_at read its pixel ids)
             if (lane + kWave < (int)nraw) evbuf[lane + kWave] = digest(evbuf[lane + kWave]);
@@ -610,6 +613,11 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, in
         }
     };
     emit_core<OutT, CMAX>(nrec, key_at, get, post_heads, key0, npix, C, dst, w, bg, reduce);
+}
+template <typename OutT, int CMAX, typename Digest, typename Reduce>
+__device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
+                                  WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+    emit_chunk<OutT, CMAX>(u, digest, digest, key0, npix, C, dst, w, bg, reduce);
 }
 template <typename OutT, int CMAX, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
@@ -845,10 +853,14 @@ struct TsCuts {
     int32_t idx[kMaxSlices];   // searchsorted(t_norm, s+1, 'left')  (or the caller's indices)
     int32_t tcut[kMaxSlices];  // t[idx[s]]
     int32_t live[kMaxSlices];  // 1 iff the sequential scan reaches this slice (strictly increasing idx)
-    int32_t pad[8];
+    int32_t tref;              // reference time of the factorised exponentials: the last live cut's timestamp
+    int32_t direct;            // 1: the window spans more than 600 tau -- exponentials are taken per slice, unfactorised
+    int32_t pad[6];
     double bg[2 * kMaxSlices];  // value of an untouched (pixel, polarity) entry of slice s, already scaled
+    double fac[kMaxSlices];    // exp((tref - tcut[s]) / tau) * scale
+    double pad2[8];
 };
-static_assert(sizeof(TsCuts) == 256, "TsCuts");
+static_assert(sizeof(TsCuts) == 384, "TsCuts");
 
 // grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
 // int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
@@ -904,10 +916,28 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
             cuts[b].bg[2 * k] = v;
             cuts[b].bg[2 * k + 1] = v;
         }
+        // exp((m - t_s) / tau) = exp((m - tref) / tau) * exp((tref - t_s) / tau): the first factor depends on the event
+        // only (one exponential per EVENT, formed by the builder's digest), the second on the slice only (here)
+        int tref = 0;
+        for (int k = 0; k < kMaxSlices; ++k) if (k < S && cuts[b].live[k]) tref = cuts[b].tcut[k];  // cut times ascend
+        int direct = 0;
+        for (int k = 0; k < kMaxSlices; ++k) {
+            double f = 0.0;
+            if (k < S && cuts[b].live[k]) {
+                const double x = ((double)tref - (double)cuts[b].tcut[k]) * (1.0 / tau);
+                if (x > 600.0) direct = 1;
+                f = exp(x) * scale;
+            }
+            cuts[b].fac[k] = f;
+        }
+        cuts[b].tref = tref;
+        cuts[b].direct = direct;
     }
 }
 
-template <typename OutT, int CM>  // CM = compile-time channel capacity, 2 * slices <= CM (12 or 16)
+// CM = compile-time channel capacity, 2 * slices <= CM (12 or 16); FACT = the factorised exponentials are compiled in
+// (launches on sparse windows; dense windows run the leaner per-slice form)
+template <typename OutT, int CM, bool FACT>
 __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
@@ -925,13 +955,29 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
     // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
     // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
     const double inv_tau = 1.0 / tau;
+    // exp((m - t_s)/tau) = exp((m - tref)/tau) * fac[s]: ONE exponential per event, formed by the digest -- one record per
+    // lane, all lanes at once -- instead of two per slice and touched pixel inside the per-pixel code (12 per pixel for the
+    // reference's 6 slices).  The digest keeps {E lo, rank, E hi, p}.  This factorised form is used by the waves whose
+    // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
+    // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
+    const int tref = cp->tref;
+    const bool fact = FACT && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
+    double fac[(CM / 2)];
+#pragma unroll
+    for (int q = 0; q < (CM / 2); ++q) fac[q] = cp->fac[q];
     // the background of every slice was computed once per window by k_ts_cuts
     if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
     wave_phase();
     const OutT *bg = w.bg;
+    auto digest = [&](const Rec &r) -> Rec {
+        if (!fact) return r;
+        const double E = exp_neg_range(((double)r.z - (double)tref) * inv_tau);
+        return make_int4(__double2loint(E), r.y, __double2hiint(E), r.w);
+    };
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
-        // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it.  INT32_MIN =
-        // never written.  Slices cut strictly before an event see the memory as it stands before it.
+        // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it, per polarity -- the record
+        // index of the last event (factorised form) or its timestamp.  INT32_MIN = never written.  Slices cut strictly
+        // before an event see the memory as it stands before it.
         int snap0[(CM / 2)], snap1[(CM / 2)];
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
@@ -939,7 +985,7 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
         uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
         for (uint32_t j = jb; j <= je; ++j) {
             int rank = INT32_MAX, t = 0, p = 0;
-            if (j < je) { const Rec e = get(j); rank = e.y; t = e.z; p = e.w; }
+            if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : e.z; p = e.w; }
 #pragma unroll
             for (int q = 0; q < (CM / 2); ++q) {
                 if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
@@ -949,26 +995,31 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
                 if (p & 1) cur1 = t; else cur0 = t;
             }
         }
-        // pass 2: one straight-line batch of exponentials, the same for every lane of the wave
+        // pass 2
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) {
             OutT v0 = bg[2 * q], v1 = bg[2 * q + 1];
             if (q < S && cu.live[q]) {
-                const double tc = (double)cu.tcut[q];
-                if (__any(snap0[q] != INT32_MIN)) {
-                    const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
-                    if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
-                }
-                if (__any(snap1[q] != INT32_MIN)) {
-                    const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
-                    if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
+                if (fact) {  // the snapshot records' exponentials times the slice factor
+                    if (snap0[q] != INT32_MIN) { const Rec e = get((uint32_t)snap0[q]); v0 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
+                    if (snap1[q] != INT32_MIN) { const Rec e = get((uint32_t)snap1[q]); v1 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
+                } else {     // one straight-line batch of exponentials, the same for every lane of the wave
+                    const double tc = (double)cu.tcut[q];
+                    if (__any(snap0[q] != INT32_MIN)) {
+                        const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
+                        if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
+                    }
+                    if (__any(snap1[q] != INT32_MIN)) {
+                        const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
+                        if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
+                    }
                 }
             }
             vals[2 * q] = v0;
             vals[2 * q + 1] = v1;
         }
     };
-    emit_chunk<OutT, CM>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    emit_chunk<OutT, CM>(u, digest, [](const Rec &r) -> Rec { return r; }, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -416,12 +416,15 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     TsCuts *cuts = WS(TsCuts, off_cuts);
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
     LAUNCH_CHECK("k_ts_cuts");
+    // sparse windows (practically every unit fully staged): the kernel with the factorised exponentials compiled in
+    const bool ts_fact = (double)plan->max_events_per_window <= 30.0 * (double)plan->H * plan->nchunk;
     if (out_dtype == EVREP_F64) {
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20);  // one-chunk units whatever the slice count
-#define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
-    k_time_surface<T, CM><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(               \
+#define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
+    k_time_surface<T, CM, F><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(            \
         bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
         static_cast<T *>(out))
+#define TS_LAUNCH(T, CM, GRID, SEG) do { if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG); } while (0)
         if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
     } else {
         const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4);
@@ -429,6 +432,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
         if (slices <= 6) TS_LAUNCH(float, 12, SPAN_GRID(span), span * kChunkPx); else TS_LAUNCH(float, 16, SPAN_GRID(span), span * kChunkPx);
     }
 #undef TS_LAUNCH
+#undef TS_LAUNCH_F
     LAUNCH_CHECK("k_time_surface");
     return EVREP_OK;
 }
