@@ -1083,50 +1083,50 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
     if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = bgv;
     wave_phase();
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
+    // The value of a FIFO slot depends on its event alone (one sample time per window): log(min(T - t, 5e8) + 1) - log(151),
+    // floored at 0 (tore.py:63-79).  So the digest forms it per EVENT -- one record per lane, all lanes at once, one logf --
+    // and the FIFOs hold finished values: 2 K logarithms per touched pixel become one per event.  Digest:
+    // {pixel id, value bits, 1 iff the event counts (ts < currentSampleTime, tore.py:17: events at T are dropped), p}.
+    auto digest = [&](const Rec &r) -> Rec {
+        bool counts;
+        float v;
+        if (tw) { const double te = tw[r.y]; counts = te < Td; v = (float)(Td - te); }
+        else { counts = r.z < T; v = (float)(double)((int64_t)T - (int64_t)r.z); }
+        v = fminf(v, 500e6f);
+        v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+        return make_int4(r.x, __float_as_int(v), counts ? 1 : 0, r.w);
+    };
     auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
-        int fp[(CM / 2)], fn[(CM / 2)];
-        int np_ = 0, nn_ = 0;
+        float fp[(CM / 2)], fn[(CM / 2)];  // most recent first; slots never filled keep the empty-FIFO value
 #pragma unroll
-        for (int q = 0; q < (CM / 2); ++q) { fp[q] = 0; fn[q] = 0; }
+        for (int q = 0; q < (CM / 2); ++q) { fp[q] = bgv; fn[q] = bgv; }
         for (uint32_t j = jb; j < je; ++j) {
             const Rec e = get(j);
-            // ts < currentSampleTime (tore.py:17): events at T are dropped
-            if (tw ? !(tw[e.y] < Td) : !(e.z < T)) continue;
-            const int held = tw ? e.y : e.z;
+            if (!e.z) continue;
+            const float v = __int_as_float(e.y);
             if (e.w > 0) {
 #pragma unroll
                 for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
-                fp[0] = held; ++np_;
+                fp[0] = v;
             } else {
 #pragma unroll
                 for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
-                fn[0] = held; ++nn_;
+                fn[0] = v;
             }
         }
 #pragma unroll
         for (int c = 0; c < CM; ++c) vals[c] = bgv;
+        // channel layout: positives [0, K), negatives [K, 2K)
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) {
-            float vp = bgv, vn = bgv;
-            if (q < np_) {
-                float v = tw ? (float)(Td - tw[fp[q]]) : (float)(double)((int64_t)T - (int64_t)fp[q]);
-                v = fminf(v, 500e6f);
-                vp = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
-            }
-            if (q < nn_) {
-                float v = tw ? (float)(Td - tw[fn[q]]) : (float)(double)((int64_t)T - (int64_t)fn[q]);
-                v = fminf(v, 500e6f);
-                vn = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
-            }
-            // channel layout: positives [0, K), negatives [K, 2K)
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
-                if (q < K && c == q) vals[c] = vp;
-                if (q < K && c == K + q) vals[c] = vn;
+                if (q < K && c == q) vals[c] = fp[q];
+                if (q < K && c == K + q) vals[c] = fn[q];
             }
         }
     };
-    emit_chunk<float, CM>(ur, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
+    emit_chunk<float, CM>(ur, digest, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
