@@ -738,13 +738,7 @@ constexpr int kCsMaxRuns = 128;
 __host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / kWave + 3) / 4; }
 __host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
 __host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_words(W) + 2 * kCsMaxRuns; }   // + the run table (pre, src)
-#ifndef EVREP_CS_ROWS
-#define EVREP_CS_ROWS 1
-#endif
-constexpr int kCsRowsPerWave = EVREP_CS_ROWS;
-static_assert(kCsRowsPerWave == 1, "k_col_sort_runs takes one row per wave");
 
-template <int R>
 __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,

@@ -51,7 +51,7 @@ struct UnitCfg {
 };
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
-// average record count per chunk, see builder_span() in evrep_capi.hip.
+// average record count per chunk, see unit_cfg() in evrep_capi.hip.
 
 // LDS carve of one builder wave.
 template <typename OutT>

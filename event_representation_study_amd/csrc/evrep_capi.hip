@@ -214,7 +214,7 @@ static int check_common(const evrep_plan *plan, const void *events, const void *
 // The pixel-sorted stream + chunk offsets + WindowMeta from the runs of k_block_keysort: the column sort, one wave per key.
 static int column_sort_keys(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
     const int NK = plan->H * plan->nchunk;
-    k_col_sort_runs<kCsRowsPerWave><<<dim3((NK + kCsWaves - 1) / kCsWaves, plan->B), kCsWaves * kWave,
+    k_col_sort_runs<<<dim3((NK + kCsWaves - 1) / kCsWaves, plan->B), kCsWaves * kWave,
                                       (size_t)kCsWaves * col_sort_wave_words(kChunkPx) * 4, stream>>>(
         CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
         plan->nchunk, plan->nchunk, plan->chunk == 4096 ? 12 : 13, 1, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff),
@@ -279,8 +279,8 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         k_block_rowsort<<<xgrid, kBsThreads, lds, stream>>>(ev, offsets, B, H, W, nblk, table, stats, s1);
         LAUNCH_CHECK("k_block_rowsort");
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
-        constexpr int rows_per_wg = kCsWaves * kCsRowsPerWave;
-        k_col_sort_runs<kCsRowsPerWave><<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
+        constexpr int rows_per_wg = kCsWaves;
+        k_col_sort_runs<<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
             s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, 0, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
@@ -338,7 +338,6 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     uc.stage = (uc.span + extra_chunks > 1) ? 128 : 64;
     return uc;
 }
-static int builder_span(const evrep_plan *plan, size_t pixel_bytes) { return unit_cfg(plan, pixel_bytes).span; }
 #define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
 
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
