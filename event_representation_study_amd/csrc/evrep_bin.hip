@@ -758,7 +758,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
     uint32_t *cnt = cnt_all + (size_t)wave * col_sort_wave_words(by_key ? kChunkPx : W);
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);  // <= kCsMaxRuns block runs of 1 << chunk_shift events
+    const int nb = min((int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift), nblk);  // <= kCsMaxRuns block runs of 1 << chunk_shift events
     // run k of the row = sorted1[beg + (k << chunk_shift) + t_k[row], ... + t_k[row + 1]); records of earlier rows = sum_k t_k[row]
     // kpr = keys per row of the run table: 1 after k_block_rowsort; nchunk after k_block_keysort, whose runs hold a
     // row's records chunk by chunk (time-ordered inside a chunk, which is all the stable column sort below needs)
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict
                                                       int nblk, int chunk_shift, WindowMeta *__restrict__ meta) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t n_win = nwin[b];
-    const int nb = (int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift);
+    const int nb = min((int)(((uint32_t)n_win + (1u << chunk_shift) - 1u) >> chunk_shift), nblk);
     BlockStats st;
     stats_identity(st);
     for (int k = lane; k < nb; k += kWave) stats_merge(st, stats[(size_t)b * nblk + k]);

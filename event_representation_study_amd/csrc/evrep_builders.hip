@@ -248,7 +248,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     }
     const int64_t beg = off[b];
     const int64_t n_win = off[b + 1] - beg;
-    const int nb = (int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift);
+    // (a window longer than the plan's max_events_per_window is the caller's error: its tail was not binned; stay in bounds)
+    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
     if (nb <= 0) return u;
     if (lane >= nb) { a = 0; len = 0; }
     const uint32_t incl = wave_incl_scan(len);
@@ -463,7 +464,7 @@ __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__res
     if (!bv.fused) return bv.meta[b];
     const int lane = threadIdx.x;
     const int64_t n_win = off[b + 1] - off[b];
-    const int nb = (int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift);
+    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
     BlockStats st;
     stats_identity(st);
     if (lane < nb) {
