@@ -49,6 +49,15 @@ def _builders(eb, rng_seed=0):
         "voxel_evl": eb.voxel(7, mode=2),
         "polstats": eb.polstats(tn, [1, 2, 1, 2, 0, 0], [0, 0, 1, 2, 4, 5]),
     }
+    # the float-time TORE of n_imagenet, an explicit ev-licious time range, the raw-polarity EventStack, the EST layer
+    tf = (torch.arange(eb.total, dtype=torch.float64) * 1e-6).to("cuda:0")  # any per-event float64 times: gathered by rank
+    out["tore_ftime"] = eb.tore(5, frame_mode=2, times_f64=tf)
+    tr = torch.tensor([[1000, 30000]] * eb.B, dtype=torch.int64)
+    out["voxel_range"] = eb.voxel(4, mode=2, t_range=tr)
+    out["event_stack_raw"] = eb.event_stack(7, premap=False)
+    seg = torch.tensor([[-0.25, 0.5, 0.1], [0.3, -1.5, 0.6], [1e9, 0.25, -0.2]], dtype=torch.float64, device="cuda:0")
+    bucket = torch.zeros(16, dtype=torch.int32, device="cuda:0")
+    out["est"] = eb.est_voxel(tn.to(torch.float32), 3, seg, bucket, -1.0, 1.0)
     out = {k: v.cpu().numpy() for k, v in out.items()}
     out["tore_bbox"] = [t.cpu().numpy() for t in eb.tore(6, frame_mode=0)]
     return out
