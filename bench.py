@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)   # 0.25 s of load: short runs on a fresh box are boosted, see DESIGN 5
+    ap.add_argument("--steps", type=int, default=1000)   # 0.2 s of load; boxes of the pool differ by up to 25 % in what they sustain, see DESIGN 5
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--events", type=int, default=EVENTS_PER_WINDOW)
