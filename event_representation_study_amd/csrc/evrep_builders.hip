@@ -147,7 +147,16 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
 __device__ inline int chunk_unit(int total) {
     const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 #if EVREP_XCD_MAP
-    if ((total & 7) == 0) return (lin & 7) * (total >> 3) + (lin >> 3);
+    if ((total & 7) == 0) {
+        const int per = total >> 3, xcd = lin & 7;
+#ifdef EVREP_XCD_ROT
+        int idx = (lin >> 3) + xcd * (EVREP_XCD_ROT);
+        idx %= per;
+#else
+        const int idx = lin >> 3;
+#endif
+        return xcd * per + idx;
+    }
 #endif
     return lin;
 }
