@@ -57,6 +57,9 @@ def parse():
                          "replayed from profiles/traffic.json and labelled so")
     ap.add_argument("--no-gw-extension", action="store_true",
                     help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
+    ap.add_argument("--probe-placement", type=int, default=0, metavar="N",
+                    help="allocate N candidate output tensors and keep the one the builder runs fastest into (DESIGN.md 8: "
+                         "the physical placement of the 0.94 GB tensor decides up to 25 %% of the launch); OFF by default")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -323,7 +326,14 @@ def main():
         for j in range(nbuf):
             wins = [make_events(N, W, H, seed=rank * 100000 + j * B + i) for i in range(B)]  # seed = window index
             batches.append(EventBatch.from_numpy(wins, H, W, device=device))
-            outs.append(torch.empty((B, H, W, C), dtype=dtype, device=device))
+            if args.probe_placement > 1:
+                from event_representation_study_amd.engine import probe_output_placement
+                o, best_us, all_us = probe_output_placement((B, H, W, C), dtype, lambda t, bb=batches[-1]: bb.optimized(scale=1.0, dtype=dtype, out=t),
+                                                            candidates=args.probe_placement, device=device)
+                placement = {"candidates": args.probe_placement, "best_us": best_us, "all_us": [round(x, 1) for x in all_us]}
+                outs.append(o)
+            else:
+                outs.append(torch.empty((B, H, W, C), dtype=dtype, device=device))
         pipe = BinBuildPipeline(device) if args.pipeline else None
 
         def build(k, ev_pair):
@@ -347,6 +357,7 @@ def main():
         step(k)
     if pipe is not None:
         pipe.drain()
+    placement_note = locals().get("placement")
     pairs = None if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                               for _ in range(args.steps)]
     sync()
@@ -391,6 +402,8 @@ def main():
         "windows_per_s": world * B * args.steps / el,
         "algorithmic_GBps_whole_step": world * alg_bytes * args.steps / el / 1e9,
     }
+    if placement_note:
+        result["config"]["output_placement_probe"] = placement_note   # --probe-placement: not the default measurement
     if dry:
         result["dry_run"] = True      # launcher / rendezvous / collectives only: NOT a measurement
         result["value"] = 0.0

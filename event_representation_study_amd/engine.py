@@ -357,6 +357,33 @@ class BinBuildPipeline:
         return self._flush()
 
 
+def probe_output_placement(shape, dtype, launch, candidates=8, launches=20, device="cuda:0"):
+    """Where a large output tensor lies in HBM decides up to 25 % of a builder launch on MI355X (the same
+    launch takes 134, 148 or 172 us into different 900 MiB allocations of one process; a linear fill does not care).
+    A service that allocates its output ring once can pick its allocations: this helper allocates `candidates` tensors,
+    times `launch(out)` into each (`launches` launches after 3 warm-up ones) and returns (best tensor, its us per launch,
+    all timings); the other tensors are released.  NOT used by bench.py unless --probe-placement is given."""
+    _require_gpu()
+    device = torch.device(device)
+    outs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(int(candidates))]
+    times = []
+    for o in outs:
+        for _ in range(3):
+            launch(o)
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(int(launches)):
+            launch(o)
+        b.record()
+        torch.cuda.synchronize(device)
+        times.append(a.elapsed_time(b) / launches * 1e3)
+    k = min(range(len(outs)), key=lambda i: times[i])
+    best = outs[k]
+    del outs
+    return best, times[k], times
+
+
 def gwd_padded_l1(Xs, Xt, h=0.7, out=None):
     """OTMI(Xs, Xt, h).solve()[1] on the GPU: Xs (n, ds), Xt (m, dt) array-likes -> 0-dim float64 cuda tensor.
     `out`: optional one-element float64 cuda tensor (e.g. ``costs[i:i+1]``) the kernel writes into directly --
