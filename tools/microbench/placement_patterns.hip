@@ -135,6 +135,24 @@ __global__ __launch_bounds__(256) void k_rot(nt4 *__restrict__ out, int n) {
     }
 }
 
+// one wave per 12 KiB tile; TOUCH: the first lanes LOAD one word from each of the tile's three 4 KiB pages when the wave
+// starts (translation prefetch), then the wave pauses SLEEP x ~0.03 us (the builder's front end), then stores
+template <int TOUCH, int SLEEP>
+__global__ __launch_bounds__(64) void k_touch(nt4 *__restrict__ out, int n, int *__restrict__ sink) {
+    extern __shared__ float4 lds[];
+    const int i = blockIdx.x;
+    const int t = (i % 8) * (n / 8) + i / 8;
+    nt4 z = {1.f, 2.f, 3.f, 4.f};
+    if (out == nullptr) { const float4 l = lds[threadIdx.x]; z.x = l.x; }
+    nt4 *b = out + (size_t)t * 12 * 64 + threadIdx.x;
+    int got = 0;
+    if (TOUCH && threadIdx.x < 3) got = __builtin_nontemporal_load(reinterpret_cast<const int *>(out + (size_t)t * 12 * 64 + threadIdx.x * 256));
+    if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+    if (TOUCH && got == 0x7fffffff) sink[0] = got;   // keeps the load alive; practically never true
+#pragma unroll
+    for (int q = 0; q < 12; ++q) __builtin_nontemporal_store(z, b + q * 64);
+}
+
 template <typename F>
 static float timed(F launch) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -160,16 +178,28 @@ int main(int argc, char **argv) {
     const bool burst = argc > 2 && argv[2][0] == 'b';
     const bool sizes = argc > 2 && argv[2][0] == 's';
     const bool rot = argc > 2 && argv[2][0] == 'r';
+    const bool touch = argc > 2 && argv[2][0] == 't';
+    int *sink; CHECK(hipMalloc(&sink, 64));
+    if (touch) printf("%-14s %8s %8s %8s %8s %8s\n", "buffer", "tile12", "sleep", "touch", "touch+sl", "tile4");
     if (rot) printf("%-14s %8s %8s %8s %8s\n", "buffer", "tile12", "tile4", "rot3", "blk4");
     if (sizes) printf("%-14s %8s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "t1", "t2", "t3", "t4", "t6", "t8", "t12", "t6@19w");
     if (burst) printf("%-14s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "memset", "tile12", "b4x3", "b3x4", "b2x6", "b1x12", "perm12");
     if (more) printf("%-14s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "memset", "tile12", "tile12x4", "inter48", "inter48t", "tile4", "tile24", "t12occ32", "t12occ10");
-    else if (!burst && !sizes && !rot) printf("%-14s %8s %8s %8s %8s %8s %8s\n", "buffer", "fill", "tile12", "tile12t", "tile12lin", "tile12d", "tile6x2");
+    else if (!burst && !sizes && !rot && !touch) printf("%-14s %8s %8s %8s %8s %8s %8s\n", "buffer", "fill", "tile12", "tile12t", "tile12lin", "tile12d", "tile6x2");
     void **bufs = (void **)malloc(sizeof(void *) * nbuf);
     for (int k = 0; k < nbuf; ++k) CHECK(hipMalloc(&bufs[k], bytes));
     for (int k = 0; k < nbuf; ++k) {
         nt4 *o = (nt4 *)bufs[k];
         const size_t nvec = bytes / 16;
+        if (touch) {
+            const float a = timed([&] { k_tile<1 | 2><<<n, 64, lds>>>(o, n); });
+            const float sl = timed([&] { k_touch<0, 100><<<n, 64, lds>>>(o, n, sink); });
+            const float tc = timed([&] { k_touch<1, 0><<<n, 64, lds>>>(o, n, sink); });
+            const float ts = timed([&] { k_touch<1, 100><<<n, 64, lds>>>(o, n, sink); });
+            const float t4 = timed([&] { k_tilev<4><<<n * 3, 64, 0>>>(o, n * 3); });
+            printf("%p %8.1f %8.1f %8.1f %8.1f %8.1f\n", bufs[k], a, sl, tc, ts, t4);
+            continue;
+        }
         if (rot) {
             const float a = timed([&] { k_tile<1 | 2><<<n, 64, lds>>>(o, n); });
             const float t4 = timed([&] { k_tilev<4><<<n * 3, 64, 0>>>(o, n * 3); });
