@@ -153,6 +153,30 @@ __global__ __launch_bounds__(64) void k_touch(nt4 *__restrict__ out, int n, int 
     for (int q = 0; q < 12; ++q) __builtin_nontemporal_store(z, b + q * 64);
 }
 
+// one wave per 12 KiB tile, stores with an explicit cache policy (gfx942 / gfx950 modifiers)
+#define ASM_STORE(MOD) asm volatile("global_store_dwordx4 %0, %1, off " MOD :: "v"(p), "v"(z) : "memory")
+template <int POL>
+__global__ __launch_bounds__(64) void k_pol(nt4 *__restrict__ out, int n) {
+    extern __shared__ float4 lds[];
+    const int i = blockIdx.x;
+    const int t = (i % 8) * (n / 8) + i / 8;
+    nt4 z = {1.f, 2.f, 3.f, 4.f};
+    if (out == nullptr) { const float4 l = lds[threadIdx.x]; z.x = l.x; }
+    nt4 *b = out + (size_t)t * 12 * 64 + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        nt4 *p = b + q * 64;
+        if (POL == 0) ASM_STORE("");
+        else if (POL == 1) ASM_STORE("nt");
+        else if (POL == 2) ASM_STORE("sc0");
+        else if (POL == 3) ASM_STORE("sc1");
+        else if (POL == 4) ASM_STORE("sc0 sc1");
+        else if (POL == 5) ASM_STORE("sc0 nt");
+        else if (POL == 6) ASM_STORE("sc1 nt");
+        else ASM_STORE("sc0 sc1 nt");
+    }
+}
+
 template <typename F>
 static float timed(F launch) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -179,18 +203,32 @@ int main(int argc, char **argv) {
     const bool sizes = argc > 2 && argv[2][0] == 's';
     const bool rot = argc > 2 && argv[2][0] == 'r';
     const bool touch = argc > 2 && argv[2][0] == 't';
+    const bool pol = argc > 2 && argv[2][0] == 'p';
+    if (pol) printf("%-14s %8s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "plain", "nt", "sc0", "sc1", "sc0sc1", "sc0nt", "sc1nt", "sc0sc1nt");
     int *sink; CHECK(hipMalloc(&sink, 64));
     if (touch) printf("%-14s %8s %8s %8s %8s %8s\n", "buffer", "tile12", "sleep", "touch", "touch+sl", "tile4");
     if (rot) printf("%-14s %8s %8s %8s %8s\n", "buffer", "tile12", "tile4", "rot3", "blk4");
     if (sizes) printf("%-14s %8s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "t1", "t2", "t3", "t4", "t6", "t8", "t12", "t6@19w");
     if (burst) printf("%-14s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "memset", "tile12", "b4x3", "b3x4", "b2x6", "b1x12", "perm12");
     if (more) printf("%-14s %8s %8s %8s %8s %8s %8s %8s %8s %8s\n", "buffer", "memset", "tile12", "tile12x4", "inter48", "inter48t", "tile4", "tile24", "t12occ32", "t12occ10");
-    else if (!burst && !sizes && !rot && !touch) printf("%-14s %8s %8s %8s %8s %8s %8s\n", "buffer", "fill", "tile12", "tile12t", "tile12lin", "tile12d", "tile6x2");
+    else if (!burst && !sizes && !rot && !touch && !pol) printf("%-14s %8s %8s %8s %8s %8s %8s\n", "buffer", "fill", "tile12", "tile12t", "tile12lin", "tile12d", "tile6x2");
     void **bufs = (void **)malloc(sizeof(void *) * nbuf);
     for (int k = 0; k < nbuf; ++k) CHECK(hipMalloc(&bufs[k], bytes));
     for (int k = 0; k < nbuf; ++k) {
         nt4 *o = (nt4 *)bufs[k];
         const size_t nvec = bytes / 16;
+        if (pol) {
+            const float p0 = timed([&] { k_pol<0><<<n, 64, lds>>>(o, n); });
+            const float p1 = timed([&] { k_pol<1><<<n, 64, lds>>>(o, n); });
+            const float p2 = timed([&] { k_pol<2><<<n, 64, lds>>>(o, n); });
+            const float p3 = timed([&] { k_pol<3><<<n, 64, lds>>>(o, n); });
+            const float p4 = timed([&] { k_pol<4><<<n, 64, lds>>>(o, n); });
+            const float p5 = timed([&] { k_pol<5><<<n, 64, lds>>>(o, n); });
+            const float p6 = timed([&] { k_pol<6><<<n, 64, lds>>>(o, n); });
+            const float p7 = timed([&] { k_pol<7><<<n, 64, lds>>>(o, n); });
+            printf("%p %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", bufs[k], p0, p1, p2, p3, p4, p5, p6, p7);
+            continue;
+        }
         if (touch) {
             const float a = timed([&] { k_tile<1 | 2><<<n, 64, lds>>>(o, n); });
             const float sl = timed([&] { k_touch<0, 100><<<n, 64, lds>>>(o, n, sink); });
