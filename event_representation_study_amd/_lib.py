@@ -47,6 +47,7 @@ SYMBOLS = {
     "evrep_plan_init": (ctypes.c_int, [_PP, _i32, _i32, _i32, _i64, _i64]),
     "evrep_workspace_bytes": (ctypes.c_size_t, [_PP]),
     "evrep_bin_events": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp]),
+    "evrep_probe_store": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),
     "evrep_mdes": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _I32P, _I32P, _I32P, _f64, _i32, _vp, _vp]),
     "evrep_optimized": (ctypes.c_int, [_PP, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
     "evrep_event_stack": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),

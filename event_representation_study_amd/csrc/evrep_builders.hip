@@ -1461,4 +1461,22 @@ __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restr
     for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c < bins) dst[c] = acc[c];
 }
 
+// --------------------------------------------------------------------------------------------
+// Placement probe: the write footprint of the float64 12-channel builder (one wave per 12 KiB tile, XCD-contiguous
+// eighths, non-temporal 16-byte stores, 19 waves per CU) with nothing else.  On MI355X the time of this kernel into a
+// 0.9 GB tensor takes one of three levels depending on where the tensor lies physically (DESIGN.md 8,
+// tools/microbench/placement_patterns.hip); engine.probe_output_placement times it into candidate allocations.
+// grid (tiles), 64 threads, dynamic LDS 8320 B.  Writes zeros.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void k_store_probe(float *__restrict__ out, int ntiles) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const int t = chunk_unit(ntiles);
+    nt4 z = {0.f, 0.f, 0.f, 0.f};
+    if (out == nullptr) z.x = (float)smem[threadIdx.x];  // keeps the LDS allocation (the occupancy) alive
+    nt4 *b = reinterpret_cast<nt4 *>(out) + (size_t)t * 12 * kWave + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) __builtin_nontemporal_store(z, b + q * kWave);
+}
+
 }  // namespace evrep

@@ -668,6 +668,15 @@ int evrep_resize_taps(const void *in, int32_t in_dtype, int32_t B, int32_t H, in
     return EVREP_OK;
 }
 
+int evrep_probe_store(void *out, size_t bytes, void *stream_) {
+    if (!out || (reinterpret_cast<uintptr_t>(out) & 15u)) return EVREP_EINVAL;
+    const size_t tiles = bytes / 12288;
+    if (tiles == 0 || tiles > 0x7fffffffu) return EVREP_EINVAL;
+    k_store_probe<<<(unsigned)tiles, kWave, 8320, static_cast<hipStream_t>(stream_)>>>(static_cast<float *>(out), (int)tiles);
+    LAUNCH_CHECK("k_store_probe");
+    return EVREP_OK;
+}
+
 size_t evrep_gw_scratch_bytes(int64_t n, int64_t m, int32_t precision) {
     if (n <= 0 || m <= 0) return 0;
     return precision == EVREP_F32 ? gw_carve<float>(nullptr, n, m).bytes : gw_carve<double>(nullptr, n, m).bytes;

@@ -357,15 +357,21 @@ class BinBuildPipeline:
         return self._flush()
 
 
-def probe_output_placement(shape, dtype, launch, candidates=8, launches=20, device="cuda:0"):
+def probe_output_placement(shape, dtype, launch=None, candidates=8, launches=10, device="cuda:0"):
     """Where a large output tensor lies in HBM decides up to 25 % of a builder launch on MI355X (the same
     launch takes 134, 148 or 172 us into different 900 MiB allocations of one process; a linear fill does not care).
-    A service that allocates its output ring once can pick its allocations: this helper allocates `candidates` tensors,
-    times `launch(out)` into each (`launches` launches after 3 warm-up ones) and returns (best tensor, its us per launch,
-    all timings); the other tensors are released.  NOT used by bench.py unless --probe-placement is given."""
+    A producer that allocates its output ring once can pick its allocations: this helper allocates `candidates` tensors,
+    times a writer into each and returns (best tensor, its us per launch, all timings); the other tensors are released.
+    The writer is `launch(out)` if given, else the library's placement probe (evrep_probe_store: the write footprint of
+    the float64 12-channel builder and nothing else -- it overwrites the candidates with zeros)."""
     _require_gpu()
     device = torch.device(device)
+    lib = _lib.load()
     outs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(int(candidates))]
+    if launch is None:
+        def launch(o):
+            with torch.cuda.device(device):
+                check(lib.evrep_probe_store(_ptr(o), o.numel() * o.element_size(), _stream_ptr()), "evrep_probe_store")
     times = []
     for o in outs:
         for _ in range(3):

@@ -198,6 +198,12 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream);
 int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox, void *stream);
 
+/* Placement probe (no reference counterpart): writes zeros over `bytes` of `out` with the write footprint of the float64
+ * 12-channel builder and nothing else.  On MI355X the physical placement of a ~1 GB output tensor decides up to 25 % of a
+ * builder launch; a producer that allocates its output ring once can time this call into a few
+ * candidate allocations and keep the fastest (engine.probe_output_placement does).  out DEVICE, 16-byte aligned. */
+int evrep_probe_store(void *out, size_t bytes, void *stream);
+
 /* OTMI(Xs, Xt, h).solve()[1] (representation_search/compute_otmi.py:61-93) in closed form for
  * POT's max_iter=0 path: mean over the LxL zero-padded grid of |Ks - Kt|.
  * Xs DEVICE double [n,ds], Xt DEVICE double [m,dt] (ds, dt <= 32); scratch DEVICE of

@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r02
 set -e
 R=${1:?round directory name, e.g. r02}; O=gpurun_out/final; P=profiles/$R; mkdir -p $P
-cp $O/bench.json $P/bench.json; cp $O/bench_f32.json $P/bench_f32.json; cp $O/bench_probe.json $O/placement_patterns.txt $P/
+cp $O/bench.json $P/bench.json; cp $O/bench_f32.json $P/bench_f32.json; cp $O/bench_noprobe.json $O/placement_patterns.txt $P/
 cp $O/kt/bench_kernel_stats.csv $P/bench_kernel_stats.csv; cp $O/kt/bench_kernel_trace.csv $P/bench_kernel_trace.csv
 grep "^{" $O/kt.log > $P/bench_under_rocprof.json
 cp $O/fetch/pmc_fetch_counter_collection.csv $O/write/pmc_write_counter_collection.csv $O/sq/pmc_sq_counter_collection.csv $P/
