@@ -207,3 +207,19 @@ def test_rebinning_is_idempotent_and_deterministic(monkeypatch):
     for _ in range(20):
         eb.rebin()
         assert torch.equal(eb.optimized(), first)
+
+
+def test_placement_probe_writes_zeros_and_returns_a_candidate():
+    """evrep_probe_store (the builder's write footprint, DESIGN.md 8) zero-fills whole 12 KiB tiles of the tensor;
+    probe_output_placement returns one of its candidates with one timing per candidate."""
+    from event_representation_study_amd import engine as eng
+    best, us, all_us = eng.probe_output_placement((4, 48, 64, 12), torch.float64, candidates=3, launches=2)
+    assert best.shape == (4, 48, 64, 12) and len(all_us) == 3 and us == min(all_us)
+    nbytes = best.numel() * 8
+    covered = (nbytes // 12288) * 12288 // 8
+    assert not best.reshape(-1)[:covered].any()
+    # a caller-supplied writer is timed instead when given
+    calls = []
+    best2, _, t2 = eng.probe_output_placement((2, 8, 8, 2), torch.float32, launch=lambda o: calls.append(o.data_ptr()) or o.fill_(1.0),
+                                              candidates=2, launches=1)
+    assert len(t2) == 2 and len(set(calls)) == 2 and bool((best2 == 1).all())
