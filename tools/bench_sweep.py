@@ -15,7 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from event_representation_study_amd.engine import EventBatch  # noqa: E402
+from event_representation_study_amd.engine import EventBatch, probe_output_placement  # noqa: E402
 from event_representation_study_amd.synthetic import make_events  # noqa: E402
 
 
@@ -53,14 +53,20 @@ def main():
                                       6, torch.float32),
         }
         for name, (fn, C, dt) in builders.items():
-            out = torch.empty((B, H, W, C), dtype=dt, device="cuda:0")
+            # float64 outputs of ~1 GB are placement-sensitive: like bench.py, take the fastest of a few
+            # candidate allocations; the narrower outputs are indifferent
+            if dt == torch.float64 and B * H * W * C * 8 >= (512 << 20):
+                out, _, cand = probe_output_placement((B, H, W, C), dt, candidates=12)
+            else:
+                out, cand = torch.empty((B, H, W, C), dtype=dt, device="cuda:0"), None
             ms = timed(lambda: fn(out), 20)
             elem = out.element_size()
             alg = B * (16 * N + elem * H * W * C)
             print(json.dumps({"config": tag, "W": W, "H": H, "events_per_window": N, "batch": B, "builder": name,
                               "bin_ms": round(t_bin, 4), "build_ms": round(ms, 4),
                               "algorithmic_bytes": alg, "build_GBps": round(alg / ms / 1e6, 1),
-                              "events_per_s_bin_plus_build": round(B * N / ((t_bin + ms) * 1e-3))}))
+                              "events_per_s_bin_plus_build": round(B * N / ((t_bin + ms) * 1e-3)),
+                              "placement_probe_us": [round(x, 1) for x in cand] if cand else None}))
             del out
         del eb
         torch.cuda.empty_cache()
