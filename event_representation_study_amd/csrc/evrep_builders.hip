@@ -46,8 +46,10 @@ constexpr int kEvStage = 64;                // records staged in LDS; denser chu
 // (two-chunk float32 units and TORE's shifted frame hold ~65 records on the sparse windows they are chosen for: the
 // key-sorted front end orders them inside LDS).
 struct UnitCfg {
-    int span;   // 128-pixel chunks per unit
-    int stage;  // records the wave's LDS stage holds (a multiple of 64)
+    int span;    // 128-pixel chunks per unit
+    int stage;   // records the wave's LDS stage holds (a multiple of 64)
+    int partpx;  // pixels of one part tile: 64 (kPartPx), or 128 for narrow pixels, whose 64-pixel tiles are too small to
+                 // pay for their own fill / store / phase sequence (n_imagenet accumulators 67 -> 62 us, EventStack 87 -> 81)
 };
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
@@ -62,9 +64,11 @@ struct WaveLds {
     Rec *evbuf;   // `nstage` records of the unit (the classic front end fills the first kEvStage)
     int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
     int nstage;
-    __device__ WaveLds(unsigned char *smem, int C, int segcap_, int nstage_) : segcap(segcap_), nstage(nstage_) {
+    int partpx;   // pixels of the part tile
+    __device__ WaveLds(unsigned char *smem, int C, int segcap_, int nstage_, int partpx_ = kPartPx)
+        : segcap(segcap_), nstage(nstage_), partpx(partpx_) {
         size_t o = 0;
-        tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)kPartPx * C * sizeof(OutT));
+        tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)partpx_ * C * sizeof(OutT));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
         evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)nstage_ * sizeof(Rec);
         segs = reinterpret_cast<uint2 *>(smem + o);
@@ -72,8 +76,8 @@ struct WaveLds {
 };
 
 // segcap = pixels one unit can touch: span * kChunkPx (+ kChunkPx for TORE's shifted frame)
-__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap, int nstage) {
-    return align16((size_t)kPartPx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
+__host__ __device__ inline size_t chunk_lds_bytes(int C, size_t elem, int segcap, int nstage, int partpx = kPartPx) {
+    return align16((size_t)partpx * C * elem) + align16((size_t)EVREP_MAX_CHANNELS * elem) +
            (size_t)nstage * sizeof(Rec) + align16((size_t)(segcap + 1) * sizeof(uint2));
 }
 
@@ -502,13 +506,14 @@ template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename Post
 __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHeads post_heads, int key0, int npix,
                                  int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
+    const int PP = w.partpx;  // pixels per part tile (wave-uniform)
     // a zero tile is filled at once (it overlaps the record load); a background that had to be
     // loaded is filled after the segment heads are listed, when it has arrived behind the records
-    if (!bg || nrec == 0) tile_fill(w.tile, min(kPartPx, npix), C, bg);
+    if (!bg || nrec == 0) tile_fill(w.tile, min(PP, npix), C, bg);
     if (nrec == 0) {  // empty chunk: the same background tile is streamed for every part
         wave_phase();
-        for (int part = 0; part * kPartPx < npix; ++part)
-            tile_store(w.tile, min(kPartPx, npix - part * kPartPx) * C, dst + (size_t)part * kPartPx * C);
+        for (int part = 0; part * PP < npix; ++part)
+            tile_store(w.tile, min(PP, npix - part * PP) * C, dst + (size_t)part * PP * C);
         return;
     }
     // segment heads = runs of equal pixel id among the sorted records
@@ -534,7 +539,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
         if (nseg > w.segcap) nseg = w.segcap;  // cannot happen: a unit never holds more distinct pixels
         if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
     }
-    if (bg) tile_fill(w.tile, min(kPartPx, npix), C, bg);
+    if (bg) tile_fill(w.tile, min(PP, npix), C, bg);
     wave_phase();
     post_heads();
 
@@ -547,37 +552,37 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
             px = (int)sg.x;
             if (px >= 0 && px < npix) reduce(sg.y, w.segs[lane + 1].y, get, vals); else px = -1;
         }
-        for (int part = 0; part * kPartPx < npix; ++part) {
-            const int np = min(kPartPx, npix - part * kPartPx);
+        for (int part = 0; part * PP < npix; ++part) {
+            const int np = min(PP, npix - part * PP);
             if (part) { wave_phase(); tile_fill(w.tile, np, C, bg); wave_phase(); }
-            const int q = px - part * kPartPx;
-            if (px >= 0 && q >= 0 && q < kPartPx) {
+            const int q = px - part * PP;
+            if (px >= 0 && q >= 0 && q < PP) {
                 OutT *mine = w.tile + (size_t)q * C;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
             }
             wave_phase();
-            tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
+            tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
         }
     } else {
         // dense chunk: one pass per part tile, each segment reduced in the pass of its own part.  The segment list is
-        // pixel-ordered, so a part owns the contiguous range [sb, se) of it -- at most kPartPx entries, one per lane,
+        // pixel-ordered, so a part owns the contiguous range [sb, se) of it -- at most PP entries, one per lane,
         // every lane of the range busy (r02: striding the whole list and skipping the other part's entries left half
         // of the lanes idle in each of twice as many reduce rounds)
         int sb = 0;
-        for (int part = 0; part * kPartPx < npix; ++part) {
-            const int np = min(kPartPx, npix - part * kPartPx);
+        for (int part = 0; part * PP < npix; ++part) {
+            const int np = min(PP, npix - part * PP);
             if (part) { wave_phase(); tile_fill(w.tile, np, C, bg); wave_phase(); }
             int se = sb;
             for (int k0 = sb; k0 < nseg; k0 += kWave) {
                 const int k = k0 + lane;
-                const int c = __popcll(__ballot(k < nseg && (int)w.segs[k].x < (part + 1) * kPartPx));
+                const int c = __popcll(__ballot(k < nseg && (int)w.segs[k].x < (part + 1) * PP));
                 se += c;
                 if (c < kWave) break;
             }
             for (int k = sb + lane; k < se; k += kWave) {
                 const uint2 sg = w.segs[k];
-                const int q = (int)sg.x - part * kPartPx;
+                const int q = (int)sg.x - part * PP;
                 if (q < 0 || q >= np) continue;
                 OutT vals[CMAX];
                 reduce(sg.y, w.segs[k + 1].y, get, vals);
@@ -587,7 +592,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
             }
             sb = se;
             wave_phase();
-            tile_store(w.tile, np * C, dst + (size_t)part * kPartPx * C);
+            tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
         }
     }
 }
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<float> w(smem, S, uc.span * kChunkPx, uc.stage);
+    WaveLds<float> w(smem, S, uc.span * kChunkPx, uc.stage, uc.partpx);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
@@ -1237,7 +1242,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
                                                    float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = P.C;
-    WaveLds<float> w(smem, C, uc.span * kChunkPx, uc.stage);
+    WaveLds<float> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
