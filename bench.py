@@ -332,9 +332,14 @@ def main():
                 from event_representation_study_amd.engine import probe_output_placement
                 # timed with the library's store probe (the builder's write footprint, no builder launch: the k_mdes
                 # statistics of a profiled run hold the real steps only)
-                o, best_us, all_us = probe_output_placement((B, H, W, C), dtype, candidates=args.probe_placement, device=device)
-                placement = {"candidates": args.probe_placement, "writer": "evrep_probe_store", "best_us": round(best_us, 1),
-                             "all_us": [round(x, 1) for x in all_us]}
+                try:
+                    o, best_us, all_us = probe_output_placement((B, H, W, C), dtype, candidates=args.probe_placement, device=device)
+                    placement = {"candidates": args.probe_placement, "writer": "evrep_probe_store", "best_us": round(best_us, 1),
+                                 "all_us": [round(x, 1) for x in all_us]}
+                except torch.OutOfMemoryError:   # a crowded device: take one allocation, say so
+                    torch.cuda.empty_cache()
+                    o = torch.empty((B, H, W, C), dtype=dtype, device=device)
+                    placement = {"candidates": 1, "note": "out of memory while probing %d candidates" % args.probe_placement}
                 outs.append(o)
             else:
                 outs.append(torch.empty((B, H, W, C), dtype=dtype, device=device))
