@@ -357,37 +357,48 @@ class BinBuildPipeline:
         return self._flush()
 
 
-def probe_output_placement(shape, dtype, launch=None, candidates=8, launches=10, device="cuda:0"):
+def probe_output_placement(shape, dtype, launch=None, candidates=8, launches=10, device="cuda:0", keep_first=False,
+                           good_GBps=None, max_candidates=None):
     """Where a large output tensor lies in HBM decides up to 25 % of a builder launch on MI355X (the same
     launch takes 134, 148 or 172 us into different 900 MiB allocations of one process; a linear fill does not care).
     A producer that allocates its output ring once can pick its allocations: this helper allocates `candidates` tensors,
     times a writer into each and returns (best tensor, its us per launch, all timings); the other tensors are released.
     The writer is `launch(out)` if given, else the library's placement probe (evrep_probe_store: the write footprint of
-    the float64 12-channel builder and nothing else -- it overwrites the candidates with zeros)."""
+    the float64 12-channel builder and nothing else -- it overwrites the candidates with zeros).
+    Fast regions come in runs and some processes find none among their first allocations: with good_GBps set, further
+    rounds of `candidates` allocations follow (all kept alive meanwhile, so every round sees new regions) until one
+    reaches that rate or max_candidates tensors have been tried.
+    keep_first: also return the FIRST candidate (what a caller that does not probe would have got), as a 4th element."""
     _require_gpu()
     device = torch.device(device)
     lib = _lib.load()
-    outs = [torch.empty(shape, dtype=dtype, device=device) for _ in range(int(candidates))]
     if launch is None:
         def launch(o):
             with torch.cuda.device(device):
                 check(lib.evrep_probe_store(_ptr(o), o.numel() * o.element_size(), _stream_ptr()), "evrep_probe_store")
-    times = []
-    for o in outs:
-        for _ in range(3):
-            launch(o)
-        torch.cuda.synchronize(device)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(int(launches)):
-            launch(o)
-        b.record()
-        torch.cuda.synchronize(device)
-        times.append(a.elapsed_time(b) / launches * 1e3)
+    outs, times = [], []
+    limit = int(max_candidates) if max_candidates else int(candidates)
+    while len(outs) < limit:
+        for _ in range(min(int(candidates), limit - len(outs))):
+            o = torch.empty(shape, dtype=dtype, device=device)
+            for _ in range(3):
+                launch(o)
+            torch.cuda.synchronize(device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(int(launches)):
+                launch(o)
+            b.record()
+            torch.cuda.synchronize(device)
+            outs.append(o)
+            times.append(a.elapsed_time(b) / launches * 1e3)
+        nbytes = outs[0].numel() * outs[0].element_size()
+        if good_GBps is None or nbytes / (min(times) * 1e-6) / 1e9 >= good_GBps:
+            break
     k = min(range(len(outs)), key=lambda i: times[i])
-    best = outs[k]
+    best, first = outs[k], outs[0]
     del outs
-    return best, times[k], times
+    return (best, times[k], times, first) if keep_first else (best, times[k], times)
 
 
 def gwd_padded_l1(Xs, Xt, h=0.7, out=None):
