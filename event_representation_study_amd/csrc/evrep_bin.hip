@@ -1,11 +1,11 @@
-// evrep_bin.hip -- the (y,x) binning pass: a stable two-level partition of every window's events
-// by pixel id, written for gfx950 (wave64, LDS counters, ballot multisplit).
-//
-// Level 1 (across workgroups): events of a window are cut into chunks; each workgroup histograms
-// its chunk by sensor row (k_row_hist), a per-window scan turns the (chunk,row) table into
-// destinations (k_row_scan), and each workgroup re-walks its chunk placing events stably
-// (k_row_scatter).  Level 2 (inside one workgroup per row): k_col_sort orders the row's events by
-// column, stably, so every pixel's events end up contiguous and in time order.
+// evrep_bin.hip -- the (y,x) binning pass: every window's events partitioned by pixel, stably (time order kept inside
+// a pixel), written for gfx950 (wave64, LDS counters, ballot multisplit).  Four passes, chosen by evrep_plan_init:
+//   * key-sorted (round 2, sparse windows): k_block_keysort orders each workgroup's events by (sensor row, 128-pixel
+//     chunk) in LDS; the builder waves gather their unit from the block runs and finish the order (evrep_builders.hip);
+//   * key pass for dense windows: k_block_keysort + k_col_sort_runs per (row, chunk) key -> the pixel-sorted stream;
+//   * two-kernel pass: k_block_rowsort (by sensor row) + k_col_sort_runs per row;
+//   * three-kernel pass (round 1): k_row_hist, k_row_scan / k_row_scatter(_fused), k_col_sort -- the first section
+//     of this file; very long windows and very tall sensors.
 //
 // This replaces the `index = y*W + x` scatter every reference builder starts with
 // (event_stack.py:123-125, operations.py:40, time_surface.py:67, tore.py:23-47): after it, each

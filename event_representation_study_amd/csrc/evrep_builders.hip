@@ -2,17 +2,20 @@
 // the binned stream (evrep_bin.hip), gfx950.
 //
 // Work unit = one wavefront (a 64-thread workgroup) owning a chunk of kChunkPx = 128 consecutive
-// pixels of one sensor row of one window.  The wave (emit_chunk)
-//   1. has the chunk's first 64 records in flight (one coalesced 16 B/lane load) before anything else,
+// pixels of one sensor row of one window (two chunks for narrow float32 outputs on sparse windows).  The wave
+//   1. gets the unit's records, grouped by pixel and time-ordered inside a pixel (unit_front): after the key-sorted
+//      binning pass it gathers them itself from the window's block runs and groups them in LDS (unit_records);
+//      after the classic passes they are one coalesced 16 B/lane load of the pixel-sorted stream; the builder's
+//      digest (a per-event division, exponential or logarithm) is applied one record per lane (emit_chunk),
 //   2. fills its private LDS part tile (kPartPx pixels x C, output layout) with the channel
 //      background (zero, or the builder's empty-pixel value),
 //   3. lists the non-empty pixels of the chunk (segment heads of the pixel-sorted records, ballot
 //      prefix) -- one lane per NON-EMPTY pixel, so VALU work scales with events, not pixels,
 //   4. reduces each segment IN TIME ORDER (float64 sums round exactly as the reference's
 //      sequential scatter does) into the lane's registers,
-//   5. emits the chunk as kParts part tiles through the ONE part-size LDS tile: lanes whose pixel
+//   5. emits the chunk as part tiles through the ONE part-size LDS tile: lanes whose pixel
 //      lies in a later part keep their values in registers while the earlier part is streamed
-//      out with 16-byte-per-lane coalesced stores.  Halving the tile takes the float64 12-channel
+//      out with 16-byte-per-lane coalesced non-temporal stores.  Halving the tile takes the float64 12-channel
 //      builder from 9 to 19 resident waves per CU while a wave still moves 12 KB, so almost twice the
 //      store bytes are in flight per CU (202 -> 168 us for the headline kernel).
 // No block barrier exists (one wave per workgroup; wave_phase() only orders LDS phases), every
