@@ -1,0 +1,45 @@
+"""Long fuzz campaign (not part of the test suite): python tools/fuzz_campaign.py <first seed> <seconds>
+Random geometry / density / batch / hot pixels; every builder under the key-sorted pass (forced), the classic passes
+(forced) and the pass evrep_plan_init chooses, bit for bit against each other; ERGO-12 and EventStack against the oracle."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from event_representation_study_amd import engine as eng
+from event_representation_study_amd.synthetic import make_events
+import oracle
+def builders(eb):
+    out = {"ergo12": eb.optimized(), "ergo12_f32": eb.optimized(dtype=torch.float32), "es": eb.event_stack(),
+           "ts": eb.time_surface(), "tore": eb.tore(6, frame_mode=2), "tore1": eb.tore(5, frame_mode=1), "vox": eb.voxel(5), "vox2": eb.voxel(9, mode=2),
+           "mdes": eb.mdes([0, 1, 2, 3, 4, 5, 6, 2], [0, 1, 2, 3, 4, 5, 6, 0], [0, 1, 2, 3, 0, 1, 2, 3])}
+    return {k: v.cpu().numpy() for k, v in out.items()}
+t0 = time.time(); n = 0; seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
+    seed = seed0 + n; n += 1
+    rng = np.random.default_rng(seed)
+    W = int(rng.choice([1, 7, 64, 127, 128, 129, 200, 256, 300, 640, 1000]))
+    H = int(rng.integers(1, 60))
+    B = int(rng.integers(1, 5))
+    dens = float(rng.choice([0.01, 0.05, 0.2, 0.25, 0.5, 2.0]))
+    wins = []
+    for b in range(B):
+        nn = max(2, int(dens * W * H * rng.uniform(0.3, 1.7)))
+        ev = make_events(nn, W, H, seed=seed * 7 + b, polarity="pm1" if rng.random() < 0.5 else "01", span_us=int(rng.choice([5, 2000, 50000])))
+        if rng.random() < 0.3:   # a hot pixel
+            k = rng.integers(0, nn, size=nn // 3); ev[k, 0] = int(rng.integers(0, W)); ev[k, 1] = int(rng.integers(0, H))
+        wins.append(ev)
+    os.environ.pop("EVREP_BIN_CLASSIC", None); os.environ["EVREP_BIN_KEY_SORTED"] = "1"
+    ks = eng.EventBatch.from_numpy(wins, H, W)
+    os.environ.pop("EVREP_BIN_KEY_SORTED", None); os.environ["EVREP_BIN_CLASSIC"] = "1"
+    cl = eng.EventBatch.from_numpy(wins, H, W)
+    os.environ.pop("EVREP_BIN_CLASSIC", None)
+    au = eng.EventBatch.from_numpy(wins, H, W)
+    a, c, d = builders(ks), builders(cl), builders(au)
+    for k in a:
+        assert np.array_equal(a[k], c[k], equal_nan=True), (seed, k, "key-sorted vs classic", W, H, [len(w) for w in wins])
+        assert np.array_equal(a[k], d[k], equal_nan=True), (seed, k, "key-sorted vs auto(%d)" % au.plan.reserved, W, H)
+    for b, ev in enumerate(wins):
+        if ev[-1, 2] != ev[0, 2]:
+            assert np.array_equal(a["ergo12"][b], oracle.ergo12(ev, H, W), equal_nan=True), (seed, "ergo12 vs oracle", W, H, len(ev))
+        assert np.array_equal(a["es"][b], oracle.event_stack(ev, H, W)), (seed, "event stack vs oracle")
+print("fuzz campaign: %d cases ok in %.0f s" % (n, time.time() - t0))
