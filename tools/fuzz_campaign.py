@@ -17,10 +17,15 @@ t0 = time.time(); n = 0; seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
     seed = seed0 + n; n += 1
     rng = np.random.default_rng(seed)
-    W = int(rng.choice([1, 7, 64, 127, 128, 129, 200, 256, 300, 640, 1000]))
-    H = int(rng.integers(1, 60))
-    B = int(rng.integers(1, 5))
-    dens = float(rng.choice([0.01, 0.05, 0.2, 0.25, 0.5, 2.0]))
+    if os.environ.get("FUZZ_BIG"):   # the reference's sensors: the 4096-event blocks, the two-round stage of 1280x720
+        W, H = [(640, 480), (1280, 720), (304, 240), (346, 260)][int(rng.integers(0, 4))]
+        B = int(rng.integers(1, 4))
+        dens = float(rng.choice([0.01, 0.05, 0.16, 0.25, 0.4]))
+    else:
+        W = int(rng.choice([1, 7, 64, 127, 128, 129, 200, 256, 300, 640, 1000]))
+        H = int(rng.integers(1, 60))
+        B = int(rng.integers(1, 5))
+        dens = float(rng.choice([0.01, 0.05, 0.2, 0.25, 0.5, 2.0]))
     wins = []
     for b in range(B):
         nn = max(2, int(dens * W * H * rng.uniform(0.3, 1.7)))
