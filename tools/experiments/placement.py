@@ -1,0 +1,27 @@
+"""Does the builder's launch time depend on WHICH allocation the output tensor is (same process, all alive at once)?"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from event_representation_study_amd.engine import EventBatch
+from event_representation_study_amd.synthetic import make_events
+H, W, N, B = 480, 640, 50000, 32
+eb = EventBatch.from_numpy([make_events(N, W, H, seed=i) for i in range(B)], H, W)
+def t(out, n=200):
+    for _ in range(20): eb.optimized(out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): eb.optimized(out=out)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+def tf(out, n=100):
+    for _ in range(10): out.zero_()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): out.zero_()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(8)]
+print(" ".join("%.1f" % t(o) for o in outs), "| fill:", " ".join("%.1f" % tf(o) for o in outs))
+print(" ".join("%.1f" % t(o) for o in outs))
