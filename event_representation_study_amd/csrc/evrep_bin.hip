@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sort
 //                     records of earlier rows = sum over blocks of table[b][blk][row].
 // =====================================================================================================
 #ifndef BS_DEBUG
-#define BS_DEBUG 0  // timing experiments only (tools/ab): 1 = no statistics, 2 = no placement, 4 = no write-out, 8 = no counting
+#define BS_DEBUG 0  // timing experiments only (tools/experiments): 1 = no statistics, 2 = no placement, 4 = no write-out, 8 = no counting
 #endif
 constexpr int kBsThreads = 1024;
 constexpr int kBsWaves = kBsThreads / kWave;     // 16
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
 // wrong).  Nothing depends on another workgroup.
 // =====================================================================================================
 #ifndef KS_DEBUG
-#define KS_DEBUG 0  // timing experiments only (tools/ab): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
+#define KS_DEBUG 0  // timing experiments only (tools/experiments): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
 #endif
 __host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int chunk) {
     return (size_t)cap * sizeof(Rec) + (size_t)chunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
