@@ -428,6 +428,8 @@ def main():
             sync()
             placement_note["first_allocation_ms_per_step"] = (time.perf_counter() - t1) / 200 * 1e3
             outs[0] = keep
+            # beside `value`: this rank's rate had the output tensor been the first allocation (no probe)
+            result["value_per_gpu_first_allocation"] = B * N / (placement_note["first_allocation_ms_per_step"] * 1e-3)
         result["config"]["output_placement_probe"] = placement_note   # --probe-placement 0 takes the first allocation instead
     if dry:
         result["dry_run"] = True      # launcher / rendezvous / collectives only: NOT a measurement
