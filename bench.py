@@ -62,6 +62,10 @@ def parse():
                          "(DESIGN.md 8: the physical placement of the 0.94 GB float64 tensor decides 134 / 148 / 172 us of the same "
                          "launch; a service allocates its output ring once and can pick).  0 = take the first allocation.  The "
                          "candidates' timings are printed in config.output_placement_probe.")
+    ap.add_argument("--first-allocation", action="store_true",
+                    help="after the timed region, also time 200 steps into the FIRST candidate allocation (what a run without the "
+                         "placement probe gets) -> value_per_gpu_first_allocation; off by default so that a profiled run's kernel "
+                         "statistics hold the measured steps only (all_us[0] of the probe already predicts it)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -417,7 +421,7 @@ def main():
     if placement_note:
         # the same step into the FIRST candidate allocation (what a run without the probe gets), 200 steps, beside the line's value
         first = locals().get("first_alloc")
-        if first is not None and not args.pipeline:
+        if first is not None and not args.pipeline and args.first_allocation:
             keep, outs[0] = outs[0], first
             for k in range(20):
                 step(0)

@@ -8,7 +8,7 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd $R
-python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --first-allocation > $O/bench.json 2> $O/bench.err
 python bench.py --out-dtype f32 --no-cpu-baseline --no-gwd --no-gw-extension --no-live-traffic > $O/bench_f32.json 2>> $O/bench.err
 python bench.py --probe-placement 0 --no-cpu-baseline --no-gwd --no-gw-extension --no-live-traffic > $O/bench_noprobe.json 2>> $O/bench.err
 (hipcc --offload-arch=gfx950 -O3 -o /tmp/placement_patterns $R/tools/microbench/placement_patterns.hip && /tmp/placement_patterns 12 && /tmp/placement_patterns 12 sizes && /tmp/placement_patterns 12 more) > $O/placement_patterns.txt 2>&1
