@@ -100,6 +100,7 @@ def test_window_sizes_around_two_kernel_binning_limits(oracle, sizes, monkeypatc
     (EVREP_BIN_CLASSIC keeps the key-sorted pass, tests/test_gpu_key_sorted.py, out of the choice.)"""
     from event_representation_study_amd import engine as eng
     monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     H, W = 36, 200
     wins = [make_events(n, W, H, seed=n % 1000 + 3) for n in sizes]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -119,6 +120,7 @@ def test_tall_sensors_around_the_lds_limit_of_the_row_sort(oracle, H, monkeypatc
     take the two-kernel pass, taller ones the three-kernel pass; same tensors either way."""
     from event_representation_study_amd import engine as eng
     monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     W = 70
     wins = [make_events(30000, W, H, seed=H), make_events(100, W, H, seed=H + 1)]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -135,6 +137,7 @@ def test_three_kernel_binning_pass_still_agrees(oracle, monkeypatch):
     H, W = 120, 160
     wins = [make_events(20000, W, H, seed=5), make_events(9000, W, H, seed=6, polarity="01")]
     monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     a = eng.EventBatch.from_numpy(wins, H, W)
     monkeypatch.setenv("EVREP_BIN_THREE_KERNEL", "1")
     b = eng.EventBatch.from_numpy(wins, H, W)

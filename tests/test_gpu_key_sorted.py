@@ -22,6 +22,7 @@ def assert_bit_equal(a, b, msg):
 def _batches(eng, wins, H, W, monkeypatch, force=True):
     """the same windows under the key-sorted pass and under the classic pass"""
     monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)   # the suite may run under a globally forced pass
     if force:
         monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
     ks = eng.EventBatch.from_numpy(wins, H, W)
@@ -91,6 +92,7 @@ def test_the_pass_is_chosen_for_the_headline_windows_and_matches_the_oracle(orac
     from event_representation_study_amd import engine as eng
     monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
     monkeypatch.delenv("EVREP_BIN_KEY_SORTED", raising=False)
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     H, W = 480, 640
     wins = [make_events(50000, W, H, seed=900 + i, polarity="pm1" if i else "01") for i in range(3)]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -109,6 +111,7 @@ def test_gen4_sensor_two_round_stage(oracle, monkeypatch):
     """1280x720 (BASELINE config 3): 7200 keys leave room for a 4096-record stage, the block is written in two rounds."""
     from event_representation_study_amd import engine as eng
     monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     H, W = 720, 1280
     wins = [make_events(200000, W, H, seed=31), make_events(8000, W, H, seed=32, polarity="01")]
     eb = eng.EventBatch.from_numpy(wins, H, W)
@@ -201,6 +204,7 @@ def test_rebinning_is_idempotent_and_deterministic(monkeypatch):
     H, W = 480, 640
     wins = [make_events(50000, W, H, seed=40 + i) for i in range(4)]
     monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     eb = eng.EventBatch.from_numpy(wins, H, W)
     assert eb.plan.reserved == 2
     first = eb.optimized().clone()
