@@ -57,11 +57,13 @@ def parse():
                          "replayed from profiles/traffic.json and labelled so")
     ap.add_argument("--no-gw-extension", action="store_true",
                     help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
-    ap.add_argument("--probe-placement", type=int, default=16, metavar="N",
-                    help="before the warm-up, allocate N candidate output tensors and keep the one the builder runs fastest into "
-                         "(DESIGN.md 8: the physical placement of the 0.94 GB float64 tensor decides 134 / 148 / 172 us of the same "
-                         "launch; a service allocates its output ring once and can pick).  0 = take the first allocation.  The "
-                         "candidates' timings are printed in config.output_placement_probe.")
+    ap.add_argument("--probe-placement", type=int, default=0, metavar="N",
+                    help="0 (default, r03): the output tensor is the FIRST allocation, as any caller gets it -- the builder paces its "
+                         "stores (DESIGN.md 3.2), so its launch no longer depends on where the tensor lies.  N > 1 (r02's default was "
+                         "16): before the warm-up, allocate N candidate output tensors and keep the one the store probe runs fastest "
+                         "into; the candidates' timings are printed in config.output_placement_probe.")
+    ap.add_argument("--pacing", type=int, default=None, metavar="TICKS",
+                    help="store pacing of the builder: default automatic; 0 = off (r02's behaviour); > 0 = hold in 10 ns ticks")
     ap.add_argument("--first-allocation", action="store_true",
                     help="after the timed region, also time 200 steps into the FIRST candidate allocation (what a run without the "
                          "placement probe gets) -> value_per_gpu_first_allocation; off by default so that a profiled run's kernel "
@@ -332,6 +334,10 @@ def main():
         for j in range(nbuf):
             wins = [make_events(N, W, H, seed=rank * 100000 + j * B + i) for i in range(B)]  # seed = window index
             batches.append(EventBatch.from_numpy(wins, H, W, device=device))
+            if args.pacing is not None:
+                import ctypes
+                from event_representation_study_amd._lib import check
+                check(batches[-1].lib.evrep_plan_set_pacing(ctypes.byref(batches[-1].plan), args.pacing), "evrep_plan_set_pacing")
             if args.probe_placement > 1:
                 from event_representation_study_amd.engine import probe_output_placement
                 # timed with the library's store probe (the builder's write footprint, no builder launch: the k_mdes
@@ -392,7 +398,11 @@ def main():
         torch.distributed.barrier()
     el = time.perf_counter() - t0
     t = torch.tensor([el], dtype=torch.float64, device=device)
+    per_rank_ms = [el / max(args.steps, 1) * 1e3]
     if world > 1:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / max(args.steps, 1) * 1e3 for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     el = max(float(t.item()), 1e-9)
 
@@ -418,8 +428,12 @@ def main():
                    "pipeline": pipe is not None,
                    "events_per_window": N, "batch": B, "height": H, "width": W, "channels": C,
                    "parallelism": "windows sharded over %d GPU(s), one process per GPU, no data-path collective" % world},
+        "ms_per_step_per_rank": per_rank_ms,
         "windows_per_s": world * B * args.steps / el,
         "algorithmic_GBps_whole_step": world * alg_bytes * args.steps / el / 1e9,
+        # third-party boundaries of the reference that are restated, never run (packages absent from the image and from
+        # /root/reference): what the parity claims of this line do NOT pin
+        "parity_unpinned": ["torch_scatter.scatter", "POT", "tonic", "cv2"],
     }
     if placement_note:
         # the same step into the FIRST candidate allocation (what a run without the probe gets), 200 steps, beside the line's value
@@ -473,10 +487,13 @@ def main():
             result["roofline"]["traffic_source"] = ("collected in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
                                                     "(two separate passes of tools/pmc_workload.py), calibrated on a 1 GiB fill "
                                                     "and a 1 GiB copy of the same process as MI355X_MICROARCH.md prescribes")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+    if rank == 0 and not args.no_cpu_baseline and not dry:
+        # rank 0's host cores, after the timed region and every GPU leg (the other ranks wait at the barrier below)
         result["cpu_baseline"] = cpu_baseline(N)
     elif rank == 0:
         result["cpu_baseline"] = None
+    if world > 1:
+        torch.distributed.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -14,7 +14,7 @@ ST_EMPTY, ST_OOB, ST_UNSORTED, ST_FLAT_TIME = 1, 2, 4, 8
 F64, F32 = 0, 1
 MAX_CHANNELS = 16
 MAX_DIM = 4096
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FUNCS = ["timestamp", "polarity", "count", "timestamp_pos", "timestamp_neg", "count_pos", "count_neg"]
 AGGS = ["sum", "mean", "max", "variance"]
@@ -28,6 +28,7 @@ class Plan(ctypes.Structure):
         ("max_events_per_window", ctypes.c_int64),
         ("chunk", ctypes.c_int32), ("nblk", ctypes.c_int32),
         ("nchunk", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("pacing", ctypes.c_int32),
         ("off_meta", ctypes.c_size_t), ("off_table", ctypes.c_size_t), ("off_stats", ctypes.c_size_t),
         ("off_rowoff", ctypes.c_size_t),
         ("off_chunkoff", ctypes.c_size_t),
@@ -45,6 +46,8 @@ SYMBOLS = {
     "evrep_abi_version": (ctypes.c_int, []),
     "evrep_last_hip_error": (ctypes.c_char_p, []),
     "evrep_plan_init": (ctypes.c_int, [_PP, _i32, _i32, _i32, _i64, _i64]),
+    "evrep_plan_init_ex": (ctypes.c_int, [_PP, _i32, _i32, _i32, _i64, _i64, ctypes.c_uint32]),
+    "evrep_plan_set_pacing": (ctypes.c_int, [_PP, _i32]),
     "evrep_workspace_bytes": (ctypes.c_size_t, [_PP]),
     "evrep_bin_events": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp]),
     "evrep_probe_store": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),
@@ -67,6 +70,28 @@ SYMBOLS = {
     "evrep_entropic_gw": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "evrep_gwd_padded_l1": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
 }
+
+# evrep_plan_init_ex flags.  The C library reads no environment variable; the A/B switches of the tests and tools
+# are translated here, when a plan is made.
+PLAN_NO_KEY_PASS, PLAN_THREE_KERNEL, PLAN_FORCE_KEY_SORTED, PLAN_BIG_BLOCKS, PLAN_NO_FUSED_SCATTER = 1, 2, 4, 8, 16
+_ENV_FLAGS = (("EVREP_BIN_CLASSIC", PLAN_NO_KEY_PASS), ("EVREP_BIN_THREE_KERNEL", PLAN_THREE_KERNEL),
+              ("EVREP_BIN_KEY_SORTED", PLAN_FORCE_KEY_SORTED), ("EVREP_KS_BIG_BLOCKS", PLAN_BIG_BLOCKS),
+              ("EVREP_NO_FUSED_SCATTER", PLAN_NO_FUSED_SCATTER), ("EVREP_X_SPAN2", 64))
+
+
+def plan_flags_from_env():
+    flags = 0
+    for name, bit in _ENV_FLAGS:
+        if os.environ.get(name):
+            flags |= bit
+    return flags
+
+
+def pacing_from_env():
+    """EVREP_PACING: -1 automatic (default), 0 off, > 0 hold in 10 ns ticks (A/B timing only)."""
+    v = os.environ.get("EVREP_PACING")
+    return int(v) if v not in (None, "") else None
+
 
 _lib = None
 

@@ -42,6 +42,9 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #define EVREP_NT_STORES 1  // non-temporal output stores (the tensor is written once and never re-read by the step): -3 us on
                            // the ERGO-12 launch and -3 us on the next binning pass, whose loads find less of L2 evicted (r02)
 #endif
+#ifndef EVREP_SPARSE_EMIT
+#define EVREP_SPARSE_EMIT 1  // units of <= 64 records leave the wave through sparse_store (one burst) instead of the part tiles
+#endif
 constexpr int kParts = EVREP_PARTS;
 constexpr int kPartPx = kChunkPx / kParts;  // pixels per part tile
 constexpr int kEvStage = 64;                // records staged in LDS; denser chunks read the rest from HBM/L2
@@ -53,6 +56,7 @@ struct UnitCfg {
     int stage;   // records the wave's LDS stage holds (a multiple of 64)
     int partpx;  // pixels of one part tile: 64 (kPartPx), or 128 for narrow pixels, whose 64-pixel tiles are too small to
                  // pay for their own fill / store / phase sequence (n_imagenet accumulators 67 -> 62 us, EventStack 87 -> 81)
+    int hold;    // store pacing: the wave starts its stores no earlier than `hold` x 10 ns after it started (0 = off)
 };
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
@@ -68,8 +72,41 @@ struct WaveLds {
     int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
     int nstage;
     int partpx;   // pixels of the part tile
+    // Store pacing (r03).  The resident waves of a store-bound builder OFFER more write traffic than HBM serves (19 waves
+    // per CU x 12 KiB each, ready ~3.4 us after they start: 13 TB/s).  On most physical placements of a ~1 GB output
+    // tensor that oversubscription collapses the write rate to 5.6-5.9 TB/s (tools/microbench/placement_patterns{3,4}.hip:
+    // 168 us for the 944 MB of the headline tensor, against 135 us on the "fast" placements).  A wave that holds its first
+    // store until `hold` x 10 ns after its start keeps the offered load at the service rate -- few waves are in their
+    // store phase at any time -- and the same write takes 137-140 us wherever the tensor lies.  The clock is
+    // s_memrealtime (100 MHz, constant).  Results never depend on it.
+    long long t0;
+    int hold;
+#ifdef EVREP_TIMING  // experiment builds only (tools/experiments/phase_times.py): per-phase wave times, summed into dbg[]
+    unsigned long long *dbg;
+    __device__ inline void mark(int idx) const {   // dbg = this wave's own 8 slots: no contention
+        if (threadIdx.x == 0 && dbg) dbg[idx] = (unsigned long long)((long long)wall_clock64() - t0);
+    }
+#elif defined(EVREP_STOP_AFTER)  // experiment builds only: the wave ends at mark EVREP_STOP_AFTER (instruction counts per phase)
+    __device__ inline void mark(int idx) const { if (idx == EVREP_STOP_AFTER) __builtin_amdgcn_endpgm(); }
+#else
+    __device__ inline void mark(int) const {}
+#endif
+    __device__ inline void arm(int hold_) {
+        hold = hold_;
+#ifdef EVREP_TIMING
+        t0 = (long long)wall_clock64();
+#else
+        t0 = hold_ > 0 ? (long long)wall_clock64() : 0ll;
+#endif
+    }
+    __device__ inline void pace() const {
+        if (hold > 0) while ((long long)wall_clock64() - t0 < (long long)hold) __builtin_amdgcn_s_sleep(4);
+    }
     __device__ WaveLds(unsigned char *smem, int C, int segcap_, int nstage_, int partpx_ = kPartPx)
-        : segcap(segcap_), nstage(nstage_), partpx(partpx_) {
+        : segcap(segcap_), nstage(nstage_), partpx(partpx_), t0(0), hold(0) {
+#ifdef EVREP_TIMING
+        dbg = nullptr;
+#endif
         size_t o = 0;
         tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)partpx_ * C * sizeof(OutT));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
@@ -184,6 +221,9 @@ struct BinView {
     const WindowMeta *meta;     // classic: [B]
     Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
     int nblk, fused, chunk_shift;  // events per block run = 1 << chunk_shift (a runtime 64-bit division costs ~130 scalar instructions)
+#ifdef EVREP_TIMING
+    unsigned long long *dbg;
+#endif
 };
 
 // The records of one unit, pixel-sorted: r0 = record `lane`; records [0, nstaged) are in the wave's evbuf, later
@@ -256,14 +296,17 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     if (khi <= klo) return u;
     // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
     // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
-    uint32_t a = 0, len = 0;
+    // (the scalar loads of the extent are issued FIRST: placed behind the table loads the compiler issued them only after
+    // waiting for the tables -- a third dependent latency, ~1 us under the builder's own store load)
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    uint32_t a = 0, khi_v = 0;
     if (lane < bv.nblk) {
         const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
         a = tb[klo];
-        len = tb[khi] - a;
+        khi_v = tb[khi];
     }
-    const int64_t beg = off[b];
-    const int64_t n_win = off[b + 1] - beg;
+    uint32_t len = khi_v - a;
     // (a window longer than the plan's max_events_per_window is the caller's error: its tail was not binned; stay in bounds)
     const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
     if (nb <= 0) return u;
@@ -476,27 +519,104 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
 
 // The window statistics a builder needs: the classic passes publish WindowMeta; after the key-sorted pass the wave
 // merges the window's block statistics itself (one lane per block, DPP reductions of the fields actually used).
-__device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__restrict__ off, int b) {
-    if (!bv.fused) return bv.meta[b];
+// The loads are issued by meta_prefetch() -- at the top of the kernel, together with the unit's table loads, so that
+// their latency is not a dependent step of its own -- and consumed by meta_finish().
+struct MetaRaw {
+    int4 q0, q1, q2;
+};
+__device__ inline MetaRaw meta_prefetch(const BinView &bv, int b) {
+    MetaRaw r;
+    r.q0 = make_int4(0, 0, 0, 0); r.q1 = r.q0; r.q2 = r.q0;
+    if (bv.fused) {
+        if ((int)threadIdx.x < bv.nblk) {   // blocks beyond the window's own are masked by meta_finish
+            const int4 *sp = reinterpret_cast<const int4 *>(bv.stats + (size_t)b * bv.nblk + threadIdx.x);
+            r.q0 = sp[0]; r.q1 = sp[1]; r.q2 = sp[2];
+        }
+    } else if (threadIdx.x == 0) {
+        const int4 *mp = reinterpret_cast<const int4 *>(bv.meta + b);
+        r.q0 = mp[0]; r.q1 = mp[1]; r.q2 = mp[2];
+    }
+    return r;
+}
+__device__ inline WindowMeta meta_finish(const BinView &bv, const int64_t *__restrict__ off, int b, const MetaRaw &r) {
+    WindowMeta m;
+    if (!bv.fused) {   // WindowMeta's first 40 bytes, read by lane 0
+        m.tmin = __builtin_amdgcn_readfirstlane(r.q0.x); m.tmax = __builtin_amdgcn_readfirstlane(r.q0.y);
+        m.xmin = __builtin_amdgcn_readfirstlane(r.q0.z); m.xmax = __builtin_amdgcn_readfirstlane(r.q0.w);
+        m.ymin = __builtin_amdgcn_readfirstlane(r.q1.x); m.ymax = __builtin_amdgcn_readfirstlane(r.q1.y);
+        m.neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane(r.q1.z);
+        m.oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane(r.q1.w);
+        m.status = (uint32_t)__builtin_amdgcn_readfirstlane(r.q2.x); m.n_valid = __builtin_amdgcn_readfirstlane(r.q2.y);
+        return m;
+    }
     const int lane = threadIdx.x;
     const int64_t n_win = off[b + 1] - off[b];
     const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
     BlockStats st;
     stats_identity(st);
     if (lane < nb) {
-        const int4 *sp = reinterpret_cast<const int4 *>(bv.stats + (size_t)b * bv.nblk + lane);
-        const int4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
-        st.tmin = q0.x; st.tmax = q0.y; st.xmin = q0.z; st.xmax = q0.w;
-        st.ymin = q1.x; st.ymax = q1.y; st.neg_flags = (uint32_t)q1.z; st.oob_flags = (uint32_t)q1.w;
-        st.status = (uint32_t)q2.x; st.n_valid = q2.y;
+        st.tmin = r.q0.x; st.tmax = r.q0.y; st.xmin = r.q0.z; st.xmax = r.q0.w;
+        st.ymin = r.q1.x; st.ymax = r.q1.y; st.neg_flags = (uint32_t)r.q1.z; st.oob_flags = (uint32_t)r.q1.w;
+        st.status = (uint32_t)r.q2.x; st.n_valid = r.q2.y;
     }
-    WindowMeta m;
     m.tmin = wave_min(st.tmin); m.tmax = wave_max(st.tmax);
     m.xmin = wave_min(st.xmin); m.xmax = wave_max(st.xmax);
     m.ymin = wave_min(st.ymin); m.ymax = wave_max(st.ymax);
     m.neg_flags = wave_or(st.neg_flags); m.oob_flags = wave_or(st.oob_flags);
     m.status = wave_or(st.status); m.n_valid = wave_sum(st.n_valid);
     return m;
+}
+__device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__restrict__ off, int b) {
+    return meta_finish(bv, off, b, meta_prefetch(bv, b));
+}
+
+// The sparse emit (r03): the unit's <= 64 non-empty pixels sit in a value list in LDS (entry `slot` = the C values of
+// one pixel, in the lanes' order; it lives where the part tile would) and map[pixel] names the slot of a pixel.  Empty
+// pixels name entry PP, which is the wave's background vector (w.bg lies right behind the tile).  Every 16-byte vector
+// of the unit's output is gathered and stored, four wave-instructions at a time: the unit leaves the wave as ONE burst
+// of coalesced 1 KiB stores, with no zero fill of a tile and no part sequence in between -- a compact store phase is
+// what store pacing needs (WaveLds::pace), and what lets a float64 unit span two chunks.
+// Requires whole 16-byte vectors per pixel (C * sizeof(OutT) % 16 == 0) and a 16-byte aligned destination.
+// Vector v = 64 q + lane belongs to pixel v / vpp, piece v % vpp: both advance by constants per q.
+template <typename OutT>
+__device__ inline void sparse_store(const OutT *vlist, const unsigned char *map, int npix, int C, OutT *__restrict__ dst) {
+    constexpr int V = 16 / (int)sizeof(OutT);
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const int vpp = C / V;                              // vectors per pixel (<= 8)
+    const uint32_t inv = (65536u + (uint32_t)vpp - 1u) / (uint32_t)vpp;  // x / vpp == (x * inv) >> 16 for x < 4096
+    const int nvec = npix * vpp;
+    const int dq = (int)((64u * inv) >> 16), dr = 64 - dq * vpp;   // 64 = dq * vpp + dr
+    const nt4 *vl4 = reinterpret_cast<const nt4 *>(vlist);
+    nt4 *o4 = reinterpret_cast<nt4 *>(dst) + lane;
+    int pixel = (int)(((uint32_t)lane * inv) >> 16);
+    int sub = lane - pixel * vpp;
+    auto gather = [&]() -> nt4 {
+        const nt4 r = vl4[(int)map[pixel] * vpp + sub];
+        sub += dr; pixel += dq;
+        if (sub >= vpp) { sub -= vpp; ++pixel; }
+        return r;
+    };
+    int v0 = 0;
+    for (; v0 + 4 * kWave <= nvec; v0 += 4 * kWave) {   // whole groups: no lane test
+        const nt4 a = gather(), b = gather(), c = gather(), d = gather();
+#if EVREP_NT_STORES
+        __builtin_nontemporal_store(a, o4 + v0); __builtin_nontemporal_store(b, o4 + v0 + kWave);
+        __builtin_nontemporal_store(c, o4 + v0 + 2 * kWave); __builtin_nontemporal_store(d, o4 + v0 + 3 * kWave);
+#else
+        o4[v0] = a; o4[v0 + kWave] = b; o4[v0 + 2 * kWave] = c; o4[v0 + 3 * kWave] = d;
+#endif
+    }
+    for (; v0 < nvec; v0 += kWave) {
+        if (v0 + lane < nvec) {
+            const nt4 a = gather();
+#if EVREP_NT_STORES
+            __builtin_nontemporal_store(a, o4 + v0);
+#else
+            o4[v0] = a;
+#endif
+        }
+    }
 }
 
 // The shared back end of every builder.  `reduce(jb, je, get, vals)` turns one pixel's records
@@ -505,16 +625,36 @@ __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__res
 // caller before its own independent loads.  Pixel offsets outside [0, npix) (TORE's straddle)
 // are ignored.
 // `post_heads()` runs once the segment heads are listed (the stage may then be rewritten).
-template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename PostHeads, typename Reduce>
-__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHeads post_heads, int key0, int npix,
-                                 int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+// `get_staged(j)` = get(j) for a unit whose records are all staged in LDS (every unit of <= 64 records): no second source,
+// so the segment walks read LDS with ds_read instead of flat loads through a two-address-space pointer.
+template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename RecStaged, typename PostHeads, typename Reduce>
+__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, RecStaged get_staged, PostHeads post_heads, int key0,
+                                 int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const int PP = w.partpx;  // pixels per part tile (wave-uniform)
+    constexpr int V = 16 / (int)sizeof(OutT);
+    // units of <= 64 records (<= 64 non-empty pixels) leave through the sparse emit when a pixel is a whole number of
+    // 16-byte vectors; the others through the part tiles
+    const bool sparse = EVREP_SPARSE_EMIT && (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 &&
+                        (bg == nullptr || bg == w.bg) &&
+                        nrec <= (uint32_t)min(kWave, PP);   // the value list lives in the part tile: PP entries
     // a zero tile is filled at once (it overlaps the record load); a background that had to be
     // loaded is filled after the segment heads are listed, when it has arrived behind the records
-    if (!bg || nrec == 0) tile_fill(w.tile, min(PP, npix), C, bg);
-    if (nrec == 0) {  // empty chunk: the same background tile is streamed for every part
+    if (!sparse && (!bg || nrec == 0)) tile_fill(w.tile, min(PP, npix), C, bg);
+    const uint32_t empty4 = (uint32_t)PP * 0x01010101u;   // four map bytes naming the background entry
+    if (sparse && !bg && lane * V < EVREP_MAX_CHANNELS)   // a zero background: entry PP = w.bg has to hold it
+        reinterpret_cast<float4 *>(w.bg)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nrec == 0) {  // empty chunk: the background is streamed for every pixel
+        if (sparse) {
+            unsigned char *map = reinterpret_cast<unsigned char *>(w.segs);
+            for (int i = lane; i * 4 < npix; i += kWave) reinterpret_cast<uint32_t *>(map)[i] = empty4;
+            wave_phase();
+            w.pace();
+            sparse_store(w.tile, map, npix, C, dst);
+            return;
+        }
         wave_phase();
+        w.pace();
         for (int part = 0; part * PP < npix; ++part)
             tile_store(w.tile, min(PP, npix - part * PP) * C, dst + (size_t)part * PP * C);
         return;
@@ -542,11 +682,40 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
         if (nseg > w.segcap) nseg = w.segcap;  // cannot happen: a unit never holds more distinct pixels
         if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
     }
-    if (bg) tile_fill(w.tile, min(PP, npix), C, bg);
+    if (bg && !sparse) tile_fill(w.tile, min(PP, npix), C, bg);
     wave_phase();
     post_heads();
+    w.mark(2);
 
-    if (nseg <= kWave) {
+    if (sparse) {
+        // one lane per non-empty pixel, reduced once; the values go to the lane's entry of the value list (it lives
+        // where the part tile would), the pixel's map byte names the lane (the map takes the place of the segment
+        // list, which is spent once every lane holds its segment)
+        OutT vals[CMAX];
+        int px = -1;
+        if (lane < nseg) {
+            const uint2 sg = w.segs[lane];
+            px = (int)sg.x;
+            if (px >= 0 && px < npix) reduce(sg.y, w.segs[lane + 1].y, get_staged, vals); else px = -1;
+        }
+        w.mark(7);
+        wave_phase();
+        unsigned char *map = reinterpret_cast<unsigned char *>(w.segs);
+        for (int i = lane; i * 4 < npix; i += kWave) reinterpret_cast<uint32_t *>(map)[i] = empty4;
+        wave_phase();
+        if (px >= 0) {
+            map[px] = (unsigned char)lane;
+            OutT *mine = w.tile + (size_t)lane * C;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
+        }
+        wave_phase();
+        w.mark(3);
+        w.pace();
+        w.mark(4);
+        sparse_store(w.tile, map, npix, C, dst);
+        w.mark(5);
+    } else if (nseg <= kWave) {
         // one lane per non-empty pixel, reduced once; pixels of later parts wait in registers
         OutT vals[CMAX];
         int px = -1;
@@ -565,6 +734,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
                 for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];
             }
             wave_phase();
+            if (part == 0) w.pace();
             tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
         }
     } else {
@@ -595,6 +765,7 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, PostHea
             }
             sb = se;
             wave_phase();
+            if (part == 0) w.pace();
             tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
         }
     }
@@ -624,13 +795,14 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nraw ? evbuf[j].x : sorted[cs + j].x); };
     auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest_fly(sorted[cs + j]); };
+    auto get_staged = [&](uint32_t j) -> Rec { return evbuf[j]; };
     auto post_heads = [&]() {
         if (nraw > (uint32_t)kWave) {  // uniform: the second staged batch is still raw (key_at read its pixel ids)
             if (lane + kWave < (int)nraw) evbuf[lane + kWave] = digest(evbuf[lane + kWave]);
             wave_phase();
         }
     };
-    emit_core<OutT, CMAX>(nrec, key_at, get, post_heads, key0, npix, C, dst, w, bg, reduce);
+    emit_core<OutT, CMAX>(nrec, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
 }
 template <typename OutT, int CMAX, typename Digest, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
@@ -696,18 +868,29 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = D::C(P);
-    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
+    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+    w.arm(uc.hold);
+#ifdef EVREP_TIMING
+    w.dbg = bv.dbg + 8 * (size_t)chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+#endif
     ChunkGeom g;
-    // every independent global load first: the chunk's records, the window's statistics and extent
+    // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
+    // unit's records
+    int chunk0;
+    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
+    const int64_t n_win = off[b0 + 1] - off[b0];
+    const MetaRaw mraw = meta_prefetch(bv, b0);
+    w.mark(6);
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
+    w.mark(0);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    const int64_t n_win = off[g.b + 1] - off[g.b];
-    const WindowMeta m = window_meta(bv, off, g.b);
+    const WindowMeta m = meta_finish(bv, off, g.b, mraw);
 
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
     const MdesWindows mw = mdes_windows(n_win);
+    w.mark(1);
 
     // per-channel uniform setup
     int lo[D::kMaxC], hi[D::kMaxC], want[D::kMaxC];
@@ -779,6 +962,7 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
                 }
             }
         }
+        double rr[D::kMaxC];
 #pragma unroll
         for (int c = 0; c < D::kMaxC; ++c) {
             double r = 0.0;
@@ -790,16 +974,30 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
                     // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
                     r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
                 } else if (a == EVREP_A_SUM) r = s[c];
-                else if (a == EVREP_A_MEAN) r = cnt[c] > 1 ? s[c] / d : s[c];
-                else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+                else if (a == EVREP_A_MEAN) {
+                    // x / 1.0 == x; a float64 division is ~13 double-rate instructions for the WHOLE wave, so it is only
+                    // entered when some pixel of the wave really holds more than one event of the channel
+                    r = s[c];
+                    if (__any(cnt[c] > 1)) r = cnt[c] > 1 ? s[c] / d : s[c];
+                } else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
                 else {
-                    const double mean = cnt[c] > 1 ? s[c] / d : s[c], mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
+                    double mean = s[c], mean2 = s2[c];
+                    if (__any(cnt[c] > 1)) {
+                        mean = cnt[c] > 1 ? s[c] / d : s[c];
+                        mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
+                    }
                     const double mm = mean * mean;
                     r = mean2 - mm;
                 }
             }
-            vals[c] = (OutT)(r * scale);
+            rr[c] = r;
         }
+        if (scale != 1.0) {   // x * 1.0 == x: the unscaled call (wave-uniform) skips its float64 multiplies
+#pragma unroll
+            for (int c = 0; c < D::kMaxC; ++c) rr[c] = rr[c] * scale;
+        }
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) vals[c] = (OutT)rr[c];
     };
     emit_chunk<OutT, D::kMaxC>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
@@ -813,6 +1011,7 @@ __global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<float> w(smem, S, uc.span * kChunkPx, uc.stage, uc.partpx);
+    w.arm(uc.hold);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
@@ -962,6 +1161,7 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = 2 * S;
     WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
+    w.arm(uc.hold);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
@@ -1057,6 +1257,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
     const int C = 2 * K;
     const int span = uc.span;
     WaveLds<float> w(smem, C, (span + 1) * kChunkPx, uc.stage);
+    w.arm(uc.hold);
     const int nunit = (nchunk + span - 1) / span;
     const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
     const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
@@ -1161,6 +1362,7 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
                                                 const int64_t *__restrict__ t_range, double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<double> w(smem, bins, uc.span * kChunkPx, uc.stage);
+    w.arm(uc.hold);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
@@ -1246,6 +1448,7 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = P.C;
     WaveLds<float> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+    w.arm(uc.hold);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
@@ -1335,6 +1538,7 @@ __global__ __launch_bounds__(kWave) void k_est(BinView bv,
     extern __shared__ __align__(16) unsigned char smem[];
     const int C2 = 2 * P.C;
     WaveLds<float> w(smem, C2, uc.span * kChunkPx, uc.stage);
+    w.arm(uc.hold);
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;

@@ -1,5 +1,6 @@
 // evrep_capi.hip -- the extern "C" surface declared in include/evrep.h: argument checks, workspace
-// carving and kernel launches.  No allocation, no global state besides the last HIP error string.
+// carving and kernel launches.  No allocation, no global state besides the thread-local last HIP error string, no
+// environment variable read.
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,12 +33,13 @@ static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 template <int NSS, int NST>
 static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
     const size_t lds = (size_t)2 * (2 * NSS + 2 * NST) * kTile * sizeof(float);  // row + column tile of both clouds
-    static bool attr_set = false;  // the widest instantiations need > 64 KB of dynamic LDS: opt in once
-    if (!attr_set && lds > 64 * 1024) {
+    // the widest instantiations need > 64 KB of dynamic LDS.  The opt-in is a property of (function, DEVICE); it is
+    // renewed on every launch that needs it instead of being remembered in a process-wide flag (a second device or a
+    // second host thread would find the flag set and the attribute missing)
+    if (lds > 64 * 1024) {
         int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gwd_tiles<NSS, NST>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_gwd_tiles)");
         if (rc) return rc;
-        attr_set = true;
     }
     k_gwd_tiles<NSS, NST><<<P.ntiles, kThreads, lds, stream>>>(P);
     return EVREP_OK;
@@ -124,6 +126,19 @@ const char *evrep_last_hip_error(void) { return g_last_error; }
 
 int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
                     int64_t max_events_per_window) {
+    return evrep_plan_init_ex(plan, B, H, W, total_events, max_events_per_window, 0u);
+}
+
+int evrep_plan_set_pacing(evrep_plan *plan, int32_t ticks) {
+    if (!plan || plan->abi_version != EVREP_ABI_VERSION || ticks < -1 || ticks > 100000) return EVREP_EINVAL;
+    plan->pacing = ticks;
+    return EVREP_OK;
+}
+
+int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
+                       int64_t max_events_per_window, uint32_t flags) {
+    const bool f_classic = flags & EVREP_PLAN_NO_KEY_PASS, f_three = flags & EVREP_PLAN_THREE_KERNEL;
+    const bool f_force_ks = flags & EVREP_PLAN_FORCE_KEY_SORTED, f_big = flags & EVREP_PLAN_BIG_BLOCKS;
     if (!plan || B <= 0 || H <= 0 || W <= 0 || H > EVREP_MAX_DIM || W > EVREP_MAX_DIM) return EVREP_EINVAL;
     if (total_events < 0 || max_events_per_window < 0 || max_events_per_window > total_events) return EVREP_EINVAL;
     if (total_events >= (int64_t)1 << 31 || (int64_t)H * W >= (int64_t)1 << 30) return EVREP_EINVAL;
@@ -134,6 +149,8 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     plan->B = B; plan->H = H; plan->W = W;
     plan->total_events = total_events;
     plan->max_events_per_window = max_events_per_window;
+    plan->flags = (int32_t)flags;
+    plan->pacing = -1;
     int64_t chunk = 2048;
     int64_t nblk = (max_events_per_window + chunk - 1) / chunk;
     if (nblk > 128) {
@@ -143,7 +160,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     // the two-kernel pass (k_block_rowsort + k_col_sort_runs): windows of <= 64 blocks of 8192 events on sensors
     // whose per-wave row counters fit next to the 128 KB record stage in one workgroup's LDS (H <= ~900)
     const bool two_kernel = max_events_per_window <= (int64_t)kCsMaxRuns * kBsChunk &&
-                            block_rowsort_lds_bytes(H) + 1024 <= 160 * 1024 && !getenv("EVREP_BIN_THREE_KERNEL");
+                            block_rowsort_lds_bytes(H) + 1024 <= 160 * 1024 && !f_three;
     if (two_kernel) {
         chunk = kBsChunk;
         nblk = (max_events_per_window + chunk - 1) / chunk;
@@ -159,14 +176,12 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
     const int64_t NK = (int64_t)H * plan->nchunk;
     const bool key_sorted = two_kernel && max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk && NK < 65535 &&
                             block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
-                            ((double)max_events_per_window <= 30.0 * (double)NK || getenv("EVREP_BIN_KEY_SORTED")) &&
-                            !getenv("EVREP_BIN_CLASSIC") &&
-                            !getenv("EVREP_BIN_THREE_KERNEL");
+                            ((double)max_events_per_window <= 30.0 * (double)NK || f_force_ks) && !f_classic && !f_three;
     // dense windows on the same sensors: k_block_keysort + the column sort run per KEY (k_col_sort_runs, by_key),
     // then the classic builders on the pixel-sorted stream
     const bool key_dense = !key_sorted && two_kernel && NK < 65535 &&
                            block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
-                           !getenv("EVREP_BIN_CLASSIC") && !getenv("EVREP_BIN_THREE_KERNEL");
+                           !f_classic && !f_three;
     size_t table_words = (size_t)B * nblk * (H + 1);
     if (key_dense) {
         plan->reserved = 3;
@@ -176,7 +191,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
         plan->reserved = 2;
         // windows of <= 16 x 4096 events: 4096-event blocks (the builder waves still find a record's run by the
         // 16-step readlane chain), twice the workgroups of the 8192-event blocks
-        if (max_events_per_window <= (int64_t)kBsChainBlocks * 4096 && !getenv("EVREP_KS_BIG_BLOCKS")) {
+        if (max_events_per_window <= (int64_t)kBsChainBlocks * 4096 && !f_big) {
             chunk = 4096;
             nblk = (max_events_per_window + chunk - 1) / chunk;
             if (nblk < 1) nblk = 1;
@@ -240,24 +255,22 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     if (plan->reserved == 2 || plan->reserved == 3) {
         if ((chunk != kBsChunk && chunk != 4096) || nblk > (plan->reserved == 2 ? kBsMaxBlocks : kCsMaxRuns)) return EVREP_EINVAL;
         const int NK = H * plan->nchunk;
-        static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
-        if (!attr_set) {
-            int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort<1024>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
-                                "hipFuncSetAttribute(k_block_keysort)");
-            if (!rc2) rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_keysort<512>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
-                                      "hipFuncSetAttribute(k_block_keysort)");
-            if (rc2) return rc2;
-            attr_set = true;
-        }
+        // > 64 KB of dynamic LDS has to be opted into per (function, device): renewed on every launch that needs it (no
+        // process-wide "already done" flag: a plan may run on any device, from any host thread)
+        auto opt_in = [&](const void *fn, size_t lds) -> int {
+            if (lds <= 64 * 1024) return EVREP_OK;
+            return hip_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
+                             "hipFuncSetAttribute(k_block_keysort)");
+        };
         if (chunk == 4096) {
             // a 2048-record stage (two rounds) keeps the workgroup under 53 KB where the key table allows: three per CU
             const int cap = block_keysort_lds_bytes(NK, 2048, 4096) <= 52 * 1024 ? 2048 : 4096;
+            if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<512>), block_keysort_lds_bytes(NK, cap, 4096))) return rc2;
             k_block_keysort<512><<<xgrid, 512, block_keysort_lds_bytes(NK, cap, 4096), stream>>>(
                 ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
         } else {
             const int cap = block_keysort_lds_bytes(NK, kBsChunk, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096;
+            if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<1024>), block_keysort_lds_bytes(NK, cap, kBsChunk))) return rc2;
             k_block_keysort<1024><<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap, kBsChunk), stream>>>(
                 ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
         }
@@ -268,13 +281,11 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     if (plan->reserved == 1) {
         if (chunk != kBsChunk || nblk > kCsMaxRuns) return EVREP_EINVAL;
         const size_t lds = block_rowsort_lds_bytes(H);
-        static bool attr_set = false;  // > 64 KB of dynamic LDS has to be opted into once per process
-        if (!attr_set) {
+        if (lds > 64 * 1024) {  // per (function, device) opt-in, renewed per launch (see k_block_keysort above)
             int rc2 = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_rowsort),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024),
                                 "hipFuncSetAttribute(k_block_rowsort)");
             if (rc2) return rc2;
-            attr_set = true;
         }
         k_block_rowsort<<<xgrid, kBsThreads, lds, stream>>>(ev, offsets, B, H, W, nblk, table, stats, s1);
         LAUNCH_CHECK("k_block_rowsort");
@@ -287,7 +298,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     }
     k_row_hist<<<xgrid, kBinThreads, (size_t)H * 4, stream>>>(ev, offsets, B, H, W, chunk, nblk, table, stats);
     LAUNCH_CHECK("k_row_hist");
-    if (chunk <= kStageRecs && fused_scatter_lds_bytes(H) <= 65536 && !getenv("EVREP_NO_FUSED_SCATTER")) {
+    if (chunk <= kStageRecs && fused_scatter_lds_bytes(H) <= 65536 && !(plan->flags & EVREP_PLAN_NO_FUSED_SCATTER)) {
         // scan fused into the scatter (one kernel and one launch boundary fewer)
         k_row_scatter_fused<<<xgrid, kBinThreads, fused_scatter_lds_bytes(H), stream>>>(ev, offsets, B, H, W, chunk, nblk, table,
                                                                                      stats, row_off, meta, s1);
@@ -317,6 +328,9 @@ static BinView bin_view(const evrep_plan *plan, void *workspace) {
     bv.spill = WS(Rec, off_sorted2);
     bv.nblk = plan->nblk;
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
+#ifdef EVREP_TIMING
+    bv.dbg = WS(unsigned long long, off_sorted2);   // 8 slots per builder wave in the (idle) spill stream
+#endif
     return bv;
 }
 
@@ -337,9 +351,30 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     uc.span = (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) ? 1 : (per_chunk <= 30.0 ? 2 : 1);  // a 128-pixel chunk of >= 8 KB stays alone
     uc.stage = (uc.span + extra_chunks > 1) ? 128 : 64;
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
+    uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     return uc;
 }
 #define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
+
+// Automatic store pacing (plan->pacing == -1) of a builder instance whose launch is bound by its HBM writes on sparse
+// windows.  The waves resident on a CU offer U x unit_bytes every wave lifetime; on most placements of a ~1 GB output tensor
+// MI355X serves ~5.7 TB/s when that offer exceeds ~7 TB/s (19 waves x 12 KiB ready after ~7 us: 8.5 TB/s), and
+// 6.4-6.9 TB/s when it stays just below (tools/experiments/pacing.py: the float64 12-channel builder takes
+// 168 us unpaced, 148 us held at 7.0 us, 155 us held at 7.5 us -- a cliff on the short side, a slope on the long side, so
+// the hold sits 2 % beyond the knee).  The hold scales with the bytes the CU's resident waves own.
+static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_bytes, int span, size_t pixel_bytes) {
+    const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    if (per_chunk > 30.0) return 0;   // dense windows are bound by their segment walks, not by their stores
+    int waves = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves, kernel, kWave, lds_bytes) != hipSuccess || waves <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const int nunit = (plan->nchunk + span - 1) / span;
+    const double unit_bytes = (double)plan->W * (double)pixel_bytes / (double)nunit;   // a row's bytes over its units
+    const double ticks = 715.0 * ((double)waves * unit_bytes) / (19.0 * 12288.0);
+    return ticks < 50.0 ? 0 : (int)(ticks + 0.5);
+}
 
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
                const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
@@ -357,12 +392,17 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     bool ergo = C == Ergo12Table::kC;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
-    const UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+    UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+    if ((plan->flags & EVREP_PLAN_X_SPAN2) && plan->nchunk >= 2) { uc.span = 2; uc.stage = 128; }
     const int span = uc.span;
+    const bool pace_auto = plan->pacing < 0 && out_dtype == EVREP_F64 && C * 8 >= 64;   // the store-bound instances
 #define MDES_LAUNCH(T, DESC)                                                                                          \
-    k_mdes<T, DESC><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx, uc.stage), stream>>>(                    \
-        bin_view(plan, workspace), offsets, P, plan->H, plan->W,  \
-        plan->nchunk, uc, scale, static_cast<T *>(out))
+    do {                                                                                                              \
+        const size_t lds_ = chunk_lds_bytes(C, sizeof(T), span * kChunkPx, uc.stage, uc.partpx);                       \
+        if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T)); \
+        k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, workspace), offsets, P, plan->H, plan->W,   \
+                                                                  plan->nchunk, uc, scale, static_cast<T *>(out));           \
+    } while (0)
 #define MDES_RUNTIME(T)                                     \
     do {                                                    \
         if (C <= 4) MDES_LAUNCH(T, RuntimeDesc<4>);         \

@@ -35,9 +35,11 @@ class EventBatch:
 
     events  : (total, 4) int32 cuda tensor, rows [x, y, t, p], each window time-sorted
     offsets : (B+1,) int64 tensor (host or device); window b = rows [offsets[b], offsets[b+1])
+    plan_flags : _lib.PLAN_* bits (None: from the EVREP_BIN_* environment switches of the tests and A/B tools)
+    pacing  : store pacing of the wide float64 builders, see evrep_plan_set_pacing (None: EVREP_PACING or automatic)
     """
 
-    def __init__(self, events, offsets, height, width, max_events_per_window=None):
+    def __init__(self, events, offsets, height, width, max_events_per_window=None, plan_flags=None, pacing=None):
         _require_gpu()
         self.lib = _lib.load()
         if events.dtype != torch.int32 or events.dim() != 2 or events.shape[1] != 4 or not events.is_cuda:
@@ -54,8 +56,12 @@ class EventBatch:
         self.H, self.W = int(height), int(width)
         self.total = int(self.events.shape[0])
         self.plan = Plan()
-        check(self.lib.evrep_plan_init(ctypes.byref(self.plan), self.B, self.H, self.W, self.total,
-                                       int(max_events_per_window)), "evrep_plan_init")
+        flags = _lib.plan_flags_from_env() if plan_flags is None else int(plan_flags)
+        check(self.lib.evrep_plan_init_ex(ctypes.byref(self.plan), self.B, self.H, self.W, self.total,
+                                          int(max_events_per_window), flags), "evrep_plan_init_ex")
+        pacing = _lib.pacing_from_env() if pacing is None else int(pacing)
+        if pacing is not None:
+            check(self.lib.evrep_plan_set_pacing(ctypes.byref(self.plan), pacing), "evrep_plan_set_pacing")
         nbytes = int(self.lib.evrep_workspace_bytes(ctypes.byref(self.plan)))
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._binned = False

@@ -10,7 +10,9 @@
  * Conventions
  *   - plain C types only; every pointer marked DEVICE is a HIP device pointer, `stream` is a
  *     hipStream_t passed as void* (NULL = the null stream);
- *   - no global state, no allocation: the caller owns a workspace of evrep_workspace_bytes();
+ *   - no global state (nothing is remembered between calls, no environment variable is read, any number of host
+ *     threads may drive any number of devices and streams), no allocation: the caller owns a workspace of
+ *     evrep_workspace_bytes();
  *   - every call is asynchronous on `stream` and returns an EVREP_* status (launch errors
  *     included); data-dependent failures the reference reports as Python exceptions are
  *     recorded per window in the workspace and read back with evrep_read_status();
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVREP_ABI_VERSION 1
+#define EVREP_ABI_VERSION 2
 
 /* return codes */
 #define EVREP_OK 0
@@ -64,9 +66,22 @@ typedef struct evrep_plan {
                                       2 = key-sorted (k_block_keysort alone; the builder waves finish the order by pixel),
                                       3 = k_block_keysort + the column sort per (row, chunk) key (dense windows),
                                       1 = k_block_rowsort + the column sort per row, 0 = the three-kernel pass */
+    int32_t flags;                 /* EVREP_PLAN_* bits the plan was made with */
+    int32_t pacing;                /* store pacing of the wide float64 builders (evrep_plan_set_pacing): -1 = automatic,
+                                      0 = off, > 0 = every builder wave starts its stores no earlier than this many
+                                      10 ns ticks after it started */
     size_t off_meta, off_table, off_stats, off_rowoff, off_chunkoff, off_sorted1, off_sorted2, off_cuts, off_scratch;
     size_t workspace_bytes;
 } evrep_plan;
+
+/* evrep_plan_init_ex flags: which binning passes the plan may choose from (A/B timing and the cross-pass parity
+ * tests; every pass produces the same tensors bit for bit), and two tuning knobs. */
+#define EVREP_PLAN_NO_KEY_PASS 1u       /* keep passes 2 and 3 (k_block_keysort) out of the choice */
+#define EVREP_PLAN_THREE_KERNEL 2u      /* the round-1 three-kernel pass (0) only */
+#define EVREP_PLAN_FORCE_KEY_SORTED 4u  /* pass 2 also for windows denser than it is chosen for */
+#define EVREP_PLAN_BIG_BLOCKS 8u        /* key-sorted pass: 8192-event blocks also for short windows */
+#define EVREP_PLAN_NO_FUSED_SCATTER 16u /* three-kernel pass: separate scan and scatter kernels */
+#define EVREP_PLAN_X_SPAN2 64u          /* experiment: float64 MDES units of two 128-pixel chunks */
 
 int evrep_abi_version(void);
 const char *evrep_last_hip_error(void);
@@ -75,6 +90,13 @@ const char *evrep_last_hip_error(void);
  * max_events_per_window in any one window. */
 int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
                     int64_t max_events_per_window);
+/* The same with EVREP_PLAN_* flags (evrep_plan_init = flags 0).  The library itself reads no environment variable:
+ * the Python binding translates EVREP_BIN_CLASSIC / EVREP_BIN_THREE_KERNEL / EVREP_BIN_KEY_SORTED / ... into flags. */
+int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
+                       int64_t max_events_per_window, uint32_t flags);
+/* Store pacing of the builders whose launch is bound by HBM writes: ticks = -1 automatic (what
+ * evrep_plan_init sets), 0 off, > 0 explicit hold in 10 ns ticks.  Results never depend on it. */
+int evrep_plan_set_pacing(evrep_plan *plan, int32_t ticks);
 size_t evrep_workspace_bytes(const evrep_plan *plan);
 
 /* The (y,x) binning pass every builder consumes: a stable two-level partition of each window's

@@ -1,0 +1,42 @@
+"""Where a builder wave's time goes (experiment build: -DEVREP_TIMING, EVREP_LIB_PATH=<that .so>).  Phase marks of k_mdes, mean
+us since the wave started: 0 records fetched and grouped (unit_front), 1 window statistics merged, 2 segment heads listed +
+digest, 3 reduced and published (pace entry), 4 pace left, 5 stores issued.
+
+    hipcc ... -DEVREP_TIMING -o /tmp/libevrep_timing.so ...; EVREP_LIB_PATH=/tmp/libevrep_timing.so python tools/experiments/phase_times.py [hold ...]
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+from event_representation_study_amd._lib import check
+from event_representation_study_amd.engine import EventBatch
+from event_representation_study_amd.synthetic import make_events
+
+H, W, N, B = 480, 640, 50000, 32
+eb = EventBatch.from_numpy([make_events(N, W, H, seed=i) for i in range(B)], H, W)
+eb.bin()
+outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(4)]
+holds = [int(v) for v in sys.argv[1:]] or [0, 600, 670]
+nunit = B * H * ((W + 127) // 128)
+assert nunit * 64 <= (eb.total + 1) * 16, "the spill stream is too small for the marks"
+dbg = eb.workspace[eb.plan.off_sorted2: eb.plan.off_sorted2 + nunit * 64].view(torch.int64).view(nunit, 8)
+for o in outs:
+    for h in holds:
+        check(eb.lib.evrep_plan_set_pacing(ctypes.byref(eb.plan), h), "pacing")
+        for _ in range(3):
+            eb.optimized(out=o)
+        torch.cuda.synchronize()
+        dbg.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            eb.optimized(out=o)
+        b.record()
+        torch.cuda.synchronize()
+        d = dbg.cpu().numpy().astype(float) / 100.0
+        import numpy as np
+        ph = ["%d: %.2f/%.2f" % (i, d[:, i].mean(), np.percentile(d[:, i], 95)) for i in range(6)]
+        print("%x hold %4d  %.1f us/launch  phases mean/p95 (us) %s" % (o.data_ptr(), h, a.elapsed_time(b) * 100, "  ".join(ph)), flush=True)
