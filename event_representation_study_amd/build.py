@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libevrep.so")
 SOURCES = ["evrep_capi.hip"]                      # unity build: includes the kernel files
-DEPS = ["evrep_capi.hip", "evrep_bin.hip", "evrep_builders.hip", "evrep_gwd.hip", "evrep_gw.hip", "evrep_common.h",
+DEPS = ["evrep_capi.hip", "evrep_bin.hip", "evrep_builders.hip", "evrep_gwd.hip", "evrep_otmi.hip", "evrep_gw.hip", "evrep_common.h",
         os.path.join(ROOT, "include", "evrep.h")]
 
 # -ffp-contract=off: the parity contract is bit-exactness with the reference's separate

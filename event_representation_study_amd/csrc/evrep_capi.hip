@@ -11,6 +11,7 @@
 #include "evrep_bin.hip"
 #include "evrep_builders.hip"
 #include "evrep_gwd.hip"
+#include "evrep_otmi.hip"
 #include "evrep_gw.hip"
 
 using namespace evrep;
@@ -45,6 +46,27 @@ static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
     return EVREP_OK;
 }
 
+
+template <int NSS, int NST>
+static int gwd_launch_tiles_batch(const GwdPair *pairs, int P, const int64_t *total, int64_t want, int cus, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (2 * NSS + 2 * NST) * kTile * sizeof(float);
+    if (lds > 64 * 1024) {
+        int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gwd_tiles_batch<NSS, NST>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_gwd_tiles_batch)");
+        if (rc) return rc;
+    }
+    // exactly the workgroups the device holds at once: resident workgroups are what keeps the matrix pipe fed (DESIGN.md
+    // 3.3), and a grid beyond that runs its surplus as a thin second round behind the first.  The kernel is compiled for
+    // 5 (4 for the wide instances) waves per SIMD = workgroups per CU (amdgpu_waves_per_eu in evrep_gwd.hip); LDS allows
+    // 160 KB / lds.  (hipOccupancyMaxActiveBlocksPerMultiprocessor reports one less than the hardware runs here.)
+    int per_cu = NSS + NST <= 11 ? 5 : 4;
+    const int by_lds = (int)((160 * 1024) / (lds + 64));
+    if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds;
+    const int64_t resident = (int64_t)cus * per_cu;
+    const int grid = (int)(want < resident ? want : resident);
+    k_gwd_tiles_batch<NSS, NST><<<grid, kThreads, lds, stream>>>(pairs, P, total);
+    return EVREP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------- entropic GW (F5)
 template <typename T>
@@ -686,6 +708,79 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     LAUNCH_CHECK("k_gwd_tiles");
     k_gwd_finish<<<1, 1024, 0, stream>>>(partial, P.ntiles, (double)L, cost);
     LAUNCH_CHECK("k_gwd_finish");
+    return EVREP_OK;
+}
+
+size_t evrep_gwd_batch_scratch_bytes(int32_t P, int32_t ds, int32_t dt, int64_t n_cap, int64_t m_cap) {
+    if (P <= 0 || n_cap <= 0 || m_cap <= 0 || ds <= 0 || dt <= 0 || ds > kGwdMaxD || dt > kGwdMaxD) return 0;
+    return gwd_batch_layout(P, ds, dt, n_cap, m_cap).bytes;
+}
+
+int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row, const int64_t *n, int32_t ds,
+                              const double *Xt, const int64_t *xt_row, const int64_t *m, int32_t dt, int64_t n_cap,
+                              int64_t m_cap, double h, void *scratch, double *costs, void *stream_) {
+    if (P <= 0 || P > 65535 || !Xs || !Xt || !n || !m || !scratch || !costs) return EVREP_EINVAL;
+    if (ds <= 0 || dt <= 0 || ds > kGwdMaxD || dt > kGwdMaxD || n_cap <= 0 || m_cap <= 0 || !(h > 0.0)) return EVREP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(scratch) & 255u) return EVREP_EINVAL;
+    const int64_t Lc = n_cap > m_cap ? n_cap : m_cap;
+    const int64_t Tc = pad_tile(Lc) / kTile;
+    if (Tc * (Tc + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const GwdBatchLayout L = gwd_batch_layout(P, ds, dt, n_cap, m_cap);
+    GwdBatchArgs B;
+    B.Xs = Xs; B.Xt = Xt; B.xs_row = xs_row; B.xt_row = xt_row; B.n = n; B.m = m; B.P = P; B.ds = ds; B.dt = dt;
+    B.n_cap = n_cap; B.m_cap = m_cap;
+    B.scratch = static_cast<char *>(scratch);
+    B.pairs = reinterpret_cast<GwdPair *>(B.scratch + L.off_pairs);
+    B.total_tiles = reinterpret_cast<int64_t *>(B.scratch + L.off_total);
+    B.partial = reinterpret_cast<double *>(B.scratch + L.off_partial);
+    // four launches for ALL pairs: the pair table; the clouds' partial sums; the scaling pass; the tiles (a fixed grid
+    // striding over the concatenated tile list, so no size has to be known on the host); the final sums
+    k_gwd_batch_setup<<<1, kThreads, 0, stream>>>(B);
+    LAUNCH_CHECK("k_gwd_batch_setup");
+    k_gwd_stats_batch<<<dim3(kStatBlocks, 2, P), kThreads, 0, stream>>>(B.pairs, ds, dt);
+    LAUNCH_CHECK("k_gwd_stats_batch");
+    const int sblocks = (int)((pad_tile(n_cap) + kThreads - 1) / kThreads), tblocks = (int)((pad_tile(m_cap) + kThreads - 1) / kThreads);
+    k_gwd_prep_batch<<<dim3(sblocks + tblocks, P), kThreads, 0, stream>>>(B.pairs, ds, dt, h, sblocks);
+    LAUNCH_CHECK("k_gwd_prep_batch");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t want = (int64_t)P * (Tc * (Tc + 1) / 2);
+    int rc = EVREP_OK;
+    const int ss = gwd_steps(ds), st = gwd_steps(dt);
+#define GWD_CASE(A, Bq) if (ss == A && st == Bq) rc = gwd_launch_tiles_batch<A, Bq>(B.pairs, P, B.total_tiles, want, cus, stream)
+    GWD_CASE(3, 3); else GWD_CASE(3, 8); else GWD_CASE(3, 17); else GWD_CASE(8, 3); else GWD_CASE(8, 8);
+    else GWD_CASE(8, 17); else GWD_CASE(17, 3); else GWD_CASE(17, 8); else GWD_CASE(17, 17);
+#undef GWD_CASE
+    if (rc) return rc;
+    LAUNCH_CHECK("k_gwd_tiles_batch");
+    k_gwd_finish_batch<<<P, 1024, 0, stream>>>(B.pairs, costs);
+    LAUNCH_CHECK("k_gwd_finish_batch");
+    return EVREP_OK;
+}
+
+int evrep_otmi_event_clouds(const int32_t *events, const int64_t *offsets, int32_t B, int32_t height, int32_t width,
+                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *stream_) {
+    if (!events || !offsets || !Xs || !n_out || !quad_out || B <= 0 || B > 65535 || height <= 1 || width <= 1 || cap <= 0)
+        return EVREP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(events) & 15u) return EVREP_EINVAL;
+    k_otmi_events<<<B, kOtmiThreads, 0, static_cast<hipStream_t>(stream_)>>>(reinterpret_cast<const int4 *>(events), offsets,
+                                                                            height, width, cap, Xs, n_out, quad_out);
+    LAUNCH_CHECK("k_otmi_events");
+    return EVREP_OK;
+}
+
+int evrep_otmi_rep_clouds(const void *rep, int32_t rep_dtype, int32_t items, int32_t B, int32_t S, int32_t C,
+                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *stream_) {
+    if (!rep || !quad || !Xt || !m_out || items <= 0 || items > 65535 || B <= 0 || S < 4 || C <= 0 || C + 2 > kGwdMaxD || m_cap <= 0)
+        return EVREP_EINVAL;
+    if (rep_dtype != EVREP_F64 && rep_dtype != EVREP_F32) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (rep_dtype == EVREP_F64)
+        k_otmi_rep<double><<<dim3(3, items), kOtmiThreads, 0, stream>>>(static_cast<const double *>(rep), B, S, C, quad, m_cap, Xt, m_out);
+    else
+        k_otmi_rep<float><<<dim3(3, items), kOtmiThreads, 0, stream>>>(static_cast<const float *>(rep), B, S, C, quad, m_cap, Xt, m_out);
+    LAUNCH_CHECK("k_otmi_rep");
     return EVREP_OK;
 }
 

@@ -19,21 +19,13 @@ constexpr int kTile = 128;  // tile edge; 4 waves, each a 32-row strip of four 3
 constexpr int kStatBlocks = 64;  // partial-sum blocks per cloud
 
 
-// grid (kStatBlocks, 2): block (j, c) sums x and x^2 per dimension over its slice of cloud c
+// Block `blk` of kStatBlocks sums x and x^2 per dimension over its slice of one cloud
 // (float64, one pass; the clouds hold O(1e4) points of magnitude <= 255, so sum(x^2)/N - mean^2
-// keeps ~1e-11 relative accuracy, far inside the 1e-5 budget).  partial: [2][kStatBlocks][2*kGwdMaxD].
-__global__ __launch_bounds__(kThreads) void k_gwd_stats(const double *__restrict__ Xs, int64_t n, int ds,
-                                                       const double *__restrict__ Xt, int64_t m, int dt,
-                                                       double *__restrict__ partial) {
-    __shared__ double red[kWaves][2 * kGwdMaxD];
-    const bool second = blockIdx.y == 1;
-    const double *X = second ? Xt : Xs;
-    const int64_t N = second ? m : n;
-    const int d = second ? dt : ds;
+// keeps ~1e-11 relative accuracy, far inside the 1e-5 budget).  dst: this cloud's [kStatBlocks][2*kGwdMaxD].
+__device__ inline void gwd_stats_body(const double *__restrict__ X, int64_t N, int d, int blk, double *__restrict__ dst,
+                                      double (*red)[2 * kGwdMaxD]) {
     const int64_t per = (N + kStatBlocks - 1) / kStatBlocks;
-    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = (i0 + per < N) ? i0 + per : N;
-    // flat walk over the slice's elements: consecutive lanes read consecutive doubles (coalesced);
-    // a lane's elements e = i0*d + tid + k*256 visit dimension (e % d)
+    const int64_t i0 = (int64_t)blk * per, i1 = (i0 + per < N) ? i0 + per : N;
     double s[kGwdMaxD], q[kGwdMaxD];
 #pragma unroll
     for (int k = 0; k < kGwdMaxD; ++k) { s[k] = 0.0; q[k] = 0.0; }
@@ -57,8 +49,18 @@ __global__ __launch_bounds__(kThreads) void k_gwd_stats(const double *__restrict
     if (threadIdx.x < 2 * d) {
         double a = 0.0;
         for (int w = 0; w < kWaves; ++w) a += red[w][threadIdx.x];
-        partial[((size_t)blockIdx.y * kStatBlocks + blockIdx.x) * (2 * kGwdMaxD) + threadIdx.x] = a;
+        dst[(size_t)blk * (2 * kGwdMaxD) + threadIdx.x] = a;
     }
+}
+
+// grid (kStatBlocks, 2): block (j, c) = slice j of cloud c.  partial: [2][kStatBlocks][2*kGwdMaxD].
+__global__ __launch_bounds__(kThreads) void k_gwd_stats(const double *__restrict__ Xs, int64_t n, int ds,
+                                                       const double *__restrict__ Xt, int64_t m, int dt,
+                                                       double *__restrict__ partial) {
+    __shared__ double red[kWaves][2 * kGwdMaxD];
+    const bool second = blockIdx.y == 1;
+    gwd_stats_body(second ? Xt : Xs, second ? m : n, second ? dt : ds, (int)blockIdx.x,
+                   partial + (size_t)blockIdx.y * kStatBlocks * (2 * kGwdMaxD), red);
 }
 
 // Augmented coordinates the matrix cores consume (built per tile in LDS):
@@ -77,28 +79,19 @@ __host__ __device__ inline int gwd_steps(int d) { return d + 2 <= 6 ? 3 : (d + 2
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// grid (ceil(npad / 256) + ceil(mpad / 256)), 256 threads: both clouds in one launch.  Every block first finishes
-// the cloud statistics from the 2 x 64 partial sums itself (fixed order, so all blocks agree bit for bit; no
-// separate one-block kernel), then centres / scales one point per thread and writes both augmented forms,
+// One block of the scaling pass of ONE cloud (blk = its index among the cloud's ceil(Npad / 256) blocks).  The block
+// first finishes the cloud statistics from the 64 partial sums itself (fixed order, so all blocks agree bit for bit;
+// no separate one-block kernel), then centres / scales one point per thread and writes both augmented forms,
 // dimension-major float32, zero points beyond N:  YA, YB = [2 * steps][Npad].
 // sigma^2 = mean ||a - abar||^2 = sum_k (E[x_k^2] - E[x_k]^2).
-__global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict__ Xs, int64_t n, int ds, int64_t npad,
-                                                      const double *__restrict__ Xt, int64_t m, int dt, int64_t mpad,
-                                                      const double *__restrict__ stat_partial, double h, int sblocks,
-                                                      float *__restrict__ YsA, float *__restrict__ YsB,
-                                                      float *__restrict__ YtA, float *__restrict__ YtB) {
-    __shared__ double smean[kGwdMaxD];
-    __shared__ double ssc;
-    const int c = (int)blockIdx.x >= sblocks ? 1 : 0;  // which cloud this block scales
-    const double *X = c ? Xt : Xs;
-    const int64_t N = c ? m : n, Npad = c ? mpad : npad;
-    const int d = c ? dt : ds;
-    float *YA = c ? YtA : YsA, *YB = c ? YtB : YsB;
+__device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
+                                     const double *__restrict__ stat_cloud, double h, float *__restrict__ YA,
+                                     float *__restrict__ YB, double *smean, double *ssc) {
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
         double sx = 0.0, sq = 0.0;
         if (k < d) {
-            const double *p = stat_partial + (size_t)c * kStatBlocks * (2 * kGwdMaxD) + 2 * k;
+            const double *p = stat_cloud + 2 * k;
 #pragma unroll 16
             for (int j = 0; j < kStatBlocks; ++j) { sx += p[(size_t)j * (2 * kGwdMaxD)]; sq += p[(size_t)j * (2 * kGwdMaxD) + 1]; }
         }
@@ -107,12 +100,12 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict_
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
         smean[k] = mean;
-        if (k == 0) ssc = sqrt(1.4426950408889634 / (2.0 * h * h * var));
+        if (k == 0) *ssc = sqrt(1.4426950408889634 / (2.0 * h * h * var));
     }
     __syncthreads();
-    const int64_t i = (int64_t)((int)blockIdx.x - (c ? sblocks : 0)) * kThreads + threadIdx.x;
+    const int64_t i = (int64_t)blk * kThreads + threadIdx.x;
     if (i >= Npad) return;
-    const double sc = ssc;
+    const double sc = *ssc;
     const int kp = 2 * gwd_steps(d);
     const bool real = i < N;
     float nrm = 0.0f;
@@ -128,6 +121,19 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict_
     YA[(int64_t)(d + 1) * Npad + i] = real ? -1.0f : 0.0f;
     YB[(int64_t)(d + 1) * Npad + i] = real ? nrm : 0.0f;
     for (int k = d + 2; k < kp; ++k) { YA[(int64_t)k * Npad + i] = 0.0f; YB[(int64_t)k * Npad + i] = 0.0f; }
+}
+
+// grid (ceil(npad / 256) + ceil(mpad / 256)), 256 threads: both clouds in one launch.
+__global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict__ Xs, int64_t n, int ds, int64_t npad,
+                                                      const double *__restrict__ Xt, int64_t m, int dt, int64_t mpad,
+                                                      const double *__restrict__ stat_partial, double h, int sblocks,
+                                                      float *__restrict__ YsA, float *__restrict__ YsB,
+                                                      float *__restrict__ YtA, float *__restrict__ YtB) {
+    __shared__ double smean[kGwdMaxD];
+    __shared__ double ssc;
+    const int c = (int)blockIdx.x >= sblocks ? 1 : 0;  // which cloud this block scales
+    gwd_prep_body(c ? Xt : Xs, c ? m : n, c ? dt : ds, c ? mpad : npad, (int)blockIdx.x - (c ? sblocks : 0),
+                  stat_partial + (size_t)c * kStatBlocks * (2 * kGwdMaxD), h, c ? YtA : YsA, c ? YtB : YsB, smean, &ssc);
 }
 
 // Operands of one 32-point strip for v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3): lane l holds
@@ -165,33 +171,34 @@ struct GwdTileArgs {
 // partial[blockIdx.x] = sum over the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
 // NSS / NST: inner MFMA steps = gwd_steps(ds), gwd_steps(dt) (compile time).
 template <int NSS, int NST>
-__global__ __launch_bounds__(kThreads) void k_gwd_tiles(GwdTileArgs P) {
+__device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds, double *red, int tid) {
     constexpr int KPS = 2 * NSS, KPT = 2 * NST;
-    extern __shared__ float lds[];  // As[KPS][kTile] Bs At[KPT][kTile] Bt
-    __shared__ double red[kWaves];
     const int64_t n = P.n, m = P.m;
     const int T = P.T;
-    // decode (bi, bj), bi <= bj, from the linear upper-triangular index
-    int t = blockIdx.x, bi = 0;
-    while (t >= T - bi) { t -= T - bi; ++bi; }
-    const int bj = bi + t;
+    // decode (bi, bj), bi <= bj, from the linear upper-triangular index: row bi starts at bi * T - bi (bi - 1) / 2.
+    // Closed form (a float estimate, corrected by at most a step either way) instead of walking up to T rows
+    int bi = (int)(((float)(2 * T + 1) - sqrtf((float)(2 * T + 1) * (float)(2 * T + 1) - 8.0f * (float)tile)) * 0.5f);
+    bi = bi < 0 ? 0 : (bi > T - 1 ? T - 1 : bi);
+    while (bi > 0 && (int64_t)bi * T - (int64_t)bi * (bi - 1) / 2 > tile) --bi;
+    while (bi + 1 < T && (int64_t)(bi + 1) * T - (int64_t)(bi + 1) * bi / 2 <= tile) ++bi;
+    const int bj = bi + (int)(tile - ((int64_t)bi * T - (int64_t)bi * (bi - 1) / 2));
     const int64_t i0 = (int64_t)bi * kTile, j0 = (int64_t)bj * kTile;
     const bool has_s = j0 < n, has_t = j0 < m;  // bi <= bj: the row range starts no later
     float *As = lds, *Bs = lds + KPS * kTile, *At = lds + 2 * KPS * kTile, *Bt = At + KPT * kTile;
     if (has_s)
-        for (int e = threadIdx.x; e < KPS * kTile; e += kThreads) {
+        for (int e = tid; e < KPS * kTile; e += kThreads) {
             const int k = e / kTile, i = e % kTile;
             As[e] = P.YsA[(int64_t)k * P.npad + i0 + i];
             Bs[e] = P.YsB[(int64_t)k * P.npad + j0 + i];
         }
     if (has_t)
-        for (int e = threadIdx.x; e < KPT * kTile; e += kThreads) {
+        for (int e = tid; e < KPT * kTile; e += kThreads) {
             const int k = e / kTile, i = e % kTile;
             At[e] = P.YtA[(int64_t)k * P.mpad + i0 + i];
             Bt[e] = P.YtB[(int64_t)k * P.mpad + j0 + i];
         }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int r0 = wave * 32;
     float as[NSS], at[NST];
     if (has_s) gwd_load_strip<NSS>(As, r0, lane, as);
@@ -225,7 +232,215 @@ __global__ __launch_bounds__(kThreads) void k_gwd_tiles(GwdTileArgs P) {
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
     if (lane == 0) red[wave] = d;
     __syncthreads();
-    if (threadIdx.x == 0) P.partial[blockIdx.x] = (bi == bj ? 1.0 : 2.0) * (((red[0] + red[1]) + red[2]) + red[3]);
+    if (tid == 0) P.partial[tile] = (bi == bj ? 1.0 : 2.0) * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+template <int NSS, int NST>
+__global__ __launch_bounds__(kThreads) void k_gwd_tiles(GwdTileArgs P) {
+    extern __shared__ float lds[];  // As[KPS][kTile] Bs At[KPT][kTile] Bt
+    __shared__ double red[kWaves];
+    gwd_tile_body<NSS, NST>(P, (int)blockIdx.x, lds, red, (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------- batched solves
+// P independent (Xs, Xt) pairs in FOUR launches in all (r03; one solve alone is four launches, three of them tiny:
+// 21.6 of 91 us).  The clouds' sizes live on the DEVICE (the harness kernels of evrep_otmi.hip produce them), so
+// nothing here depends on a host read-back: k_gwd_batch_setup derives every pair's paddings, tile count and
+// scratch pointers; the statistics / scaling grids are sized by the caller's upper bounds (surplus blocks leave at
+// once); the tile kernel is a fixed grid of workgroups striding over the concatenated tile list of all pairs.
+struct GwdPair {
+    GwdTileArgs a;          // a.partial points at this pair's first tile sum
+    const double *Xs, *Xt;
+    double *stat;           // [2][kStatBlocks][2 * kGwdMaxD]
+    int64_t tile0;          // first tile of the pair in the concatenated list
+};
+
+struct GwdBatchArgs {
+    const double *Xs, *Xt;            // bases of the clouds
+    const int64_t *xs_row, *xt_row;   // [P] first row of each pair's cloud (NULL: p * n_cap / p * m_cap)
+    const int64_t *n, *m;             // [P] DEVICE sizes
+    int32_t P, ds, dt;
+    int64_t n_cap, m_cap;             // upper bounds: size the per-pair scratch slots
+    char *scratch;
+    GwdPair *pairs;                   // [P] in scratch
+    int64_t *total_tiles;             // [1] in scratch
+    double *partial;                  // concatenated tile sums
+};
+
+__host__ __device__ inline int64_t gwd_pad_tile(int64_t n) { return (n + kTile - 1) / kTile * kTile; }
+
+struct GwdBatchLayout {
+    size_t off_pairs, off_total, off_stat, off_y, off_partial, stat_stride, ys_bytes, yt_bytes, y_stride, partial_stride, bytes;
+};
+__host__ __device__ inline GwdBatchLayout gwd_batch_layout(int P, int ds, int dt, int64_t n_cap, int64_t m_cap) {
+    GwdBatchLayout L;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int64_t Lc = n_cap > m_cap ? n_cap : m_cap;
+    const int64_t T = gwd_pad_tile(Lc) / kTile;
+    size_t o = 0;
+    L.off_pairs = o;  o += up((size_t)P * sizeof(GwdPair));
+    L.off_total = o;  o += 256;
+    L.stat_stride = up((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
+    L.off_stat = o;   o += (size_t)P * L.stat_stride;
+    L.ys_bytes = up((size_t)2 * gwd_steps(ds) * gwd_pad_tile(n_cap) * sizeof(float));
+    L.yt_bytes = up((size_t)2 * gwd_steps(dt) * gwd_pad_tile(m_cap) * sizeof(float));
+    L.y_stride = 2 * L.ys_bytes + 2 * L.yt_bytes;
+    L.off_y = o;      o += (size_t)P * L.y_stride;
+    L.partial_stride = (size_t)(T * (T + 1) / 2);
+    L.off_partial = o; o += up((size_t)P * L.partial_stride * sizeof(double));
+    L.bytes = o;
+    return L;
+}
+
+// grid (1), 256 threads: the pair table.  A pair whose clouds exceed the caller's bounds (or are empty) gets no tiles;
+// its cost is NaN (k_gwd_finish_batch).
+__global__ __launch_bounds__(kThreads) void k_gwd_batch_setup(GwdBatchArgs B) {
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const GwdBatchLayout L = gwd_batch_layout(B.P, B.ds, B.dt, B.n_cap, B.m_cap);
+    for (int p0 = 0; p0 < B.P; p0 += kThreads) {
+        const int p = p0 + threadIdx.x;
+        int64_t nt = 0, n = 0, m = 0;
+        int T = 0;
+        if (p < B.P) {
+            n = B.n[p]; m = B.m[p];
+            if (n > 0 && m > 0 && n <= B.n_cap && m <= B.m_cap) {
+                const int64_t Lp = n > m ? n : m;
+                T = (int)(gwd_pad_tile(Lp) / kTile);
+                nt = (int64_t)T * (T + 1) / 2;
+            }
+        }
+        // exclusive scan of nt over the 256 pairs of this round (wave scans + 4 wave totals)
+        __shared__ int64_t wtot[kWaves];
+        int64_t incl = nt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int64_t base = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
+        const int64_t tile0 = base + incl - nt;
+        if (p < B.P) {
+            GwdPair q;
+            char *y = B.scratch + L.off_y + (size_t)p * L.y_stride;
+            q.a.YsA = reinterpret_cast<const float *>(y);
+            q.a.YsB = reinterpret_cast<const float *>(y + L.ys_bytes);
+            q.a.YtA = reinterpret_cast<const float *>(y + 2 * L.ys_bytes);
+            q.a.YtB = reinterpret_cast<const float *>(y + 2 * L.ys_bytes + L.yt_bytes);
+            q.a.n = n; q.a.m = m;
+            q.a.npad = gwd_pad_tile(n > 0 ? n : 1); q.a.mpad = gwd_pad_tile(m > 0 ? m : 1);
+            q.a.T = T; q.a.ntiles = (int32_t)nt;
+            q.a.partial = B.partial + tile0;
+            q.Xs = B.Xs + (B.xs_row ? B.xs_row[p] : (int64_t)p * B.n_cap) * B.ds;
+            q.Xt = B.Xt + (B.xt_row ? B.xt_row[p] : (int64_t)p * B.m_cap) * B.dt;
+            q.stat = reinterpret_cast<double *>(B.scratch + L.off_stat + (size_t)p * L.stat_stride);
+            q.tile0 = tile0;
+            B.pairs[p] = q;
+        }
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) carry = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *B.total_tiles = carry;
+}
+
+// grid (kStatBlocks, 2, P): the statistics of cloud blockIdx.y of pair blockIdx.z
+__global__ __launch_bounds__(kThreads) void k_gwd_stats_batch(const GwdPair *__restrict__ pairs, int ds, int dt) {
+    __shared__ double red[kWaves][2 * kGwdMaxD];
+    const GwdPair &q = pairs[blockIdx.z];
+    if (q.a.ntiles == 0) return;
+    const bool second = blockIdx.y == 1;
+    gwd_stats_body(second ? q.Xt : q.Xs, second ? q.a.m : q.a.n, second ? dt : ds, (int)blockIdx.x,
+                   q.stat + (size_t)blockIdx.y * kStatBlocks * (2 * kGwdMaxD), red);
+}
+
+// grid (sblocks_cap + tblocks_cap, P): the scaling pass of pair blockIdx.y; blocks beyond the pair's own paddings leave
+__global__ __launch_bounds__(kThreads) void k_gwd_prep_batch(const GwdPair *__restrict__ pairs, int ds, int dt, double h,
+                                                            int sblocks_cap) {
+    __shared__ double smean[kGwdMaxD];
+    __shared__ double ssc;
+    const GwdPair &q = pairs[blockIdx.y];
+    if (q.a.ntiles == 0) return;
+    const int c = (int)blockIdx.x >= sblocks_cap ? 1 : 0;
+    const int blk = (int)blockIdx.x - (c ? sblocks_cap : 0);
+    const int64_t Npad = c ? q.a.mpad : q.a.npad;
+    if ((int64_t)blk * kThreads >= Npad) return;
+    gwd_prep_body(c ? q.Xt : q.Xs, c ? q.a.m : q.a.n, c ? dt : ds, Npad, blk,
+                  q.stat + (size_t)c * kStatBlocks * (2 * kGwdMaxD), h, const_cast<float *>(c ? q.a.YtA : q.a.YsA),
+                  const_cast<float *>(c ? q.a.YtB : q.a.YsB), smean, &ssc);
+}
+
+// A pair's table entry as wave-uniform values.  Inside the tile loop (global stores, barriers) the compiler cannot prove
+// the table unclobbered, loads it with VECTOR loads and keeps the 20-odd dwords in VGPRs -- every address computation
+// of the tile body then runs on the VALU in 64 bits.  readfirstlane puts each dword into an SGPR.
+__device__ inline void gwd_load_pair_uniform(const GwdPair *q, GwdTileArgs &a, int64_t &tile0) {
+    static_assert(sizeof(GwdTileArgs) % 4 == 0, "GwdTileArgs is a whole number of dwords");
+    constexpr int NW = (int)(sizeof(GwdTileArgs) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&q->a);
+    uint32_t w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+    __builtin_memcpy(&a, w, sizeof(GwdTileArgs));
+    const uint32_t *t0 = reinterpret_cast<const uint32_t *>(&q->tile0);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0[0]), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0[1]);
+    tile0 = (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// A fixed grid of workgroups (as many as the device holds at once) strides over the concatenated tile list of all pairs:
+// tile t belongs to the last pair with tile0 <= t (pairs without tiles share their successor's tile0 and are passed over).
+template <int NSS, int NST>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NSS + NST <= 11 ? 5 : 4)))   // as k_gwd_tiles
+void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs, int P,
+                                                             const int64_t *__restrict__ total_tiles) {
+    extern __shared__ float lds[];
+    __shared__ double red[kWaves];
+    const int64_t total = *total_tiles;
+    int p = 0;
+    int64_t next0 = P > 1 ? pairs[1].tile0 : total;   // first tile of the pair behind p
+    GwdTileArgs a;                                     // the current pair's arguments, in SGPRs until the pair changes
+    int64_t tile0;
+    gwd_load_pair_uniform(pairs, a, tile0);
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        // the workgroup's tiles ascend, so the pair index only moves forward: one scalar load per pair passed (a binary
+        // search per tile cost eight dependent loads, ~4 us of a ~16 us tile)
+        if (t >= next0) {
+            while (p + 1 < P && t >= next0) { ++p; next0 = p + 1 < P ? pairs[p + 1].tile0 : total; }
+            gwd_load_pair_uniform(pairs + p, a, tile0);
+        }
+        // the thread index is laundered through an empty asm every iteration: otherwise the body's lane-derived LDS
+        // addresses are hoisted out of the tile loop and stay live across it (17 VGPRs, one workgroup per CU less --
+        // and the matrix pipe is fed by the number of resident workgroups)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        gwd_tile_body<NSS, NST>(a, (int)(t - tile0), lds, red, tid);
+        __syncthreads();   // the LDS tiles and `red` are reused by the next tile
+    }
+}
+
+// grid (P), 1024 threads: k_gwd_finish of pair blockIdx.x (the same fixed summation order as the single solve, so a
+// batched cost equals the single-solve cost bit for bit); NaN for a pair that has no tiles (empty / oversized cloud).
+__global__ __launch_bounds__(1024) void k_gwd_finish_batch(const GwdPair *__restrict__ pairs, double *__restrict__ costs) {
+    __shared__ double red[16];
+    const GwdPair &q = pairs[blockIdx.x];
+    const int count = q.a.ntiles;
+    if (count == 0) { if (threadIdx.x == 0) costs[blockIdx.x] = __longlong_as_double(0x7ff8000000000000ll); return; }
+    const double *partial = q.a.partial;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) { s0 += partial[i]; s1 += partial[i + 1024]; s2 += partial[i + 2048]; s3 += partial[i + 3072]; }
+    for (; i < count; i += 1024) s0 += partial[i];
+    double d = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int w = 0; w < 16; ++w) tsum += red[w];
+        const double L = (double)(q.a.n > q.a.m ? q.a.n : q.a.m);
+        costs[blockIdx.x] = tsum / (L * L);
+    }
 }
 
 // grid (1), 1024 threads: deterministic final reduction of the per-tile sums (fixed assignment and tree);

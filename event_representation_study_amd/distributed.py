@@ -36,6 +36,19 @@ def gather_scalars(local_values, n_items, device=None):
     return torch.stack(parts).sum(0)
 
 
+def gather_vector(local_vec, indices, n_items):
+    """local_vec: DEVICE (or CPU) float64 tensor of this rank's scores for the items `indices` -> the full vector on every
+    rank: ONE all_gather, no host round trip per score."""
+    vec = torch.zeros(n_items, dtype=torch.float64, device=local_vec.device)
+    if len(indices):
+        vec[torch.as_tensor(list(indices), dtype=torch.int64, device=local_vec.device)] = local_vec.to(torch.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return vec
+    parts = [torch.zeros_like(vec) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, vec)
+    return torch.stack(parts).sum(0)
+
+
 def sharded_scores(score_fn, items):
     """Evaluate score_fn(item) for this rank's share of `items` and all-gather the scalars."""
     mine = shard_indices(len(items))

@@ -205,6 +205,10 @@ class EventBatch:
         out = self._out(out, 2 * k, torch.float32)
         keep, tptr = self._i32_dev(sample_times, 1)
         fptr, sfptr, keep_f = ctypes.c_void_p(None), ctypes.c_void_p(None), None
+        if sample_times_f64 is not None and times_f64 is None:
+            # the C ABI rejects the pair (EINVAL); silently falling back to the int32 sample times would return a
+            # plausible but different tensor
+            raise ValueError("sample_times_f64 needs times_f64 (float64 event times)")
         if times_f64 is not None:      # float64 timestamps, one per event (the events' own t column is then not used)
             if times_f64.dtype != torch.float64 or times_f64.device != self.device or times_f64.numel() != self.total \
                     or not times_f64.is_contiguous():
@@ -430,3 +434,131 @@ def gwd_padded_l1(Xs, Xt, h=0.7, out=None):
         check(lib.evrep_gwd_padded_l1(_ptr(a), n, int(a.shape[1]), _ptr(b), m, int(b.shape[1]), float(h),
                                       _ptr(scratch), _ptr(cost), _stream_ptr()), "evrep_gwd_padded_l1")
     return cost
+
+
+class GwdWorkspace:
+    """Scratch of the batched GWD solves and of the device harness, allocated once and grown on demand (a solve used to
+    allocate its scratch per call and synchronise on its scalar)."""
+
+    def __init__(self, device=None):
+        _require_gpu()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._bufs = {}
+
+    def get(self, name, nbytes):
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._bufs[name] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return buf
+
+    def typed(self, name, shape, dtype):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return self.get(name, max(n, 256))[:n].view(dtype).view(*shape)
+
+
+_WORKSPACES = {}
+
+
+def _default_workspace(device):
+    key = str(device)
+    if key not in _WORKSPACES:
+        _WORKSPACES[key] = GwdWorkspace(device)
+    return _WORKSPACES[key]
+
+
+def gwd_padded_l1_batch(Xs, n, Xt, m, n_cap, m_cap, xs_row=None, xt_row=None, h=0.7, out=None, workspace=None):
+    """P solves of OTMI(Xs, Xt, h).solve()[1] in ONE call (five launches in all, no host synchronisation).
+    Xs: (rows, ds) float64 cuda tensor holding every source cloud, pair p = rows [xs_row[p], xs_row[p] + n[p])
+    (xs_row None: p * n_cap); Xt / xt_row / m likewise.  n, m, xs_row, xt_row: int64 cuda tensors of length P (the sizes
+    may come straight from the device harness).  n_cap, m_cap: host upper bounds of the sizes.  Returns (P,) float64
+    costs on the device (NaN for an empty or oversized cloud)."""
+    _require_gpu()
+    lib = _lib.load()
+    dev = Xs.device
+    P = int(n.numel())
+    for t, nm in ((Xs, "Xs"), (Xt, "Xt")):
+        if t.dtype != torch.float64 or t.dim() != 2 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous 2-D float64 CUDA tensor" % nm)
+    for t, nm in ((n, "n"), (m, "m"), (xs_row, "xs_row"), (xt_row, "xt_row")):
+        if t is not None and (t.dtype != torch.int64 or t.numel() != P or not t.is_cuda or not t.is_contiguous()):
+            raise ValueError("%s must be a contiguous int64 CUDA tensor of length %d" % (nm, P))
+    ds, dt = int(Xs.shape[1]), int(Xt.shape[1])
+    ws = workspace or _default_workspace(dev)
+    nbytes = int(lib.evrep_gwd_batch_scratch_bytes(P, ds, dt, int(n_cap), int(m_cap)))
+    if nbytes == 0:
+        raise ValueError("bad batch geometry (P=%d, ds=%d, dt=%d, n_cap=%d, m_cap=%d)" % (P, ds, dt, n_cap, m_cap))
+    scratch = ws.get("gwd_scratch", nbytes)
+    if out is None:
+        out = torch.empty(P, dtype=torch.float64, device=dev)
+    elif out.dtype != torch.float64 or out.numel() != P or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float64 CUDA tensor of length %d" % P)
+    null = ctypes.c_void_p(None)
+    with torch.cuda.device(dev):
+        check(lib.evrep_gwd_padded_l1_batch(P, _ptr(Xs), _ptr(xs_row) if xs_row is not None else null, _ptr(n), ds,
+                                            _ptr(Xt), _ptr(xt_row) if xt_row is not None else null, _ptr(m), dt,
+                                            int(n_cap), int(m_cap), float(h), _ptr(scratch), _ptr(out), _stream_ptr()),
+              "evrep_gwd_padded_l1_batch")
+    return out
+
+
+def otmi_event_clouds(events, offsets, height, width, cap=None, workspace=None):
+    """Device half of otmi(): events (total, 4) int32 cuda tensor of B windows (offsets: (B+1,) int64, host or device) ->
+    (Xs (B, 3, cap, 4) float64, n (B, 3) int64, quad (B, 3) int32), all on the device, nothing read back."""
+    _require_gpu()
+    lib = _lib.load()
+    dev = events.device
+    off_host = offsets.detach().cpu() if isinstance(offsets, torch.Tensor) else torch.as_tensor(np.asarray(offsets, dtype=np.int64))
+    B = int(off_host.numel() - 1)
+    if cap is None:
+        cap = int((off_host[1:] - off_host[:-1]).max().item())
+    off_dev = off_host.to(dev, torch.int64)
+    ws = workspace or _default_workspace(dev)
+    Xs = ws.typed("otmi_xs", (B, 3, int(cap), 4), torch.float64)
+    n = ws.typed("otmi_n", (B, 3), torch.int64)
+    quad = ws.typed("otmi_quad", (B, 3), torch.int32)
+    with torch.cuda.device(dev):
+        check(lib.evrep_otmi_event_clouds(_ptr(events), _ptr(off_dev), B, int(height), int(width), int(cap), _ptr(Xs),
+                                          _ptr(n), _ptr(quad), _stream_ptr()), "evrep_otmi_event_clouds")
+    return Xs, n, quad
+
+
+def otmi_rep_clouds(reps, quad, B, workspace=None, slot="otmi_xt"):
+    """Device half of otmi(): reps (items, S, S, C) float64/float32 cuda tensor of letterboxed representations (item i
+    belongs to window i % B), quad (B, 3) int32 from otmi_event_clouds -> (Xt (items, 3, m_cap, C + 2) float64,
+    m (items, 3) int64)."""
+    _require_gpu()
+    lib = _lib.load()
+    dev = reps.device
+    reps = reps.contiguous()
+    items, S, S2, C = (int(v) for v in reps.shape)
+    if S != S2:
+        raise ValueError("letterboxed representations are square")
+    m_cap = (S - (S // 2 - 1)) ** 2
+    ws = workspace or _default_workspace(dev)
+    Xt = ws.typed(slot, (items, 3, m_cap, C + 2), torch.float64)
+    m = ws.typed(slot + "_m", (items, 3), torch.int64)
+    dt = {torch.float64: _lib.F64, torch.float32: _lib.F32}[reps.dtype]
+    with torch.cuda.device(dev):
+        check(lib.evrep_otmi_rep_clouds(_ptr(reps), dt, items, int(B), S, C, _ptr(quad), int(m_cap), _ptr(Xt), _ptr(m),
+                                        _stream_ptr()), "evrep_otmi_rep_clouds")
+    return Xt, m, m_cap
+
+
+def otmi_batch(events, offsets, reps, height, width, h=0.7, workspace=None):
+    """otmi(events_b, rep_{r,b}, height, width, S) for R representations x B windows, entirely on the device:
+    events (total, 4) int32 cuda tensor + offsets (B+1), reps (R, B, S, S, C) letterboxed representations ->
+    (R, B) float64 cuda tensor of the mean cost over the three scored quadrants, plus the (R, B, 3) quadrant costs.
+    The event clouds are built once per window and shared by the R representations."""
+    R, B = int(reps.shape[0]), int(reps.shape[1])
+    ws = workspace or _default_workspace(events.device)
+    Xs, n, quad = otmi_event_clouds(events, offsets, height, width, workspace=ws)
+    cap = int(Xs.shape[2])
+    Xt, m, m_cap = otmi_rep_clouds(reps.reshape(R * B, *reps.shape[2:]), quad, B, workspace=ws)
+    dev = events.device
+    P = R * B * 3
+    slot = torch.arange(B * 3, device=dev, dtype=torch.int64).repeat(R)       # pair p -> its window's (b, k) slot
+    costs = gwd_padded_l1_batch(Xs.view(-1, 4), n.view(-1)[slot].contiguous(), Xt.view(-1, int(Xt.shape[-1])),
+                                m.view(-1), cap, m_cap, xs_row=(slot * cap).contiguous(),
+                                xt_row=(torch.arange(P, device=dev, dtype=torch.int64) * m_cap), h=h, workspace=ws)
+    q = costs.view(R, B, 3)
+    return q.mean(dim=2), q

@@ -157,3 +157,63 @@ def measure_cp(windows, build_rep, height, width, img_size=240):
 
     scores = distributed.sharded_scores(score, list(windows))
     return float(scores.mean().item()), scores
+
+
+# ------------------------------------------------------------------------------------------------ device path (r03)
+def rep_for_gwd_batch(rep, img_size):
+    """(B, H, W, C) representations on the GPU -> (B, img_size, img_size, C) float64, letterboxed: the batched form of
+    rep_for_gwd (keep-ratio resize, INTER_AREA when shrinking, then letterbox(114) without scale-up), one resize launch."""
+    rep = rep if rep.dtype == torch.float64 else rep.to(torch.float64)
+    B, h0, w0, C = (int(v) for v in rep.shape)
+    r = img_size / max(h0, w0)
+    if r != 1:
+        rep = resize_batch(rep, int(h0 * r), int(w0 * r), "area" if r < 1 else "linear")
+    h, w = int(rep.shape[1]), int(rep.shape[2])
+    r2 = min(min(img_size / h, img_size / w), 1.0)
+    nw, nh = int(round(w * r2)), int(round(h * r2))
+    if (w, h) != (nw, nh):
+        rep = resize_batch(rep, nh, nw, "linear")
+    dw, dh = (img_size - nw) / 2, (img_size - nh) / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    out = torch.full((B, nh + top + bottom, nw + left + right, C), 114.0, dtype=torch.float64, device=rep.device)
+    out[:, top:top + nh, left:left + nw] = rep
+    return out
+
+
+def measure_cp_device(windows, builders, height, width, img_size=240, h=0.7, workspace=None):
+    """C_p of several representations over the same windows, entirely on the device (BASELINE config 4): this rank's
+    windows are ONE EventBatch; every builder is one launch over the batch; resize + letterbox are batched; the quadrant
+    point clouds are built by the device harness (the event side once, shared by all representations); the 3 solves of
+    every (representation, window) are scored by ONE batched GWD call per representation; the scores of all ranks meet
+    in ONE all_gather.  builders: {name: fn(EventBatch) -> (B, H, W, C) tensor, or a list of B (Hb, Wb, C) tensors}.
+    Returns {name: (C_p, per-window scores)}."""
+    from . import engine as eng
+    windows = list(windows)
+    mine = distributed.shard_indices(len(windows))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    if mine:
+        wins = [np.ascontiguousarray(windows[i], dtype=np.int32).reshape(-1, 4) for i in mine]
+        batch = eng.EventBatch.from_numpy(wins, height, width, device=dev)
+        ws = workspace or eng._default_workspace(dev)
+        Xs, n, quad = eng.otmi_event_clouds(batch.events, batch.offsets_host, height, width, workspace=ws)
+        cap, B = int(Xs.shape[2]), len(wins)
+    for name, build in builders.items():
+        if mine:
+            rep = build(batch)
+            if isinstance(rep, (list, tuple)):                       # TORE: its own bounding-box frame per window
+                lb = torch.cat([rep_for_gwd_batch(r[None], img_size) for r in rep])
+            else:
+                lb = rep_for_gwd_batch(rep, img_size)
+            Xt, m, m_cap = eng.otmi_rep_clouds(lb, quad, B, workspace=ws)
+            P = 3 * B
+            costs = eng.gwd_padded_l1_batch(Xs.view(-1, 4), n.view(-1), Xt.view(-1, int(Xt.shape[-1])), m.view(-1), cap, m_cap,
+                                            xs_row=torch.arange(P, device=dev, dtype=torch.int64) * cap,
+                                            xt_row=torch.arange(P, device=dev, dtype=torch.int64) * m_cap, h=h, workspace=ws)
+            local = costs.view(B, 3).mean(dim=1)
+        else:
+            local = torch.zeros(0, dtype=torch.float64, device=dev)
+        scores = distributed.gather_vector(local, mine, len(windows))
+        out[name] = (scores.mean(), scores)
+    return {k: (float(v[0].item()), v[1]) for k, v in out.items()}   # the only host synchronisation

@@ -89,16 +89,28 @@ class RepPrecomputer:
         return resize_batch(rep, self.S, self.S, mode, out_dtype=torch.float32)
 
     # ------------------------------------------------------------------------------------------ host side
-    def _pinned(self, shape):
-        """Pinned staging buffers are recycled round-robin (page-locking a fresh 150 MB buffer per batch costs more
-        than the copy); a ring deeper than the writer queue, so a buffer is never reused while a writer holds it."""
-        ring = self._ring.setdefault(shape, [])
+    def _pinned_parts(self, shapes):
+        """Pinned staging for ONE batch: a flat float32 buffer from a ring (page-locking a fresh 150 MB buffer per batch
+        costs more than the copy), cut into one view per part -- so the parts of a batch never share storage, however
+        many there are (TORE hands one part per sample when the bounding-box frames differ).  The ring is deeper than
+        the writer queue + the writers, so a buffer is not handed out again while a writer may still read it."""
+        sizes = [int(np.prod(sh)) for sh in shapes]
+        total = max(sum(sizes), 1)
         depth = 4 + self.nwriters + 2
+        ring = self._ring.setdefault("flat", [])
         if len(ring) < depth:
-            ring.append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
-            return ring[-1]
-        self._ring_pos[shape] = (self._ring_pos.get(shape, -1) + 1) % depth
-        return ring[self._ring_pos[shape]]
+            ring.append(torch.empty(total, dtype=torch.float32, pin_memory=True))
+            flat = ring[-1]
+        else:
+            pos = self._ring_pos["flat"] = (self._ring_pos.get("flat", -1) + 1) % depth
+            if ring[pos].numel() < total:
+                ring[pos] = torch.empty(total, dtype=torch.float32, pin_memory=True)
+            flat = ring[pos]
+        views, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            views.append(flat[o:o + n].view(sh))
+            o += n
+        return views
 
     def _write(self, path_base, arr):
         if self.container == "h5":
@@ -143,43 +155,47 @@ class RepPrecomputer:
         main = torch.cuda.current_stream(self.device)
         it = iter(window_batches)
         pending = collections.deque()
-        with concurrent.futures.ThreadPoolExecutor(self.nloaders) as ex:
-            def submit_next():
-                try:
-                    item = next(it)
-                except StopIteration:
-                    return
-                pending.append(ex.submit(self._load, item))
-            for _ in range(self.nloaders + 1):
-                submit_next()
-            while pending:
-                slot, total, offs, nwin, nmax = pending.popleft().result()
-                submit_next()
-                ev_dev = torch.empty((total, 4), dtype=torch.int32, device=self.device)
-                ev_dev.copy_(slot["buf"][:total], non_blocking=True)
-                slot["free"] = torch.cuda.Event()
-                slot["free"].record(main)                              # the loader may refill the buffer after this
-                slot["busy"] = False
-                batch = EventBatch(ev_dev, torch.from_numpy(offs), self.H, self.W, max_events_per_window=nmax)
-                small = self.represent_batch(batch)
-                parts = small if isinstance(small, list) else [small]
-                hosts = []
-                done = torch.cuda.Event()
-                self.copy_stream.wait_stream(main)
-                with torch.cuda.stream(self.copy_stream):
-                    for part in parts:
-                        host = self._pinned(tuple(part.shape))
-                        host.copy_(part, non_blocking=True)
-                        part.record_stream(self.copy_stream)
-                        hosts.append(host)
-                    done.record(self.copy_stream)
-                host_list = hosts[0] if not isinstance(small, list) else hosts
-                q.put((count, host_list, done))
-                count += nwin
-        for _ in threads:
-            q.put(None)
-        for t in threads:
-            t.join()
+        try:
+            with concurrent.futures.ThreadPoolExecutor(self.nloaders) as ex:
+                def submit_next():
+                    try:
+                        item = next(it)
+                    except StopIteration:
+                        return
+                    pending.append(ex.submit(self._load, item))
+                for _ in range(self.nloaders + 1):
+                    submit_next()
+                while pending:
+                    slot, total, offs, nwin, nmax = pending.popleft().result()
+                    submit_next()
+                    try:
+                        ev_dev = torch.empty((total, 4), dtype=torch.int32, device=self.device)
+                        ev_dev.copy_(slot["buf"][:total], non_blocking=True)
+                        slot["free"] = torch.cuda.Event()
+                        slot["free"].record(main)                          # the loader may refill the buffer after this
+                    finally:
+                        slot["busy"] = False                               # also when the H2D failed: the slot is not leaked
+                    batch = EventBatch(ev_dev, torch.from_numpy(offs), self.H, self.W, max_events_per_window=nmax)
+                    small = self.represent_batch(batch)
+                    parts = small if isinstance(small, list) else [small]
+                    hosts = self._pinned_parts([tuple(part.shape) for part in parts])
+                    done = torch.cuda.Event()
+                    self.copy_stream.wait_stream(main)
+                    with torch.cuda.stream(self.copy_stream):
+                        for part, host in zip(parts, hosts):
+                            host.copy_(part, non_blocking=True)
+                            part.record_stream(self.copy_stream)
+                        done.record(self.copy_stream)
+                    host_list = hosts[0] if not isinstance(small, list) else hosts
+                    q.put((count, host_list, done))
+                    count += nwin
+        finally:
+            # whatever happened above (a loader raising, a GPU error, out of memory): the writers get their sentinels and
+            # are joined, so nothing blocks in q.get() and what was queued is written and reported
+            for _ in threads:
+                q.put(None)
+            for t in threads:
+                t.join()
         if errors:
             raise errors[0]
         return count - first_index, sum(written), time.perf_counter() - t0

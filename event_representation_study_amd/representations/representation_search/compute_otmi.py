@@ -8,6 +8,7 @@ materialising an n x n matrix."""
 import numpy as np
 
 from ...engine import gwd_padded_l1
+from ... import engine as _engine
 
 
 class OTMI:
@@ -79,3 +80,22 @@ def otmi(events, rep, height, width, rep_size):
     costs = [OTMI(Xs.copy(), Xt.copy(), h=0.7, reg=0.05).solve()[1]
              for Xs, Xt in otmi_point_clouds(events, rep, height, width, rep_size)]
     return np.mean(costs)
+
+
+def otmi_batch(events_list, reps, height, width, rep_size):
+    """otmi() for B samples in one go, entirely on the device (r03): the quadrant clouds are built by
+    evrep_otmi_event_clouds / evrep_otmi_rep_clouds, the 3 B solves are ONE evrep_gwd_padded_l1_batch call, and the only
+    host synchronisation is the final read-back of the B means.  events_list: B raw (n, 4) integer event arrays / tensors;
+    reps: B letterboxed (rep_size, rep_size, C) arrays or cuda tensors (same C).  Returns a float64 array of B scores, each
+    what otmi(events_b, rep_b, height, width, rep_size) returns."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    evs = [np.ascontiguousarray(np.asarray(e.cpu() if hasattr(e, "cpu") else e), dtype=np.int32).reshape(-1, 4) for e in events_list]
+    offs = np.zeros(len(evs) + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in evs], out=offs[1:])
+    events = torch.from_numpy(np.concatenate(evs)).to(dev)
+    rep_t = torch.stack([torch.as_tensor(r).to(dev, torch.float64) for r in reps])[None]   # (1, B, S, S, C)
+    if int(rep_t.shape[2]) != int(rep_size) or int(rep_t.shape[3]) != int(rep_size):
+        raise ValueError("reps must be letterboxed to (rep_size, rep_size, C)")
+    mean, _ = _engine.otmi_batch(events, torch.from_numpy(offs), rep_t, height, width)
+    return mean[0].cpu().numpy()

@@ -20,8 +20,10 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     yi = field_to_int64(y, "y", truncate=True)
     if len(xi) and (xi.min() < 1 or yi.min() < 1):
         raise NotImplementedError("events2ToreFeature: x, y below 1 (numpy negative-index wrap) are not supported")
-    float_time = ts.dtype.kind == "f" and len(ts) and not np.all(ts == np.rint(ts)) or \
-        isinstance(sampleTimes, (float, np.floating)) and float(sampleTimes) != np.rint(float(sampleTimes))
+    # the sample time may arrive as a Python number, a numpy scalar, a 0-d array or a 0-d tensor: normalise first (a
+    # non-integral one handed as a 0-d array must not be truncated by int())
+    st = float(np.asarray(sampleTimes.cpu() if isinstance(sampleTimes, torch.Tensor) else sampleTimes).reshape(()))
+    float_time = bool(ts.dtype.kind == "f" and len(ts) and not np.all(ts == np.rint(ts))) or st != np.rint(st)
     n = len(xi)
     ev = np.empty((n, 4), dtype=np.int32)
     ev[:, 0], ev[:, 1] = int64_to_int32(xi - 1, "x"), int64_to_int32(yi - 1, "y")
@@ -36,10 +38,10 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
         batch = EventBatch.from_numpy(ev, Hf, Wf)
         raise_for_status(batch, what="events2ToreFeature")
         tf = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.float64)).to(batch.device)
-        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, times_f64=tf, sample_times_f64=[float(sampleTimes)])
+        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, times_f64=tf, sample_times_f64=[st])
     else:
         ev[:, 2] = int64_to_int32(field_to_int64(ts, "t"), "t")
         batch = EventBatch.from_numpy(ev, Hf, Wf)
         raise_for_status(batch, what="events2ToreFeature")
-        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(sampleTimes)])
+        rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(st)])
     return rep[0].cpu().numpy()

@@ -234,6 +234,34 @@ size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m);
 int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt,
                         double h, void *scratch, double *cost, void *stream);
 
+/* P solves at once: costs[p] = evrep_gwd_padded_l1 of the pair p, bit for bit, in five launches for ALL pairs (a single
+ * solve is four launches, three of them tiny).  The clouds' sizes are read on the DEVICE, so pairs produced by
+ * evrep_otmi_event_clouds / evrep_otmi_rep_clouds are scored without a host read-back.
+ * Xs DEVICE double: pair p's source cloud = rows [xs_row[p], xs_row[p] + n[p]) of ds columns (xs_row NULL: p * n_cap);
+ * likewise Xt / xt_row / m / dt.  xs_row, n, xt_row, m DEVICE int64 [P].  n_cap, m_cap: upper bounds of n[p], m[p]
+ * (they size the scratch slots; a pair beyond them, or with an empty cloud, costs NaN).  All pairs share ds, dt, h.
+ * scratch DEVICE of evrep_gwd_batch_scratch_bytes; costs DEVICE double [P]. */
+size_t evrep_gwd_batch_scratch_bytes(int32_t P, int32_t ds, int32_t dt, int64_t n_cap, int64_t m_cap);
+int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row, const int64_t *n, int32_t ds,
+                              const double *Xt, const int64_t *xt_row, const int64_t *m, int32_t dt, int64_t n_cap,
+                              int64_t m_cap, double h, void *scratch, double *costs, void *stream);
+
+/* The point clouds of the harness otmi(events, rep, height, width, rep_size)
+ * (representation_search/compute_otmi.py:96-211), built on the device in the reference's own order.
+ * evrep_otmi_event_clouds: events DEVICE int32 [total,4] + offsets DEVICE int64 [B+1] (B windows) -> for window b the
+ *   three scored sensor quadrants (the most populated one is skipped, :134-135; quadrants 2-4 re-origined, :140-147;
+ *   float32 x / ((W-1)//2), y / ((H-1)//2), (t - t0) / (t1 - t0), (p - pmin) / (pmax - pmin), rows with
+ *   x < (W-1)//2 and y < (H-1)//2 kept, :164-173): Xs DEVICE double [B][3][cap][4], n_out DEVICE int64 [B][3],
+ *   quad_out DEVICE int32 [B][3] (which quadrant each slot holds).  cap >= the longest window.
+ * evrep_otmi_rep_clouds: rep DEVICE (items, S, S, C) letterboxed representations, item i belongs to window i % B ->
+ *   for slot k the cut of quadrant quad[i % B][k] (:150-155,177-179), two positional channels (:181-198), rows with
+ *   sum |feat| > 0 (:200-202): Xt DEVICE double [items][3][m_cap][C+2], m_out DEVICE int64 [items][3];
+ *   m_cap >= (S - S/2 + 1)^2. */
+int evrep_otmi_event_clouds(const int32_t *events, const int64_t *offsets, int32_t B, int32_t height, int32_t width,
+                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *stream);
+int evrep_otmi_rep_clouds(const void *rep, int32_t rep_dtype, int32_t items, int32_t B, int32_t S, int32_t C,
+                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *stream);
+
 /* Per-channel resize of a channel-last representation (B,H,W,C) -> (B,Ho,Wo,C), what resize_image /
  * resize_image_process do with cv2.resize per channel before a representation is stored or scored
  * (ev-YOLOv6/yolov6/data/gen4/precompute_reps.py:179-260,424; gen1_2yolo.py:230-265).  The interpolation is given as

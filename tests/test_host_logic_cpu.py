@@ -135,3 +135,27 @@ def test_world_size_2_gloo_gather_of_gwd_scalars():
     assert np.allclose(v0, want) and v0 == v1                # every rank ends with the full vector
     assert w0 == w1 == [float(i) ** 2 for i in range(9)]
     assert abs(cp0 - np.mean(want)) < 1e-12 and cp0 == cp1
+
+
+def test_precompute_parts_of_one_batch_never_share_pinned_storage(monkeypatch):
+    """TORE hands one part per sample when the bounding-box frames differ; more same-shape parts than the
+    ring is deep used to receive the same host buffer inside one batch.  Every batch now cuts its parts out of ONE flat
+    buffer of the ring."""
+    import torch
+    from event_representation_study_amd import precompute
+
+    real_empty = torch.empty
+    monkeypatch.setattr(precompute.torch, "empty", lambda *a, pin_memory=False, **k: real_empty(*a, **k))
+    pc = precompute.RepPrecomputer.__new__(precompute.RepPrecomputer)
+    pc.nwriters, pc._ring, pc._ring_pos = 4, {}, {}
+    shapes = [(37, 640, 12)] * 25 + [(640, 11, 12)] * 3          # more same-shape parts than the ring is deep
+    seen_flat = []
+    for _ in range(3 * (4 + pc.nwriters + 2)):                    # wraps the ring twice
+        views = pc._pinned_parts(shapes)
+        assert [tuple(v.shape) for v in views] == shapes
+        spans = sorted((v.data_ptr(), v.data_ptr() + v.numel() * 4) for v in views)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "parts of one batch overlap"
+        seen_flat.append(views[0].untyped_storage().data_ptr())
+    depth = 4 + pc.nwriters + 2
+    assert len(set(seen_flat[:depth])) == depth                  # consecutive batches get different buffers
+    assert seen_flat[depth:2 * depth] == seen_flat[2 * depth:3 * depth]   # ... recycled round-robin afterwards
