@@ -64,6 +64,7 @@ SYMBOLS = {
     "evrep_est_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _f64, _f64, _vp, _vp]),
     "evrep_read_status": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
     "evrep_read_bbox": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
+    "evrep_copy_window_meta_async": (ctypes.c_int, [_PP, _vp, _vp, _vp]),
     "evrep_gwd_scratch_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "evrep_resize_taps": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
     "evrep_gw_scratch_bytes": (ctypes.c_size_t, [_i64, _i64, _i32]),

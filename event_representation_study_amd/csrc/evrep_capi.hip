@@ -634,6 +634,21 @@ static int read_meta_field(const evrep_plan *plan, const void *workspace, size_t
     return hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 }
 
+int evrep_copy_window_meta_async(const evrep_plan *plan, const void *workspace, void *meta_out, void *stream_) {
+    if (!plan || plan->abi_version != EVREP_ABI_VERSION || !workspace || !meta_out) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const char *meta = static_cast<const char *>(workspace) + plan->off_meta;
+    if (plan->reserved == 2) {  // the key-sorted pass leaves the block statistics unmerged: merge them now
+        char *ws = const_cast<char *>(static_cast<const char *>(workspace));
+        k_window_meta<<<plan->B, kWave, 0, stream>>>(reinterpret_cast<const int64_t *>(ws + plan->off_rowoff),
+                                                     reinterpret_cast<const BlockStats *>(ws + plan->off_stats), plan->nblk, plan->chunk == 4096 ? 12 : 13,
+                                                     reinterpret_cast<WindowMeta *>(ws + plan->off_meta));
+        LAUNCH_CHECK("k_window_meta");
+    }
+    return hip_check(hipMemcpyAsync(meta_out, meta, (size_t)plan->B * sizeof(WindowMeta), hipMemcpyDeviceToHost, stream),
+                     "hipMemcpyAsync(meta)");
+}
+
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream_) {
     if (!plan || !workspace || !status) return EVREP_EINVAL;
     return read_meta_field(plan, workspace, offsetof(WindowMeta, status), sizeof(uint32_t), status,

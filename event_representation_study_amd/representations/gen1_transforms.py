@@ -8,7 +8,7 @@ one fused launch sequence on the GPU (binning pass + builder, the x255 folded in
 """
 import numpy as np
 
-from ._common import raise_for_status, single_batch
+from ._common import finish, sample_batch
 
 STACK_LEVELS = 12      # gen1_transforms.py:35
 VOXEL_BINS = 12        # :22
@@ -32,16 +32,14 @@ def _voxel_grid(events, transform, height, width, num_events):
 
 
 def _optimized(events, transform, height, width, num_events):
-    batch = single_batch(events, height, width, truncate=True, rebase_t=True)   # MDES.stack's own casts (:26-33)
-    raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
-    return batch.optimized(scale=float(SCALE))[0].cpu().numpy()
+    sb = sample_batch(events, height, width, truncate=True, rebase_t=True)   # MDES.stack's own casts (:26-33)
+    return finish(sb, sb.optimized(scale=float(SCALE)), allow_oob=True, what="MixedDensityEventStack")
 
 
 def _event_stack(events, transform, height, width, num_events):
-    batch = single_batch(events, height, width)
+    sb = sample_batch(events, height, width)
     events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34)
-    raise_for_status(batch, what="EventStack")
-    return batch.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE))[0].cpu().numpy()
+    return finish(sb, sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE)), what="EventStack")
 
 
 def _histogram(events, transform, height, width, num_events):
@@ -53,18 +51,16 @@ def _histogram(events, transform, height, width, num_events):
 
 
 def _tore(events, transform, height, width, num_events):
-    batch = single_batch(events, height, width)
-    raise_for_status(batch, what="TORE")
-    # bounding-box frame, origin-shifted, sample time t[-1] (:61-66): frame_mode 0
-    return batch.tore(k=TORE_K, frame_mode=0, scale=float(SCALE))[0].cpu().numpy()
+    sb = sample_batch(events, height, width)
+    # bounding-box frame, origin-shifted, sample time t[-1] (:61-66): frame_mode 0; the box travels with the result
+    return finish(sb, sb.tore_full(k=TORE_K, frame_mode=0, scale=float(SCALE)), what="TORE", tore_k=TORE_K)
 
 
 def _time_surface(events, transform, height, width, num_events):
-    batch = single_batch(events, height, width)
+    sb = sample_batch(events, height, width)
     events["p"] = ((events["p"] + 1) / 2).astype(np.int8)     # (:70-72)
-    raise_for_status(batch, what="ToTimesurface")
     # the six cuts searchsorted(t_norm, 1..6) are taken on the device from the same float64 formula
-    return batch.time_surface(TS_SLICES, float(TS_TAU), premap=True, scale=float(SCALE))[0].cpu().numpy()
+    return finish(sb, sb.time_surface(TS_SLICES, float(TS_TAU), premap=True, scale=float(SCALE)), what="ToTimesurface")
 
 
 # order matters: "MixedDensityEventStack" contains "EventStack" (:27 is tested before :33)

@@ -1,5 +1,5 @@
 """get_optimized_representation -- mirrors representations/optimized_representation.py:86-134."""
-from ._common import raise_for_status, single_batch
+from ._common import finish, sample_batch
 
 N_CHANNELS = 12
 
@@ -9,6 +9,5 @@ def get_optimized_representation(reshaped_return_data, num_events, height, width
     as an (H, W, 12) float64 array."""
     # x, y, p -> int32, t -> int64 and t - t.min(), as MixedDensityEventStack.stack does (:26-33); n_imagenet hands
     # all-float64 fields (imagenet.py:1002-1006)
-    batch = single_batch(reshaped_return_data, height, width, truncate=True, rebase_t=True)
-    raise_for_status(batch, allow_oob=True, what="get_optimized_representation")
-    return batch.optimized(scale=1.0)[0].cpu().numpy()
+    sb = sample_batch(reshaped_return_data, height, width, truncate=True, rebase_t=True)
+    return finish(sb, sb.optimized(scale=1.0), allow_oob=True, what="get_optimized_representation")

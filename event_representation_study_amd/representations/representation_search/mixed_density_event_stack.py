@@ -1,7 +1,7 @@
 """MixedDensityEventStack -- mirrors representation_search/mixed_density_event_stack.py:8-151."""
 import numpy as np
 
-from .._common import raise_for_status, single_batch
+from .._common import finish, sample_batch
 
 
 class MixedDensityEventStack(object):
@@ -19,8 +19,7 @@ class MixedDensityEventStack(object):
         if self.stacking_type != "SBN":
             raise NotImplementedError("only the 'SBN' stacking the reference selects is implemented")
         windows, funcs, aggs = self.indexes_functions_aggregations
-        batch = single_batch(event_sequence, self.height, self.width, truncate=True, rebase_t=True)   # astype + t - t.min(), :26-33
-        raise_for_status(batch, allow_oob=True, what="MixedDensityEventStack")
+        sb = sample_batch(event_sequence, self.height, self.width, truncate=True, rebase_t=True)   # astype + t - t.min(), :26-33
         from ... import _lib
         def window(v):      # anything that cannot index the 7-window list fails the channel (-> zeros)
             ok = isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -7 <= int(v) <= 6
@@ -28,4 +27,4 @@ class MixedDensityEventStack(object):
         w = [window(v) for v in list(windows)[: self.stack_size]]
         f = [v if v in _lib.FUNCS else None for v in list(funcs)[: self.stack_size]]
         a = [v if v in _lib.AGGS else None for v in list(aggs)[: self.stack_size]]
-        return batch.mdes(w, f, a, scale=1.0)[0].cpu().numpy()
+        return finish(sb, sb.mdes(w, f, a, scale=1.0), allow_oob=True, what="MixedDensityEventStack")

@@ -5,7 +5,7 @@ parity is UNPINNED (SURVEY.md section 8(c), rows A2' / A8').  ``str(cls)`` conta
 the dispatcher greps for ("ToVoxelGrid", "ToImage")."""
 import numpy as np
 
-from ._common import raise_for_status, single_batch
+from ._common import finish, sample_batch
 
 
 class ToVoxelGrid:
@@ -21,9 +21,8 @@ class ToVoxelGrid:
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
         if self.n_time_bins > 16:
             raise NotImplementedError("ToVoxelGrid: n_time_bins > 16")
-        batch = single_batch(events, H, W)
-        raise_for_status(batch, what="ToVoxelGrid")
-        return batch.voxel(bins=self.n_time_bins, mode=1, scale=float(scale))[0].cpu().numpy()
+        sb = sample_batch(events, H, W)
+        return finish(sb, sb.voxel(bins=self.n_time_bins, mode=1, scale=float(scale)), what="ToVoxelGrid")
 
     def __call__(self, events):
         # tonic's layout (T, 1, H, W), as a strided view of the builder's (H, W, T) result
@@ -39,9 +38,9 @@ class ToImage:
 
     def __call__(self, events):
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
-        batch = single_batch(events, H, W)
-        raise_for_status(batch, what="ToImage")
+        sb = sample_batch(events, H, W)
         # counts of p == 0 ("count_neg" falls back to p == 0 when no -1 is present) and of p == 1
         import torch
-        rep = batch.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"], dtype=torch.float32)[0]
-        return rep.permute(2, 0, 1).to(torch.int16).contiguous().cpu().numpy()   # counts are exact in float32
+        rep = sb.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"], dtype=torch.float32)
+        frames = rep[0].permute(2, 0, 1).to(torch.int16).contiguous()[None]     # counts are exact in float32
+        return finish(sb, frames, what="ToImage")

@@ -218,6 +218,11 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
 /* Synchronous read-backs (they synchronise `stream`). status: HOST uint32 [B];
  * bbox: HOST int32 [B,4] = xmin, ymin, xmax, ymax of each window's in-frame events. */
 int evrep_read_status(const evrep_plan *plan, const void *workspace, uint32_t *status, void *stream);
+/* The same statistics WITHOUT a synchronisation: B records of 64 bytes {int32 tmin, tmax, xmin, xmax, ymin, ymax; uint32
+ * neg_flags, oob_flags, status; int32 n_valid; 24 bytes reserved} are copied to meta_out (HOST, ideally pinned) behind the
+ * work queued on `stream`; they are valid once the caller has synchronised the stream -- so a per-sample wrapper needs ONE
+ * synchronisation for the status and the result together. */
+int evrep_copy_window_meta_async(const evrep_plan *plan, const void *workspace, void *meta_out, void *stream);
 int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox, void *stream);
 
 /* Placement probe (no reference counterpart): writes zeros over `bytes` of `out` with the write footprint of the float64
