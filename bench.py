@@ -55,6 +55,12 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes (~40 s) that measure roofline.traffic; the value is then "
                          "replayed from profiles/traffic.json and labelled so")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the `sweep` leg (every builder at the reference's Gen1 shape and at configs 2 / 3, build-only "
+                         "fraction of the HBM roof per builder; ~10 s)")
+    ap.add_argument("--no-precompute", action="store_true",
+                    help="skip the `precompute` leg (BASELINE config 5 on this GPU: 1280x720 windows -> (640,640,12) float32 "
+                         "HDF5 files, end-to-end samples/s and GB/s beside the pinned D2H rate of the box; ~8 s)")
     ap.add_argument("--no-gw-extension", action="store_true",
                     help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
     ap.add_argument("--probe-placement", type=int, default=0, metavar="N",
@@ -281,6 +287,63 @@ def gw_extension_leg(device):
             "sinkhorn_GBps": 2 * n * m * 8 / sk / 1e9}
 
 
+def sweep_leg(device):
+    """Every builder at the reference's real Gen1 shape (304x240, 50 000 events, gen1_2yolo.py:41-42,81-82) and at BASELINE
+    configs 2 and 3: binning and build launch timed separately with HIP events (tools/bench_sweep.py), the build launch
+    against the same algorithmic-byte definition as the headline (16 B per event + the output tensor once)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_sweep
+    rows = bench_sweep.sweep(("gen1", "c2", "c3"), iters=10, device=str(device))
+    keep = ("config", "builder", "binning_pass", "bin_ms", "build_ms", "build_GBps", "build_frac_of_8TBps",
+            "events_per_s_bin_plus_build")
+    return {"roofline_bound": "hbm", "peak_GBps": HBM_PEAK_GBPS,
+            "shapes": {k: dict(zip(("W", "H", "events_per_window", "batch"), bench_sweep.CONFIGS[k])) for k in ("gen1", "c2", "c3")},
+            "rows": [{k: r[k] for k in keep} for r in rows]}
+
+
+def precompute_leg(device, samples=512, batch=8, events=200000):
+    """BASELINE config 5 on ONE GPU (tools/precompute_reps.py): a stream of 1280x720 windows -> bin + ERGO-12 + forced
+    (640, 640) area resize on the GPU -> float32 D2H -> one HDF5 file per sample (dataset "repr", precompute_reps.py:432-435)
+    in /dev/shm.  Beside it: the GPU side alone, and the pinned D2H rate of this box for one batch's 157 MB."""
+    import shutil
+    import tempfile
+    from event_representation_study_amd.precompute import RepPrecomputer
+    from event_representation_study_amd.synthetic import make_events
+    Hc, Wc = 720, 1280
+    pool = [make_events(events, Wc, Hc, seed=9000 + i) for i in range(batch)]
+    out_dir = tempfile.mkdtemp(prefix="evrep_c5_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        pc = RepPrecomputer(Hc, Wc, 640, "optimized", device=str(device), writers=12, loaders=3)
+        pc.reserve([(batch, 640, 640, 12)])                                               # the pinned ring, up front
+        pc.run([pool, pool], out_dir, keep_files=False)                                   # warm-up: tap tables, first launches
+        n, nbytes, el = pc.run(([pool[i % batch] for i in range(batch)] for _ in range(samples // batch)), out_dir,
+                               keep_files=False)
+        for _ in range(2):
+            rep = pc.represent(pool)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            rep = pc.represent(pool)
+        torch.cuda.synchronize()
+        gpu_s = (time.perf_counter() - t0) / (10 * batch)
+        host = torch.empty(tuple(rep.shape), dtype=torch.float32, pin_memory=True)
+        host.copy_(rep, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            host.copy_(rep, non_blocking=True)
+        torch.cuda.synchronize()
+        d2h = 10 * host.numel() * 4 / (time.perf_counter() - t0) / 1e9
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    per = 640 * 640 * 12 * 4
+    return {"workload": "%d windows of %d events, 1280x720 -> (640,640,12) float32, one HDF5 file per sample in /dev/shm" % (n, events),
+            "samples_per_s": n / el, "output_GBps": nbytes / el / 1e9, "seconds": el,
+            "gpu_only_us_per_sample": gpu_s * 1e6, "gpu_only_samples_per_s": 1.0 / gpu_s,
+            "pinned_d2h_GBps": d2h, "pcie_gen5_x16_GBps": 63.0, "d2h_bound_samples_per_s": d2h * 1e9 / per,
+            "bytes_per_sample_over_pcie": per}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: run N ranks of this file under
     torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and hand back its exit code."""
@@ -486,6 +549,13 @@ def main():
                 pass
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
+    if rank == 0 and world == 1 and not dry and not args.no_sweep:
+        result["sweep"] = sweep_leg(device)
+    if rank == 0 and world == 1 and not dry and not args.no_precompute:
+        try:
+            result["precompute"] = precompute_leg(device)
+        except Exception as e:      # a full /dev/shm must not cost the bench line
+            result["precompute"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not dry and not args.no_gw_extension:   # single-GPU leg: not part of a scaling run
         result["gw_extension"] = gw_extension_leg(device)
     if not dry and rank == 0 and world == 1 and not args.no_live_traffic and B == BATCH and N == EVENTS_PER_WINDOW:

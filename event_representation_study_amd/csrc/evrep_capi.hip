@@ -30,6 +30,7 @@ static int hip_check(hipError_t e, const char *what) {
     } while (0)
 
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr double kKeySortedMaxPerUnit = 110.0;   // average records per builder unit up to which the key-sorted pass is chosen
 
 template <int NSS, int NST>
 static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
@@ -192,13 +193,16 @@ int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_
     plan->nblk = (int32_t)nblk;
     plan->nchunk = (W + kChunkPx - 1) / kChunkPx;
     plan->reserved = two_kernel ? 1 : 0;
-    // the key-sorted pass (k_block_keysort alone; the builder waves finish the order): sparse windows -- a builder
-    // unit holds <= 30 records on average, so practically every unit is ordered in one 64-lane batch -- on sensors
-    // whose key table fits next to the record stage
+    // the key-sorted pass (k_block_keysort alone; the builder waves finish the order): windows of up to ~110 records per
+    // builder unit on average, on sensors whose key table fits next to the record stage.  Up to ~30 per unit practically
+    // every unit is ordered in one 64-lane batch; up to 128 records a unit is ordered inside LDS in two register batches
+    // (the reference's own Gen1 shape, 304x240 x 50 000 events, holds ~69 per unit: binning 59.5 -> 27.9 us for 32
+    // windows, every builder + 8-11 us, bin + build 15-27 % shorter; 640x480 x 150 000 / 250 000 events likewise,
+    // profiles/r03/sweep_mid_density.txt); beyond, the units spill and the per-key column sort (pass 3) wins
     const int64_t NK = (int64_t)H * plan->nchunk;
     const bool key_sorted = two_kernel && max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk && NK < 65535 &&
                             block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
-                            ((double)max_events_per_window <= 30.0 * (double)NK || f_force_ks) && !f_classic && !f_three;
+                            ((double)max_events_per_window <= kKeySortedMaxPerUnit * (double)NK || f_force_ks) && !f_classic && !f_three;
     // dense windows on the same sensors: k_block_keysort + the column sort run per KEY (k_col_sort_runs, by_key),
     // then the classic builders on the pixel-sorted stream
     const bool key_dense = !key_sorted && two_kernel && NK < 65535 &&
@@ -371,7 +375,9 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     UnitCfg uc;
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
     uc.span = (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) ? 1 : (per_chunk <= 30.0 ? 2 : 1);  // a 128-pixel chunk of >= 8 KB stays alone
-    uc.stage = (uc.span + extra_chunks > 1) ? 128 : 64;
+    // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
+    // in two register batches: a 128-record stage
+    uc.stage = (uc.span + extra_chunks > 1 || per_chunk > 28.0) ? 128 : 64;
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     return uc;

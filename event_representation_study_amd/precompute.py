@@ -112,6 +112,13 @@ class RepPrecomputer:
             o += n
         return views
 
+    def reserve(self, shapes):
+        """Fill the pinned ring up front for batches of these part shapes (page-locking ~150 MB per buffer costs tens of
+        milliseconds each: a short run would otherwise spend most of its time in it)."""
+        depth = 4 + self.nwriters + 2
+        while len(self._ring.get("flat", [])) < depth:
+            self._pinned_parts(shapes)
+
     def _write(self, path_base, arr):
         if self.container == "h5":
             h5lite.write_dataset_file(path_base + ".h5", "repr", arr)   # fh.create_dataset("repr", ..., dtype="f4")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-builder timings at BASELINE.json configs 2 and 3 (not the driver's bench line; see bench.py).
+"""Per-builder timings at the reference's real Gen1 shape and at BASELINE.json configs 2 and 3 (bench.py runs a short form
+of this as its `sweep` leg).
 
 For every (builder, geometry, events/window, batch) it times the binning pass and the builder launch
 separately with HIP events and prints one JSON object per line: algorithmic bytes per launch
@@ -15,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from event_representation_study_amd.engine import EventBatch, probe_output_placement  # noqa: E402
+from event_representation_study_amd.engine import EventBatch  # noqa: E402
 from event_representation_study_amd.synthetic import make_events  # noqa: E402
 
 
@@ -31,17 +32,25 @@ def timed(fn, iters):
     return a.elapsed_time(b) / iters
 
 
-def main():
-    configs = [
-        ("c2", 640, 480, 50000, 32), ("c2-dense", 640, 480, 500000, 8),
-        ("c3", 1280, 720, 200000, 8), ("c3-1M", 1280, 720, 1000000, 4),
-    ]
-    for tag, W, H, N, B in configs:
+CONFIGS = {
+    "gen1": (304, 240, 50000, 32),        # the reference's real Gen1 shape (gen1_2yolo.py:41-42,81-82)
+    "c2": (640, 480, 50000, 32), "c2-150k": (640, 480, 150000, 16), "c2-250k": (640, 480, 250000, 8),
+    "c2-dense": (640, 480, 500000, 8),
+    "c3": (1280, 720, 200000, 8), "c3-1M": (1280, 720, 1000000, 4),
+}
+HBM_PEAK_GBPS = 8000.0
+
+
+def sweep(tags=("gen1", "c2", "c2-dense", "c3", "c3-1M"), iters=20, builders=None, device="cuda:0"):
+    """Rows of the sweep as dicts (bench.py's `sweep` leg calls this with fewer iterations)."""
+    rows = []
+    for tag in tags:
+        W, H, N, B = CONFIGS[tag]
         wins = [make_events(N, W, H, seed=7000 + i) for i in range(B)]
-        eb = EventBatch.from_numpy(wins, H, W)
-        t_bin = timed(lambda: eb.rebin(), 20)
-        tnorm = torch.rand(eb.total, dtype=torch.float64, device="cuda:0")  # one normalised time per event
-        builders = {
+        eb = EventBatch.from_numpy(wins, H, W, device=device)
+        t_bin = timed(lambda: eb.rebin(), iters)
+        tnorm = torch.rand(eb.total, dtype=torch.float64, device=device)  # one normalised time per event
+        table = {
             "optimized_f64": (lambda o: eb.optimized(out=o), 12, torch.float64),
             "optimized_f32": (lambda o: eb.optimized(dtype=torch.float32, out=o), 12, torch.float32),
             "event_stack_f32": (lambda o: eb.event_stack(out=o), 12, torch.float32),
@@ -52,24 +61,28 @@ def main():
             "nimagenet_acc_all_f32": (lambda o: eb.polstats(tnorm, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2], out=o),
                                       6, torch.float32),
         }
-        for name, (fn, C, dt) in builders.items():
-            # float64 outputs of ~1 GB are placement-sensitive: like bench.py, take the fastest of a few
-            # candidate allocations; the narrower outputs are indifferent
-            if dt == torch.float64 and B * H * W * C * 8 >= (512 << 20):
-                out, _, cand = probe_output_placement((B, H, W, C), dt, candidates=12)
-            else:
-                out, cand = torch.empty((B, H, W, C), dtype=dt, device="cuda:0"), None
-            ms = timed(lambda: fn(out), 20)
+        for name, (fn, C, dt) in table.items():
+            if builders is not None and name not in builders:
+                continue
+            out = torch.empty((B, H, W, C), dtype=dt, device=device)   # the first allocation, as any caller gets it (r03)
+            ms = timed(lambda: fn(out), iters)
             elem = out.element_size()
             alg = B * (16 * N + elem * H * W * C)
-            print(json.dumps({"config": tag, "W": W, "H": H, "events_per_window": N, "batch": B, "builder": name,
-                              "bin_ms": round(t_bin, 4), "build_ms": round(ms, 4),
-                              "algorithmic_bytes": alg, "build_GBps": round(alg / ms / 1e6, 1),
-                              "events_per_s_bin_plus_build": round(B * N / ((t_bin + ms) * 1e-3)),
-                              "placement_probe_us": [round(x, 1) for x in cand] if cand else None}))
+            rows.append({"config": tag, "W": W, "H": H, "events_per_window": N, "batch": B, "builder": name,
+                         "binning_pass": int(eb.plan.reserved), "bin_ms": round(t_bin, 4), "build_ms": round(ms, 4),
+                         "algorithmic_bytes": alg, "build_GBps": round(alg / ms / 1e6, 1),
+                         "build_frac_of_8TBps": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 3),
+                         "events_per_s_bin_plus_build": round(B * N / ((t_bin + ms) * 1e-3))})
             del out
         del eb
         torch.cuda.empty_cache()
+    return rows
+
+
+def main():
+    tags = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
+    for row in sweep(tags):
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
