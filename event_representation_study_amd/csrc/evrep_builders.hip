@@ -233,6 +233,10 @@ struct UnitRecs {
     uint32_t cs, ce;
     int nstaged;
     Rec r0;
+    // key-sorted single-batch units (r03): the front end has already grouped the records by pixel and listed the segments
+    // (w.segs holds nseg entries + the sentinel); record `lane` (r0) belongs at stage position `pos` -- emit_chunk stages
+    // its DIGEST there directly.  nseg < 0: not grouped (the segment heads are found from the staged pixel ids).
+    int nseg, pos;
 };
 
 // inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts), no LDS crossbar
@@ -288,11 +292,12 @@ __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &c
 //     no atomics, idempotent across builders), then read back like the classic stream.
 template <typename OutT>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
-                                        int keybase, int npixu, WaveLds<OutT> &w) {
+                                        int keybase, int npixu, WaveLds<OutT> &w, int segbase) {
     const int lane = threadIdx.x;
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
+    u.nseg = -1; u.pos = lane;
     if (khi <= klo) return u;
     // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
     // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
@@ -378,27 +383,50 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
         u.ce = nrec;
         u.nstaged = (int)nrec;
-        if (nrec == 1) { if (lane == 0) w.evbuf[0] = r; u.r0 = r; return u; }
         const uint32_t px = v0 ? (uint32_t)(r.x - keybase) : 0u;
         if (!two) {
-            // one batch: the records only have to be GROUPED by pixel, in time order inside a pixel -- emit_core gives a
-            // unit of <= 64 segments one lane per segment whatever their order.  The ballot match yields every record's
-            // group (the lanes holding its pixel); a group's place = the sizes of the groups whose first lane comes
-            // earlier (one DPP scan over the first lanes, fetched by the others through the LDS crossbar).  No counters.
-            uint64_t mask = __ballot(v0);
-            for (int bit = 0; bit < nbits; ++bit) {
-                const bool on = (px >> bit) & 1u;
-                const uint64_t bal = __ballot(on);
-                mask &= on ? bal : ~bal;
-            }
-            const uint32_t rk = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            const uint32_t size = (v0 && rk == 0u) ? (uint32_t)__popcll(mask) : 0u;
-            const uint32_t goff = wave_incl_scan(size) - size;
-            const int first = v0 ? (int)__builtin_ctzll(mask) : lane;
-            const uint32_t pos = (uint32_t)__shfl((int)goff, first, 64) + rk;
-            if (v0) w.evbuf[pos] = r;
+            // one batch: the records only have to be GROUPED by pixel, in time order inside a pixel (the lanes already are
+            // in time order: runs are visited in block = time order and are time-ordered inside a key).  r03: a leader
+            // election per pixel in LDS instead of a 7-bit ballot match (56 VALU instructions): in round k the lowest
+            // unassigned lane of every pixel wins `slot[pixel]` (ds_min), takes rank k and clears the slot; a pixel is
+            // done after as many rounds as it holds records -- one or two on sparse windows.  The winners keep the pixel's
+            // record count and first lane in `info[pixel]`; the groups' places in the stage are the prefix sums of the
+            // counts over the first lanes; the segment list emit_core wants falls out of the same numbers, so the
+            // segment-head search over the staged records is skipped, and the records go to the stage ONCE, digested
+            // (emit_chunk), instead of raw -> read back -> digested -> written again.
+            uint32_t *slot = cnt;                       // [npixu]
+            unsigned char *info = reinterpret_cast<unsigned char *>(cnt + npixu);   // [npixu][4]: count, first lane, place
+            for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
             wave_phase();
-            if (v0) r = w.evbuf[lane];
+            bool un = v0;
+            uint32_t rk = 0;
+            for (uint32_t round = 0; __any(un); ++round) {
+                if (un) atomicMin(&slot[px], (uint32_t)lane);
+                wave_phase();
+                const bool lead = un && slot[px] == (uint32_t)lane;
+                wave_phase();
+                if (lead) {
+                    slot[px] = ~0u;
+                    rk = round;
+                    info[4 * px] = (unsigned char)(round + 1);
+                    if (round == 0) info[4 * px + 1] = (unsigned char)lane;
+                    un = false;
+                }
+                wave_phase();
+            }
+            const bool first = v0 && rk == 0u;
+            const uint32_t size = first ? (uint32_t)info[4 * px] : 0u;
+            const uint32_t goff = wave_incl_scan(size) - size;
+            if (first) info[4 * px + 2] = (unsigned char)goff;
+            const uint64_t fm = __ballot(first);
+            const int nseg = __popcll(fm);
+            const int gidx = __popcll(fm & ((1ull << lane) - 1ull));
+            wave_phase();
+            u.pos = v0 ? (int)((uint32_t)info[4 * px + 2] + rk) : lane;
+            wave_phase();     // info is read: the segment list may take its place
+            if (first) w.segs[gidx] = make_uint2((uint32_t)(r.x - segbase), goff);   // relative to the builder's own origin
+            if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
+            u.nseg = nseg;
             u.r0 = r;
             return u;
         }
@@ -503,7 +531,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     g = unit_geom(H, W, nchunk, span, chunk);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = g.row * nchunk + min(chunk + span, nchunk);
-        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w);
+        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -513,6 +541,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     UnitRecs u;
     u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
+    u.nseg = -1; u.pos = (int)threadIdx.x;
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
     return u;
 }
@@ -627,9 +656,11 @@ __device__ inline void sparse_store(const OutT *vlist, const unsigned char *map,
 // `post_heads()` runs once the segment heads are listed (the stage may then be rewritten).
 // `get_staged(j)` = get(j) for a unit whose records are all staged in LDS (every unit of <= 64 records): no second source,
 // so the segment walks read LDS with ds_read instead of flat loads through a two-address-space pointer.
+// `nseg_pre` >= 0: the front end has listed the segments already (UnitRecs::nseg).
 template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename RecStaged, typename PostHeads, typename Reduce>
-__device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, RecStaged get_staged, PostHeads post_heads, int key0,
-                                 int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+__device__ inline void emit_core(uint32_t nrec, int nseg_pre, KeyAt key_at, RecAt get, RecStaged get_staged, PostHeads post_heads,
+                                 int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg,
+                                 Reduce reduce) {
     const int lane = threadIdx.x;
     const int PP = w.partpx;  // pixels per part tile (wave-uniform)
     constexpr int V = 16 / (int)sizeof(OutT);
@@ -661,7 +692,9 @@ __device__ inline void emit_core(uint32_t nrec, KeyAt key_at, RecAt get, RecStag
     }
     // segment heads = runs of equal pixel id among the sorted records
     int nseg = 0;
-    {
+    if (nseg_pre >= 0) {
+        nseg = nseg_pre;
+    } else {
         int carry = INT32_MIN;
         for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
             const uint32_t j = j0 + lane;
@@ -791,7 +824,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     const Rec r0 = u.r0;
     const Rec *__restrict__ sorted = u.sorted;
     Rec *evbuf = w.evbuf;
-    if (lane < (int)nrec) evbuf[lane] = digest(r0);
+    if (lane < (int)nrec) evbuf[u.nseg >= 0 ? u.pos : lane] = digest(r0);   // grouped units: straight to the record's place
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nraw ? evbuf[j].x : sorted[cs + j].x); };
     auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest_fly(sorted[cs + j]); };
@@ -802,7 +835,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
             wave_phase();
         }
     };
-    emit_core<OutT, CMAX>(nrec, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
+    emit_core<OutT, CMAX>(nrec, u.nseg, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
 }
 template <typename OutT, int CMAX, typename Digest, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
@@ -1284,11 +1317,12 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
     UnitRecs ur;
     ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
     ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
+    ur.nseg = -1; ur.pos = (int)threadIdx.x;
     if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
         if (bv.fused) {
             ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
-                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w);
+                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo);
         } else {
             const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
             ur.cs = co[ch_lo];
