@@ -223,3 +223,42 @@ def test_step_is_graph_capturable(eng):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_two_plans_two_streams_two_host_threads(eng, oracle):
+    """include/evrep.h: "no global state ... any number of host threads may drive any number of devices and streams".
+    Two host threads, each with its own plan / workspace / HIP stream, run bin + build concurrently (ctypes drops the GIL
+    inside the C calls); every result equals the oracle bit for bit.  Different sensors, so the two plans differ in every
+    derived field (pass, block geometry, workspace layout)."""
+    import threading
+    import torch
+    from event_representation_study_amd.synthetic import make_events
+    jobs = [(480, 640, 50000, 11), (240, 304, 20000, 12)]
+    want = [oracle.ergo12(make_events(n, w, h, seed=s), h, w) for h, w, n, s in jobs]
+    errors, results = [], [None, None]
+
+    def work(k):
+        try:
+            h, w, n, s = jobs[k]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ev = make_events(n, w, h, seed=s)
+                batch = eng.EventBatch.from_numpy([ev, ev], h, w)
+                out = None
+                for _ in range(50):
+                    batch.rebin()
+                    out = batch.optimized(out=out)
+                stream.synchronize()
+                results[k] = out.cpu().numpy()
+        except Exception as e:          # surfaced below: a thread's exception must fail the test
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for b in range(2):
+            assert np.array_equal(results[k][b], want[k])
