@@ -739,7 +739,7 @@ __host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / 
 __host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
 __host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_words(W) + 2 * kCsMaxRuns; }   // + the run table (pre, src)
 
-__global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const int4 *__restrict__ ev, const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
                                                                      int nchunk, int kpr, int chunk_shift, int by_key,
@@ -827,6 +827,12 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
         runs[kCsMaxRuns + kWave + lane] = src1;
         wave_phase_lds();
     }
+    // the runs of k_block_keysort hold 8-byte records (Rec8): the wave's key supplies row and chunk
+    const Rec8 *sorted8 = reinterpret_cast<const Rec8 *>(sorted1);
+    const int4 *evw = ev + beg;
+    auto load = [&](uint32_t at) -> Rec {
+        return by_key ? rec8_unpack(sorted8[at], row * W, ck * kChunkPx, evw) : sorted1[at];
+    };
     auto fetch = [&](uint32_t j) -> Rec {
         if (nb <= kBsChainBlocks) {
             uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
                 s += (j >= pk) ? sk - prev : 0u;
                 prev = sk;
             }
-            return sorted1[s + j];
+            return load(s + j);
         }
         uint32_t lo = 0, hi = (uint32_t)nb;
 #pragma unroll
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
             const bool go = hi - lo > 1 && runs[mid] <= j;
             if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
         }
-        return sorted1[runs[kCsMaxRuns + lo] + j];
+        return load(runs[kCsMaxRuns + lo] + j);
     };
     Rec e[4];
 #pragma unroll
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) void k_col_sort_runs(const Rec *_
 #define KS_DEBUG 0  // timing experiments only (tools/experiments): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
 #endif
 __host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int chunk) {
-    return (size_t)cap * sizeof(Rec) + (size_t)chunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
+    return (size_t)cap * sizeof(Rec8) + (size_t)chunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
 }
 
 // grid (8 * ceil(B/8) * nblk), TPB threads = TPB * 8 events per workgroup (1024 -> 8192, 512 -> 4096: windows of up to
@@ -948,15 +954,25 @@ __host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int c
 // groups to repair), dynamic LDS = block_keysort_lds_bytes(H * kpr, cap, TPB * 8); cap = records the stage holds
 // (the block is written out in rounds of cap records).
 // table: [B][nblk][H * kpr + 1] exclusive offsets of the block's keys inside its run (last entry = in-frame events).
+// Occupancy asked of the compiler (r03): the kernel is a chain of barrier-separated latencies, so a second resident
+// workgroup per CU fills them.  1024-thread instance (dense windows): 8 waves per SIMD = TWO workgroups per CU (64 VGPRs,
+// 36 bytes of scratch; left alone the compiler takes 114 VGPRs = one workgroup per CU): binning of 4 x 10^6-event 1280x720
+// windows 145 -> 123 us, of 8 x 500 000-event 640x480 windows 91 -> 80 us.  512-thread instance: 6 (80 VGPRs, no scratch).
+#ifndef KS_WAVES_512
+#define KS_WAVES_512 6
+#endif
+#ifndef KS_WAVES_1024
+#define KS_WAVES_1024 8
+#endif
 template <int TPB>
-__global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024 ? KS_WAVES_1024 : KS_WAVES_512))) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int kpr, int nblk, int cap,
                                                              uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
                                                              Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int kChunk = TPB * kBsPerLane, kNW = TPB / kWave, kPerWave = kBsPerLane * kWave;
     const int NK = H * kpr;
-    Rec *stage = reinterpret_cast<Rec *>(smem_raw);                         // [cap], output order
+    Rec8 *stage = reinterpret_cast<Rec8 *>(smem_raw);                       // [cap], output order, 8-byte records
     uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kChunk] rank inside the block, arrival order
     uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kChunk);        // [NK + 1] counts -> exclusive offsets
     __shared__ int bstats[12];  // the block's statistics, merged by one LDS atomic per wave and field (BlockStats order)
@@ -1111,14 +1127,17 @@ __global__ __launch_bounds__(TPB) void k_block_keysort(const int4 *__restrict__ 
         for (int i = 0; i < kBsPerLane; ++i)
             if (ko[i] != 0xffffffffu) ko[i] = gb[i] + sm[i];
     }
-    Rec *dst = sorted1 + beg + lo;
+    Rec8 *dst = reinterpret_cast<Rec8 *>(sorted1) + beg + lo;   // the block's own slot, 8 bytes per record
     for (uint32_t pb = 0; pb < total && !(KS_DEBUG & 2); pb += (uint32_t)cap) {
         if (pb) __syncthreads();  // the previous round has left the stage
 #pragma unroll
         for (int i = 0; i < kBsPerLane; ++i) {
             const uint32_t pos = ko[i] - pb;  // 0xffffffff - pb >= cap for every pb < 8192
-            if (pos < (uint32_t)cap)  // placed records are in frame: x + y*W is their 32-bit pixel id
-                stage[pos] = make_int4(e[i].x + e[i].y * W, lo32 + w0 + i * kWave + lane, e[i].z, e[i].w);
+            if (pos < (uint32_t)cap) {  // placed records are in frame: their column is x, or (x + y*W) mod W for an x >= W
+                int col = e[i].x;
+                if ((uint32_t)col >= (uint32_t)W) { const uint32_t key = (uint32_t)(e[i].x + e[i].y * W); col = (int)(key % (uint32_t)W); }
+                stage[pos] = rec8_pack(col, lo32 + w0 + i * kWave + lane, e[i].z, e[i].w);
+            }
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)cap, total - pb);

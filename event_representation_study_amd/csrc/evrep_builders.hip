@@ -214,7 +214,8 @@ struct ChunkGeom {
 // Key-sorted (fused == 1, k_block_keysort): the window's block runs, ordered by (row, 128-pixel chunk) only, and
 // their offset tables; the builder wave gathers its unit's records and orders them by pixel itself (unit_records).
 struct BinView {
-    const Rec *sorted;          // classic: sorted2; key-sorted: sorted1 (block runs)
+    const int4 *ev;             // the caller's events (key-sorted pass: only read for escaped polarity values, see Rec8)
+    const Rec *sorted;          // classic: sorted2 (16-byte records); key-sorted: sorted1 = the block runs, 8-byte records (Rec8)
     const uint32_t *chunk_off;  // classic only
     const uint32_t *table;      // key-sorted: [B][nblk][H * nchunk + 1]
     const BlockStats *stats;    // key-sorted: [B][nblk]
@@ -290,9 +291,10 @@ __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &c
 //   * more: the same counting sort in batches of 64, written to the unit's own slot of the spill stream (its
 //     position = records of the window with a smaller key = sum over the runs of table[k][klo]: disjoint slots,
 //     no atomics, idempotent across builders), then read back like the classic stream.
+// c0 = first sensor column of the unit (keybase = row * W + c0): what the 8-byte records are decoded against.
 template <typename OutT>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
-                                        int keybase, int npixu, WaveLds<OutT> &w, int segbase) {
+                                        int keybase, int npixu, WaveLds<OutT> &w, int segbase, int c0) {
     const int lane = threadIdx.x;
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
@@ -327,7 +329,10 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         runs[64 + lane] = src;
         wave_phase();
     }
-    const Rec *__restrict__ s1 = bv.sorted;
+    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+    const int4 *evw = bv.ev + beg;
+    const int row_base = keybase - c0;
+    auto s1_at = [&](uint32_t at) -> Rec { return rec8_unpack(s8[at], row_base, c0, evw); };
     auto fetch = [&](uint32_t j) -> Rec {
         if (nb <= kBsChainBlocks) {
             uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
@@ -338,7 +343,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                 s += (j >= pk) ? sk - prev : 0u;
                 prev = sk;
             }
-            return s1[s + j];
+            return s1_at(s + j);
         }
         uint32_t lo = 0, hi = (uint32_t)nb;
 #pragma unroll
@@ -347,7 +352,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             const bool go = hi - lo > 1 && runs[mid] <= j;
             if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
         }
-        return s1[runs[64 + lo] + j];
+        return s1_at(runs[64 + lo] + j);
     };
     uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);  // npixu <= segcap counters: the segment list is built later
     const int nbits = 32 - __builtin_clz((unsigned)npixu - 1u);  // npixu >= 128
@@ -373,11 +378,11 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             if (lane < nb && len > 0u && pre < (uint32_t)nstage) head[pre] = (uint32_t)lane;
             wave_phase();
             const uint32_t k0 = wave_incl_max_scan(head[lane]);
-            if (v0) r = s1[srcs[k0] + (uint32_t)lane];
+            if (v0) r = s1_at(srcs[k0] + (uint32_t)lane);
             if (two) {
                 const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k0, 63);
                 const uint32_t k1 = max(carry, wave_incl_max_scan(head[lane + kWave]));
-                if (v1) r1 = s1[srcs[k1] + (uint32_t)(lane + kWave)];
+                if (v1) r1 = s1_at(srcs[k1] + (uint32_t)(lane + kWave));
             }
             wave_phase();   // srcs lives in evbuf: read before the placement below writes it
         }
@@ -531,7 +536,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     g = unit_geom(H, W, nchunk, span, chunk);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = g.row * nchunk + min(chunk + span, nchunk);
-        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0);
+        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0, g.c0);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -1322,7 +1327,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
         if (bv.fused) {
             ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
-                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo);
+                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx);
         } else {
             const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
             ur.cs = co[ch_lo];

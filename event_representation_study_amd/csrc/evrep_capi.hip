@@ -253,11 +253,11 @@ static int check_common(const evrep_plan *plan, const void *events, const void *
 #define CWS(type, field) reinterpret_cast<const type *>(static_cast<const char *>(workspace) + plan->field)
 
 // The pixel-sorted stream + chunk offsets + WindowMeta from the runs of k_block_keysort: the column sort, one wave per key.
-static int column_sort_keys(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
+static int column_sort_keys(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, hipStream_t stream) {
     const int NK = plan->H * plan->nchunk;
     k_col_sort_runs<<<dim3((NK + kCsWaves - 1) / kCsWaves, plan->B), kCsWaves * kWave,
                                       (size_t)kCsWaves * col_sort_wave_words(kChunkPx) * 4, stream>>>(
-        CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
+        reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted1), offsets, CWS(uint32_t, off_table), CWS(BlockStats, off_stats), plan->H, plan->W, plan->nblk,
         plan->nchunk, plan->nchunk, plan->chunk == 4096 ? 12 : 13, 1, WS(Rec, off_sorted2), WS(uint32_t, off_chunkoff),
         WS(WindowMeta, off_meta));
     LAUNCH_CHECK("k_col_sort_runs");
@@ -289,19 +289,24 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
                              "hipFuncSetAttribute(k_block_keysort)");
         };
         if (chunk == 4096) {
-            // a 2048-record stage (two rounds) keeps the workgroup under 53 KB where the key table allows: three per CU
-            const int cap = block_keysort_lds_bytes(NK, 2048, 4096) <= 52 * 1024 ? 2048 : 4096;
+            // the whole block in one round where that keeps the workgroup under 53 KB (three per CU; 8-byte records: 32 KB of
+            // stage), else a 2048-record stage in two rounds if THAT does, else one round
+            const int cap = block_keysort_lds_bytes(NK, 4096, 4096) <= 52 * 1024 ? 4096
+                            : (block_keysort_lds_bytes(NK, 2048, 4096) <= 52 * 1024 ? 2048 : 4096);
             if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<512>), block_keysort_lds_bytes(NK, cap, 4096))) return rc2;
             k_block_keysort<512><<<xgrid, 512, block_keysort_lds_bytes(NK, cap, 4096), stream>>>(
                 ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
         } else {
-            const int cap = block_keysort_lds_bytes(NK, kBsChunk, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096;
+            // two workgroups per CU (<= 79 KB each) beat one with a one-round stage: the kernel is a chain of barrier-separated
+            // latencies, a second resident workgroup fills them
+            const int cap = block_keysort_lds_bytes(NK, 4096, kBsChunk) <= 79 * 1024 ? 4096
+                            : (block_keysort_lds_bytes(NK, kBsChunk, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096);
             if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<1024>), block_keysort_lds_bytes(NK, cap, kBsChunk))) return rc2;
             k_block_keysort<1024><<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap, kBsChunk), stream>>>(
                 ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
         }
         LAUNCH_CHECK("k_block_keysort");
-        if (plan->reserved == 3) return column_sort_keys(plan, offsets, workspace, stream);
+        if (plan->reserved == 3) return column_sort_keys(plan, events, offsets, workspace, stream);
         return EVREP_OK;
     }
     if (plan->reserved == 1) {
@@ -318,7 +323,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
         constexpr int rows_per_wg = kCsWaves;
         k_col_sort_runs<<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
-            s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, 0, s2, WS(uint32_t, off_chunkoff), meta);
+            ev, s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, 0, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;
     }
@@ -343,8 +348,9 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
 #define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
 
 // what the builders read of the binning pass (see BinView in evrep_builders.hip)
-static BinView bin_view(const evrep_plan *plan, void *workspace) {
+static BinView bin_view(const evrep_plan *plan, const int32_t *events, void *workspace) {
     BinView bv;
+    bv.ev = reinterpret_cast<const int4 *>(events);
     bv.fused = plan->reserved == 2 ? 1 : 0;
     bv.sorted = bv.fused ? CWS(Rec, off_sorted1) : CWS(Rec, off_sorted2);
     bv.chunk_off = CWS(uint32_t, off_chunkoff);
@@ -362,9 +368,9 @@ static BinView bin_view(const evrep_plan *plan, void *workspace) {
 
 // After the key-sorted pass: the pixel-sorted stream + chunk offsets + WindowMeta, for the consumers that walk
 // them directly (k_voxel_subpixel).  The column sort of the two-kernel pass, reading a row's runs chunk by chunk.
-static int ensure_column_sorted(const evrep_plan *plan, const int64_t *offsets, void *workspace, hipStream_t stream) {
+static int ensure_column_sorted(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, hipStream_t stream) {
     if (plan->reserved != 2) return EVREP_OK;
-    return column_sort_keys(plan, offsets, workspace, stream);
+    return column_sort_keys(plan, events, offsets, workspace, stream);
 }
 
 // The unit of one builder wave.  span = 128-pixel chunks it takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on
@@ -428,7 +434,7 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
     do {                                                                                                              \
         const size_t lds_ = chunk_lds_bytes(C, sizeof(T), span * kChunkPx, uc.stage, uc.partpx);                       \
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T)); \
-        k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, workspace), offsets, P, plan->H, plan->W,   \
+        k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
@@ -466,7 +472,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     const int span = uc.span;
 #define ES_LAUNCH(CM)                                                                                              \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
-        bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out)
+        bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out)
     if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
 #undef ES_LAUNCH
     LAUNCH_CHECK("k_event_stack");
@@ -490,7 +496,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
     k_time_surface<T, CM, F><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(            \
-        bin_view(plan, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
+        bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
         static_cast<T *>(out))
 #define TS_LAUNCH(T, CM, GRID, SEG) do { if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG); } while (0)
         if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
@@ -522,7 +528,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     const int span = uc.span;
 #define TORE_LAUNCH(CM)                                                                                             \
     k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
-        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, sample_times, tf, sample_times_f,    \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out)
     if (k <= 6) TORE_LAUNCH(12); else TORE_LAUNCH(16);
 #undef TORE_LAUNCH
@@ -546,7 +552,7 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     const int span = uc.span;
 #define VOXEL_LAUNCH(CM)                                                                                         \
     k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(              \
-        reinterpret_cast<const int4 *>(events), bin_view(plan, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
         bins, mode, scale, t_range, out)
     if (bins <= 8) VOXEL_LAUNCH(8); else VOXEL_LAUNCH(16);
 #undef VOXEL_LAUNCH
@@ -561,7 +567,7 @@ int evrep_voxel_subpixel(const evrep_plan *plan, const int32_t *events, const in
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || !out || (plan->total_events > 0 && !xy)) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const dim3 grid((unsigned)(((size_t)plan->H * plan->W + kThreads - 1) / kThreads), (unsigned)plan->B);
-    rc = ensure_column_sorted(plan, offsets, workspace, stream);
+    rc = ensure_column_sorted(plan, events, offsets, workspace, stream);
     if (rc) return rc;
     k_voxel_subpixel<<<grid, kThreads, 0, stream>>>(reinterpret_cast<const int4 *>(events), CWS(Rec, off_sorted2),
                                                    CWS(uint32_t, off_chunkoff), offsets, xy, plan->H, plan->W, plan->nchunk,
@@ -592,10 +598,10 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     const int span = uc.span;
     if (C <= 8)
         k_polstats<8><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(
-            bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
+            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
     else
         k_polstats<16><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(
-            bin_view(plan, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
+            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
     LAUNCH_CHECK("k_polstats");
     return EVREP_OK;
 }
@@ -616,7 +622,7 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * C * 4);
     const int span = uc.span;
     k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, uc.stage), stream>>>(
-        bin_view(plan, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
+        bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, uc, out);
     LAUNCH_CHECK("k_est");
     return EVREP_OK;

@@ -29,6 +29,29 @@ static_assert(sizeof(WindowMeta) == 64, "WindowMeta is one 64-byte line");
 //   z = t (raw int32 timestamp), w = p (raw polarity)
 using Rec = int4;
 
+// The key-sorted passes (plan->reserved 2 and 3) move 8-byte records (r03): the run position of a record already names its
+// key = (sensor row, 128-pixel chunk), so a record only carries
+//   x = t (raw int32 timestamp),   y = column mod 512 | (p + 1) << 9 | rank << 11
+// -- 9 column bits resolve any unit of up to four chunks (a builder unit spans at most three: TORE's shifted frame), 21
+// rank bits cover the 1 048 576-event windows these passes serve, and the two polarity bits hold {-1, 0, 1}; any other
+// polarity value is escaped (3) and re-read from the caller's event row `rank`.  Half the bytes k_block_keysort writes and
+// every builder wave / the per-key column sort reads.
+using Rec8 = uint2;
+__device__ inline Rec8 rec8_pack(int col, int rank, int t, int p) {
+    const uint32_t p2 = (uint32_t)(p + 1) <= 2u ? (uint32_t)(p + 1) : 3u;
+    return make_uint2((uint32_t)t, ((uint32_t)col & 511u) | (p2 << 9) | ((uint32_t)rank << 11));
+}
+// row_base = row * W, base_col = first column of the unit that owns the record, ev_win = the window's events
+__device__ inline Rec rec8_unpack(const Rec8 q, int row_base, int base_col, const int4 *__restrict__ ev_win) {
+    const uint32_t w = q.y;
+    const int col = base_col + (int)(((w & 511u) - (uint32_t)base_col) & 511u);
+    const int rank = (int)(w >> 11);
+    const uint32_t p2 = (w >> 9) & 3u;
+    int p = (int)p2 - 1;
+    if (p2 == 3u) p = ev_win[rank].w;
+    return make_int4(row_base + col, rank, (int)q.x, p);
+}
+
 // The 7 "SBN" windows of MixedDensityEventStack.create_windows
 // (representation_search/mixed_density_event_stack.py:48-74) as [lo, hi) rank ranges.
 struct MdesWindows {
