@@ -406,7 +406,7 @@ static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_byte
     }
     const int nunit = (plan->nchunk + span - 1) / span;
     const double unit_bytes = (double)plan->W * (double)pixel_bytes / (double)nunit;   // a row's bytes over its units
-    const double ticks = 710.0 * ((double)waves * unit_bytes) / (19.0 * 12288.0);
+    const double ticks = 690.0 * ((double)waves * unit_bytes) / (19.0 * 12288.0);
     return ticks < 50.0 ? 0 : (int)(ticks + 0.5);
 }
 

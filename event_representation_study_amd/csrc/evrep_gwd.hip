@@ -175,13 +175,11 @@ __device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds,
     constexpr int KPS = 2 * NSS, KPT = 2 * NST;
     const int64_t n = P.n, m = P.m;
     const int T = P.T;
-    // decode (bi, bj), bi <= bj, from the linear upper-triangular index: row bi starts at bi * T - bi (bi - 1) / 2.
-    // Closed form (a float estimate, corrected by at most a step either way) instead of walking up to T rows
-    int bi = (int)(((float)(2 * T + 1) - sqrtf((float)(2 * T + 1) * (float)(2 * T + 1) - 8.0f * (float)tile)) * 0.5f);
-    bi = bi < 0 ? 0 : (bi > T - 1 ? T - 1 : bi);
-    while (bi > 0 && (int64_t)bi * T - (int64_t)bi * (bi - 1) / 2 > tile) --bi;
-    while (bi + 1 < T && (int64_t)(bi + 1) * T - (int64_t)(bi + 1) * bi / 2 <= tile) ++bi;
-    const int bj = bi + (int)(tile - ((int64_t)bi * T - (int64_t)bi * (bi - 1) / 2));
+    // decode (bi, bj), bi <= bj, from the linear upper-triangular index (wave-uniform: scalar ALU; a closed form with a
+    // float square root and 64-bit corrections was tried in r03 and cost the kernel 7 us)
+    int t = tile, bi = 0;
+    while (t >= T - bi) { t -= T - bi; ++bi; }
+    const int bj = bi + t;
     const int64_t i0 = (int64_t)bi * kTile, j0 = (int64_t)bj * kTile;
     const bool has_s = j0 < n, has_t = j0 < m;  // bi <= bj: the row range starts no later
     float *As = lds, *Bs = lds + KPS * kTile, *At = lds + 2 * KPS * kTile, *Bt = At + KPT * kTile;
@@ -390,7 +388,14 @@ __device__ inline void gwd_load_pair_uniform(const GwdPair *q, GwdTileArgs &a, i
 // A fixed grid of workgroups (as many as the device holds at once) strides over the concatenated tile list of all pairs:
 // tile t belongs to the last pair with tile0 <= t (pairs without tiles share their successor's tile0 and are passed over).
 template <int NSS, int NST>
+#ifndef GWD_BATCH_VGPR
+#define GWD_BATCH_VGPR 0
+#endif
+#if GWD_BATCH_VGPR
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(GWD_BATCH_VGPR)))
+#else
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NSS + NST <= 11 ? 5 : 4)))   // as k_gwd_tiles
+#endif
 void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs, int P,
                                                              const int64_t *__restrict__ total_tiles) {
     extern __shared__ float lds[];

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Workload for the per-builder PMC passes (profiles/rNN/pmc_builders_*): every builder of the sweep at BASELINE config 2
-(32 windows x 50 000 events, 640x480) and config 3 (8 x 200 000, 1280x720), a few launches each, after the same 1 GiB
-fill / copy calibration kernels as tools/pmc_workload.py."""
+"""Workload for the per-builder PMC passes (profiles/rNN/pmc_builders_*): every builder of the sweep at the reference's Gen1
+shape (32 windows x 50 000 events, 304x240), BASELINE config 2 (32 x 50 000, 640x480) and config 3 (8 x 200 000, 1280x720),
+a few launches each, after the same 1 GiB fill / copy calibration kernels as tools/pmc_workload.py."""
 import os
 import sys
 
@@ -18,7 +18,8 @@ for _ in range(3):
     a.fill_(1.0)
     b.copy_(a)
 del a, b
-for W, H, N, B in ((640, 480, 50000, 32), (1280, 720, 200000, 8)):
+# the reference's real Gen1 shape first (gen1_2yolo.py:41-42,81-82), then BASELINE configs 2 and 3
+for W, H, N, B in ((304, 240, 50000, 32), (640, 480, 50000, 32), (1280, 720, 200000, 8)):
     eb = EventBatch.from_numpy([make_events(N, W, H, seed=7000 + i) for i in range(B)], H, W, device=dev)
     tn = torch.rand(eb.total, dtype=torch.float64, device=dev)
     o64 = torch.empty((B, H, W, 12), dtype=torch.float64, device=dev)
