@@ -278,6 +278,59 @@ __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &c
     return g;
 }
 
+// One batch (<= 64 records, record `lane` in r): the records only have to be GROUPED by pixel, in time order inside a
+// pixel (the lanes already are in time order: runs are visited in block = time order and are time-ordered inside a key).
+// r03: a leader election per pixel in LDS instead of a 7-bit ballot match (56 VALU instructions): in round k the lowest
+// unassigned lane of every pixel wins `slot[pixel]` (ds_min), takes rank k and clears the slot; a pixel is done after as
+// many rounds as it holds records -- one or two on sparse windows.  The winners keep the pixel's record count and first
+// lane in `info[pixel]`; the groups' places in the stage are the prefix sums of the counts over the first lanes; the
+// segment list emit_core wants falls out of the same numbers, so the segment-head search over the staged records is
+// skipped, and the records go to the stage ONCE, digested (emit_chunk), instead of raw -> read back -> digested -> written.
+template <typename OutT>
+__device__ inline void group_single_batch(const Rec &r, bool v0, uint32_t nrec, int keybase, int npixu, int segbase,
+                                          WaveLds<OutT> &w, UnitRecs &u) {
+    const int lane = threadIdx.x;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);
+    uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
+    const uint32_t px = v0 ? (uint32_t)(r.x - keybase) : 0u;
+    uint32_t *slot = cnt;                       // [npixu]
+    unsigned char *info = reinterpret_cast<unsigned char *>(cnt + npixu);   // [npixu][4]: count, first lane, place
+    for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    wave_phase();
+    bool un = v0;
+    uint32_t rk = 0;
+    for (uint32_t round = 0; __any(un); ++round) {
+        if (un) atomicMin(&slot[px], (uint32_t)lane);
+        wave_phase();
+        const bool lead = un && slot[px] == (uint32_t)lane;
+        wave_phase();
+        if (lead) {
+            slot[px] = ~0u;
+            rk = round;
+            info[4 * px] = (unsigned char)(round + 1);
+            if (round == 0) info[4 * px + 1] = (unsigned char)lane;
+            un = false;
+        }
+        wave_phase();
+    }
+    const bool first = v0 && rk == 0u;
+    const uint32_t size = first ? (uint32_t)info[4 * px] : 0u;
+    const uint32_t goff = wave_incl_scan(size) - size;
+    if (first) info[4 * px + 2] = (unsigned char)goff;
+    const uint64_t fm = __ballot(first);
+    const int nseg = __popcll(fm);
+    const int gidx = __popcll(fm & ((1ull << lane) - 1ull));
+    wave_phase();
+    u.pos = v0 ? (int)((uint32_t)info[4 * px + 2] + rk) : lane;
+    wave_phase();     // info is read: the segment list may take its place
+    if (first) w.segs[gidx] = make_uint2((uint32_t)(r.x - segbase), goff);   // relative to the builder's own origin
+    if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
+    u.ce = nrec;
+    u.nstaged = (int)nrec;
+    u.nseg = nseg;
+    u.r0 = r;
+}
+
 // Key-sorted pass: the records of keys [klo, khi) of window b (consecutive chunks of one sensor row; pixel id of the
 // first chunk's first pixel = keybase), gathered from the window's block runs and ordered by pixel, stably (the
 // runs are visited in block = time order and are time-ordered inside a key, so equal pixels stay in time order).
@@ -390,49 +443,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         u.nstaged = (int)nrec;
         const uint32_t px = v0 ? (uint32_t)(r.x - keybase) : 0u;
         if (!two) {
-            // one batch: the records only have to be GROUPED by pixel, in time order inside a pixel (the lanes already are
-            // in time order: runs are visited in block = time order and are time-ordered inside a key).  r03: a leader
-            // election per pixel in LDS instead of a 7-bit ballot match (56 VALU instructions): in round k the lowest
-            // unassigned lane of every pixel wins `slot[pixel]` (ds_min), takes rank k and clears the slot; a pixel is
-            // done after as many rounds as it holds records -- one or two on sparse windows.  The winners keep the pixel's
-            // record count and first lane in `info[pixel]`; the groups' places in the stage are the prefix sums of the
-            // counts over the first lanes; the segment list emit_core wants falls out of the same numbers, so the
-            // segment-head search over the staged records is skipped, and the records go to the stage ONCE, digested
-            // (emit_chunk), instead of raw -> read back -> digested -> written again.
-            uint32_t *slot = cnt;                       // [npixu]
-            unsigned char *info = reinterpret_cast<unsigned char *>(cnt + npixu);   // [npixu][4]: count, first lane, place
-            for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
-            wave_phase();
-            bool un = v0;
-            uint32_t rk = 0;
-            for (uint32_t round = 0; __any(un); ++round) {
-                if (un) atomicMin(&slot[px], (uint32_t)lane);
-                wave_phase();
-                const bool lead = un && slot[px] == (uint32_t)lane;
-                wave_phase();
-                if (lead) {
-                    slot[px] = ~0u;
-                    rk = round;
-                    info[4 * px] = (unsigned char)(round + 1);
-                    if (round == 0) info[4 * px + 1] = (unsigned char)lane;
-                    un = false;
-                }
-                wave_phase();
-            }
-            const bool first = v0 && rk == 0u;
-            const uint32_t size = first ? (uint32_t)info[4 * px] : 0u;
-            const uint32_t goff = wave_incl_scan(size) - size;
-            if (first) info[4 * px + 2] = (unsigned char)goff;
-            const uint64_t fm = __ballot(first);
-            const int nseg = __popcll(fm);
-            const int gidx = __popcll(fm & ((1ull << lane) - 1ull));
-            wave_phase();
-            u.pos = v0 ? (int)((uint32_t)info[4 * px + 2] + rk) : lane;
-            wave_phase();     // info is read: the segment list may take its place
-            if (first) w.segs[gidx] = make_uint2((uint32_t)(r.x - segbase), goff);   // relative to the builder's own origin
-            if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
-            u.nseg = nseg;
-            u.r0 = r;
+            group_single_batch(r, v0, nrec, keybase, npixu, segbase, w, u);
             return u;
         }
         for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
@@ -905,30 +916,10 @@ constexpr int kWantAny = 2;
 __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == EVREP_F_COUNT_POS || f == EVREP_F_COUNT_NEG; }
 
 // grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
+// One unit of MixedDensityEventStack: the window's statistics -> per-channel set-up -> digest / reduce -> emit.
 template <typename OutT, typename D>
-__global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__restrict__ off,
-                                               MdesParams P, int H, int W, int nchunk, UnitCfg uc, double scale,
-                                               OutT *__restrict__ out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int C = D::C(P);
-    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
-    w.arm(uc.hold);
-#ifdef EVREP_TIMING
-    w.dbg = bv.dbg + 8 * (size_t)chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
-#endif
-    ChunkGeom g;
-    // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
-    // unit's records
-    int chunk0;
-    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
-    const int64_t n_win = off[b0 + 1] - off[b0];
-    const MetaRaw mraw = meta_prefetch(bv, b0);
-    w.mark(6);
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    w.mark(0);
-    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    const WindowMeta m = meta_finish(bv, off, g.b, mraw);
-
+__device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double scale, const UnitRecs &u, const ChunkGeom &g,
+                                      int64_t n_win, const WindowMeta &m, OutT *__restrict__ dst, WaveLds<OutT> &w) {
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
@@ -1044,6 +1035,34 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
     };
     emit_chunk<OutT, D::kMaxC>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
+
+template <typename OutT, typename D>
+__global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__restrict__ off,
+                                               MdesParams P, int H, int W, int nchunk, UnitCfg uc, double scale,
+                                               OutT *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = D::C(P);
+    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+    w.arm(uc.hold);
+#ifdef EVREP_TIMING
+    w.dbg = bv.dbg + 8 * (size_t)chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+#endif
+    ChunkGeom g;
+    // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
+    // unit's records
+    int chunk0;
+    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
+    const int64_t n_win = off[b0 + 1] - off[b0];
+    const MetaRaw mraw = meta_prefetch(bv, b0);
+    w.mark(6);
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
+    w.mark(0);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    const WindowMeta m = meta_finish(bv, off, g.b, mraw);
+
+    mdes_emit_unit<OutT, D>(P, C, W, scale, u, g, n_win, m, dst, w);
+}
+
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
