@@ -47,25 +47,15 @@ static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
     return EVREP_OK;
 }
 
-
 template <int NSS, int NST>
-static int gwd_launch_tiles_batch(const GwdPair *pairs, int P, const int64_t *total, int64_t want, int cus, hipStream_t stream) {
+static int gwd_launch_tiles_batch(const GwdPair *pairs, int P, int64_t tile_cap, hipStream_t stream) {
     const size_t lds = (size_t)2 * (2 * NSS + 2 * NST) * kTile * sizeof(float);
     if (lds > 64 * 1024) {
         int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gwd_tiles_batch<NSS, NST>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_gwd_tiles_batch)");
         if (rc) return rc;
     }
-    // exactly the workgroups the device holds at once: resident workgroups are what keeps the matrix pipe fed (DESIGN.md
-    // 3.3), and a grid beyond that runs its surplus as a thin second round behind the first.  The kernel is compiled for
-    // 5 (4 for the wide instances) waves per SIMD = workgroups per CU (amdgpu_waves_per_eu in evrep_gwd.hip); LDS allows
-    // 160 KB / lds.  (hipOccupancyMaxActiveBlocksPerMultiprocessor reports one less than the hardware runs here.)
-    int per_cu = NSS + NST <= 11 ? 5 : 4;
-    const int by_lds = (int)((160 * 1024) / (lds + 64));
-    if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds;
-    const int64_t resident = (int64_t)cus * per_cu;
-    const int grid = (int)(want < resident ? want : resident);
-    k_gwd_tiles_batch<NSS, NST><<<grid, kThreads, lds, stream>>>(pairs, P, total);
+    k_gwd_tiles_batch<NSS, NST><<<dim3((unsigned)tile_cap, (unsigned)P), kThreads, lds, stream>>>(pairs);
     return EVREP_OK;
 }
 
@@ -770,12 +760,9 @@ int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row
     const int sblocks = (int)((pad_tile(n_cap) + kThreads - 1) / kThreads), tblocks = (int)((pad_tile(m_cap) + kThreads - 1) / kThreads);
     k_gwd_prep_batch<<<dim3(sblocks + tblocks, P), kThreads, 0, stream>>>(B.pairs, ds, dt, h, sblocks);
     LAUNCH_CHECK("k_gwd_prep_batch");
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t want = (int64_t)P * (Tc * (Tc + 1) / 2);
     int rc = EVREP_OK;
     const int ss = gwd_steps(ds), st = gwd_steps(dt);
-#define GWD_CASE(A, Bq) if (ss == A && st == Bq) rc = gwd_launch_tiles_batch<A, Bq>(B.pairs, P, B.total_tiles, want, cus, stream)
+#define GWD_CASE(A, Bq) if (ss == A && st == Bq) rc = gwd_launch_tiles_batch<A, Bq>(B.pairs, P, Tc * (Tc + 1) / 2, stream)
     GWD_CASE(3, 3); else GWD_CASE(3, 8); else GWD_CASE(3, 17); else GWD_CASE(8, 3); else GWD_CASE(8, 8);
     else GWD_CASE(8, 17); else GWD_CASE(17, 3); else GWD_CASE(17, 8); else GWD_CASE(17, 17);
 #undef GWD_CASE

@@ -162,40 +162,81 @@ struct GwdTileArgs {
     double *partial;  // [ntiles]
 };
 
-// grid: one workgroup (4 waves) per upper-triangular tile pair (bi <= bj) of the L x L grid, T = Lpad / kTile.
+// One workgroup (4 waves) per upper-triangular tile pair (bi <= bj) of the L x L grid, T = Lpad / kTile.
 // Wave w owns tile rows [32w, 32w + 32) and walks the four 32-column blocks.  Deliberately lean in registers (one
-// accumulator set, operands re-read from LDS per block): a tile is only ~2800 matrix-pipe cycles per wave, far less
-// than the latency of fetching its points, so what keeps the matrix pipe fed is the NUMBER of resident
-// workgroups, not instruction-level overlap inside one (measured: register-resident operands, double-buffered
-// accumulators and multi-tile workgroups all lowered the occupancy and ran 30-50 % slower).
-// partial[blockIdx.x] = sum over the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
+// accumulator set, operands re-read from LDS per block): a tile is only ~2800 matrix-pipe cycles per wave, so what
+// keeps the matrix pipe fed is the NUMBER of resident workgroups, not instruction-level overlap inside one (measured:
+// register-resident operands, double-buffered accumulators and multi-tile workgroups all lowered the occupancy and ran
+// 30-50 % slower).
+// partial[tile] = sum over the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
 // NSS / NST: inner MFMA steps = gwd_steps(ds), gwd_steps(dt) (compile time).
+// waves per SIMD = workgroups per CU the tile kernels are compiled for
+#define GWD_WAVES(NSS, NST) ((NSS) + (NST) <= 11 ? 5 : 4)
 template <int NSS, int NST>
-__device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds, double *red, int tid) {
-    constexpr int KPS = 2 * NSS, KPT = 2 * NST;
-    const int64_t n = P.n, m = P.m;
-    const int T = P.T;
-    // decode (bi, bj), bi <= bj, from the linear upper-triangular index (wave-uniform: scalar ALU; a closed form with a
-    // float square root and 64-bit corrections was tried in r03 and cost the kernel 7 us)
+struct GwdTileShape {
+    static constexpr int KPS = 2 * NSS, KPT = 2 * NST;
+    static constexpr int ROWS = 2 * KPS + 2 * KPT;          // point rows of 128 floats, LDS order As Bs At Bt
+    static constexpr int NV = ROWS * (kTile / 4);           // float4 per tile
+    static constexpr int NIT = (NV + kThreads - 1) / kThreads;
+};
+
+struct GwdTilePos {
+    int bi, bj;
+};
+// (bi, bj), bi <= bj, from the linear upper-triangular index (wave-uniform: scalar ALU; a closed form with a float
+// square root and 64-bit corrections was tried in r03 and cost the kernel 7 us)
+__device__ inline GwdTilePos gwd_tile_pos(int T, int tile) {
     int t = tile, bi = 0;
     while (t >= T - bi) { t -= T - bi; ++bi; }
-    const int bj = bi + t;
-    const int64_t i0 = (int64_t)bi * kTile, j0 = (int64_t)bj * kTile;
-    const bool has_s = j0 < n, has_t = j0 < m;  // bi <= bj: the row range starts no later
-    float *As = lds, *Bs = lds + KPS * kTile, *At = lds + 2 * KPS * kTile, *Bt = At + KPT * kTile;
-    if (has_s)
-        for (int e = tid; e < KPS * kTile; e += kThreads) {
-            const int k = e / kTile, i = e % kTile;
-            As[e] = P.YsA[(int64_t)k * P.npad + i0 + i];
-            Bs[e] = P.YsB[(int64_t)k * P.npad + j0 + i];
+    GwdTilePos q;
+    q.bi = bi; q.bj = bi + t;
+    return q;
+}
+
+// The tile's point rows as float4, EVERY load of a thread issued before anything waits for one (r02 / early r03: eleven
+// dependent load -> wait -> LDS write rounds per tile; the rows are padded to whole tiles and 16-byte aligned).
+template <int NSS, int NST>
+__device__ inline void gwd_tile_fetch(const GwdTileArgs &P, GwdTilePos q, int tid, float4 (&v)[GwdTileShape<NSS, NST>::NIT]) {
+    using S = GwdTileShape<NSS, NST>;
+    const int64_t i0 = (int64_t)q.bi * kTile, j0 = (int64_t)q.bj * kTile;
+    const bool has_s = j0 < P.n, has_t = j0 < P.m;  // bi <= bj: the row range starts no later
+    const float *ysa = P.YsA, *ysb = P.YsB, *yta = P.YtA, *ytb = P.YtB;   // values, not members: a select of members
+    const int64_t npad = P.npad, mpad = P.mpad;                           // would index the struct in scratch
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+        const int e = tid + it * kThreads, row = e / (kTile / 4), c = (e % (kTile / 4)) * 4;
+        v[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < S::NV) {
+            const bool s_row = row < 2 * S::KPS;
+            const int k = s_row ? (row < S::KPS ? row : row - S::KPS)
+                                : (row < 2 * S::KPS + S::KPT ? row - 2 * S::KPS : row - 2 * S::KPS - S::KPT);
+            const bool a_form = s_row ? row < S::KPS : row < 2 * S::KPS + S::KPT;
+            const float *base = s_row ? (a_form ? ysa : ysb) : (a_form ? yta : ytb);
+            const int64_t pad = s_row ? npad : mpad;
+            if (s_row ? has_s : has_t)
+                v[it] = *reinterpret_cast<const float4 *>(base + (int64_t)k * pad + (a_form ? i0 : j0) + c);
         }
-    if (has_t)
-        for (int e = tid; e < KPT * kTile; e += kThreads) {
-            const int k = e / kTile, i = e % kTile;
-            At[e] = P.YtA[(int64_t)k * P.mpad + i0 + i];
-            Bt[e] = P.YtB[(int64_t)k * P.mpad + j0 + i];
-        }
-    __syncthreads();
+    }
+}
+template <int NSS, int NST>
+__device__ inline void gwd_tile_stage(const float4 (&v)[GwdTileShape<NSS, NST>::NIT], float *lds, int tid) {
+    using S = GwdTileShape<NSS, NST>;
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+        const int e = tid + it * kThreads;
+        if (e < S::NV) *reinterpret_cast<float4 *>(lds + 4 * e) = v[it];
+    }
+}
+
+// The tile's sum from the staged rows (the caller's barrier stands between the stage and this).  Ends with the barrier
+// that publishes the wave sums; thread 0 then stores partial[tile].
+template <int NSS, int NST>
+__device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTilePos q, const float *lds, double *red, int tid) {
+    using S = GwdTileShape<NSS, NST>;
+    const int64_t n = P.n, m = P.m;
+    const int64_t i0 = (int64_t)q.bi * kTile, j0 = (int64_t)q.bj * kTile;
+    const bool has_s = j0 < n, has_t = j0 < m;
+    const float *As = lds, *Bs = lds + S::KPS * kTile, *At = lds + 2 * S::KPS * kTile, *Bt = At + S::KPT * kTile;
     const int lane = tid & 63, wave = tid >> 6;
     const int r0 = wave * 32;
     float as[NSS], at[NST];
@@ -230,11 +271,27 @@ __device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds,
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
     if (lane == 0) red[wave] = d;
     __syncthreads();
-    if (tid == 0) P.partial[tile] = (bi == bj ? 1.0 : 2.0) * (((red[0] + red[1]) + red[2]) + red[3]);
+    if (tid == 0) P.partial[tile] = (q.bi == q.bj ? 1.0 : 2.0) * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
+// One tile, start to end (the unit the microbenchmark times).
 template <int NSS, int NST>
-__global__ __launch_bounds__(kThreads) void k_gwd_tiles(GwdTileArgs P) {
+__device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds, double *red, int tid) {
+    const GwdTilePos q = gwd_tile_pos(P.T, tile);
+    float4 v[GwdTileShape<NSS, NST>::NIT];
+    gwd_tile_fetch<NSS, NST>(P, q, tid, v);
+    gwd_tile_stage<NSS, NST>(v, lds, tid);
+    __syncthreads();
+    gwd_tile_compute<NSS, NST>(P, tile, q, lds, red, tid);
+}
+
+// grid (ntiles): one workgroup per tile.  (r03 measured the alternatives once more -- a resident grid striding over the
+// tile list, with and without the next tile's rows prefetched into registers: 86-99 us against 67 us for this form;
+// tools/microbench/gwd_tile_phases.hip.  The hardware's own dispatch of short workgroups balances the SIMDs better than
+// any static assignment of tiles to resident workgroups, whose waves wait for each other at two barriers per tile.)
+template <int NSS, int NST>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GWD_WAVES(NSS, NST))))
+void k_gwd_tiles(GwdTileArgs P) {
     extern __shared__ float lds[];  // As[KPS][kTile] Bs At[KPT][kTile] Bt
     __shared__ double red[kWaves];
     gwd_tile_body<NSS, NST>(P, (int)blockIdx.x, lds, red, (int)threadIdx.x);
@@ -385,42 +442,19 @@ __device__ inline void gwd_load_pair_uniform(const GwdPair *q, GwdTileArgs &a, i
     tile0 = (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// A fixed grid of workgroups (as many as the device holds at once) strides over the concatenated tile list of all pairs:
-// tile t belongs to the last pair with tile0 <= t (pairs without tiles share their successor's tile0 and are passed over).
+// grid (tile_cap, P): workgroup (t, p) evaluates tile t of pair p; tile_cap = the tile count of the caller's size bounds,
+// workgroups beyond a pair's own count leave at once.  (The first r03 form -- a resident grid striding over the
+// concatenated tile list -- took 82 us per 12.5k x 14.4k pair where the single solve's one-workgroup-per-tile kernel took 67.)
 template <int NSS, int NST>
-#ifndef GWD_BATCH_VGPR
-#define GWD_BATCH_VGPR 0
-#endif
-#if GWD_BATCH_VGPR
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(GWD_BATCH_VGPR)))
-#else
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NSS + NST <= 11 ? 5 : 4)))   // as k_gwd_tiles
-#endif
-void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs, int P,
-                                                             const int64_t *__restrict__ total_tiles) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GWD_WAVES(NSS, NST))))
+void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs) {
     extern __shared__ float lds[];
     __shared__ double red[kWaves];
-    const int64_t total = *total_tiles;
-    int p = 0;
-    int64_t next0 = P > 1 ? pairs[1].tile0 : total;   // first tile of the pair behind p
-    GwdTileArgs a;                                     // the current pair's arguments, in SGPRs until the pair changes
+    GwdTileArgs a;
     int64_t tile0;
-    gwd_load_pair_uniform(pairs, a, tile0);
-    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        // the workgroup's tiles ascend, so the pair index only moves forward: one scalar load per pair passed (a binary
-        // search per tile cost eight dependent loads, ~4 us of a ~16 us tile)
-        if (t >= next0) {
-            while (p + 1 < P && t >= next0) { ++p; next0 = p + 1 < P ? pairs[p + 1].tile0 : total; }
-            gwd_load_pair_uniform(pairs + p, a, tile0);
-        }
-        // the thread index is laundered through an empty asm every iteration: otherwise the body's lane-derived LDS
-        // addresses are hoisted out of the tile loop and stay live across it (17 VGPRs, one workgroup per CU less --
-        // and the matrix pipe is fed by the number of resident workgroups)
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        gwd_tile_body<NSS, NST>(a, (int)(t - tile0), lds, red, tid);
-        __syncthreads();   // the LDS tiles and `red` are reused by the next tile
-    }
+    gwd_load_pair_uniform(pairs + blockIdx.y, a, tile0);
+    if ((int)blockIdx.x >= a.ntiles) return;
+    gwd_tile_body<NSS, NST>(a, (int)blockIdx.x, lds, red, (int)threadIdx.x);
 }
 
 // grid (P), 1024 threads: k_gwd_finish of pair blockIdx.x (the same fixed summation order as the single solve, so a
