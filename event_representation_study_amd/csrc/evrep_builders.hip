@@ -539,6 +539,29 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     return u;
 }
 
+// Classic passes (the stream is pixel-sorted already): records [64, min(nrec, stage)) of the unit go to the wave's LDS
+// stage RAW, every load in flight before the first write (r03).  Until then a dense unit read everything behind its first
+// 64 records inside the divergent segment walks -- a global load and, for the builders whose digest divides, a float64
+// division per step of the longest segment of the wave (70 % of the records of a 640x480 window of 500 000 events).
+// emit_chunk digests the staged batches one record per lane once the segment heads are listed.
+template <typename OutT>
+__device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT> &w) {
+    const int nrec = (int)(u.ce - u.cs), lane = threadIdx.x;
+    const int n = min(nrec, w.nstage);
+    if (n <= kWave || w.nstage <= 2 * kEvStage) return;   // wave-uniform; only the builders that ask for a deep stage (unit_cfg)
+    // stages of up to 256 records: three batches behind the register batch
+    const Rec *src = u.sorted + u.cs + lane;
+    const bool h1 = kWave + lane < n, h2 = 2 * kWave + lane < n, h3 = 3 * kWave + lane < n;
+    Rec t1 = make_int4(0, 0, 0, 0), t2 = t1, t3 = t1;
+    if (h1) t1 = src[kWave];
+    if (h2) t2 = src[2 * kWave];
+    if (h3) t3 = src[3 * kWave];
+    if (h1) w.evbuf[kWave + lane] = t1;
+    if (h2) w.evbuf[2 * kWave + lane] = t2;
+    if (h3) w.evbuf[3 * kWave + lane] = t3;
+    u.nstaged = n;
+}
+
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
 template <typename OutT>
 __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
@@ -559,6 +582,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
     u.nseg = -1; u.pos = (int)threadIdx.x;
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
+    stage_classic(u, w);
     return u;
 }
 
@@ -807,6 +831,7 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, KeyAt key_at, RecA
                 se += c;
                 if (c < kWave) break;
             }
+            if (part == 0) w.mark(7);
             for (int k = sb + lane; k < se; k += kWave) {
                 const uint2 sg = w.segs[k];
                 const int q = (int)sg.x - part * PP;
@@ -819,9 +844,11 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, KeyAt key_at, RecA
             }
             sb = se;
             wave_phase();
-            if (part == 0) w.pace();
+            if (part == 0) { w.mark(3); w.pace(); }
             tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
+            if (part == 0) w.mark(4);
         }
+        w.mark(5);
     }
 }
 
@@ -851,8 +878,8 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest_fly(sorted[cs + j]); };
     auto get_staged = [&](uint32_t j) -> Rec { return evbuf[j]; };
     auto post_heads = [&]() {
-        if (nraw > (uint32_t)kWave) {  // uniform: the second staged batch is still raw (key_at read its pixel ids)
-            if (lane + kWave < (int)nraw) evbuf[lane + kWave] = digest(evbuf[lane + kWave]);
+        if (nraw > (uint32_t)kWave) {  // uniform: the later staged batches are still raw (key_at read their pixel ids)
+            for (int j = lane + kWave; j < (int)nraw; j += kWave) evbuf[j] = digest(evbuf[j]);
             wave_phase();
         }
     };
@@ -1357,6 +1384,7 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
             ur.cs = co[ch_lo];
             ur.ce = co[ch_hi + 1];
             if ((int)threadIdx.x < (int)(ur.ce - ur.cs)) ur.r0 = ur.sorted[ur.cs + threadIdx.x];
+            stage_classic(ur, w);
         }
     }
     // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)

@@ -351,7 +351,7 @@ static BinView bin_view(const evrep_plan *plan, const int32_t *events, void *wor
     bv.nblk = plan->nblk;
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
 #ifdef EVREP_TIMING
-    bv.dbg = WS(unsigned long long, off_sorted2);   // 8 slots per builder wave in the (idle) spill stream
+    bv.dbg = bv.fused ? WS(unsigned long long, off_sorted2) : WS(unsigned long long, off_sorted1);   // 8 slots per builder wave in the stream that is idle
 #endif
     return bv;
 }
@@ -367,13 +367,14 @@ static int ensure_column_sorted(const evrep_plan *plan, const int32_t *events, c
 // sparse windows (<= 30 records per chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel
 // fast path), else 1.  stage = records its LDS stage holds: 64 for one-chunk units, 128 for wider ones (they hold ~65
 // records on the sparse windows they are chosen for).
-static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_chunks = 0, bool wide_part = false) {
+static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_chunks = 0, bool wide_part = false, bool deep_stage = true) {
     UnitCfg uc;
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
     uc.span = (pixel_bytes * kChunkPx > 8192 || plan->nchunk < 2) ? 1 : (per_chunk <= 30.0 ? 2 : 1);  // a 128-pixel chunk of >= 8 KB stays alone
     // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
-    // in two register batches: a 128-record stage
-    uc.stage = (uc.span + extra_chunks > 1 || per_chunk > 28.0) ? 128 : 64;
+    // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
+    // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
+    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0) ? 128 : 64);
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     return uc;
@@ -458,7 +459,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
+    const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
 #define ES_LAUNCH(CM)                                                                                              \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
@@ -483,7 +484,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     // sparse windows (practically every unit fully staged): the kernel with the factorised exponentials compiled in
     const bool ts_fact = (double)plan->max_events_per_window <= 30.0 * (double)plan->H * plan->nchunk;
     if (out_dtype == EVREP_F64) {
-        const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20);  // one-chunk units whatever the slice count
+        const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20, 0, false, false);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
     k_time_surface<T, CM, F><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(            \
         bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
@@ -491,7 +492,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
 #define TS_LAUNCH(T, CM, GRID, SEG) do { if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG); } while (0)
         if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
     } else {
-        const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4);
+        const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4, 0, false, false);
         const int span = uc.span;
         if (slices <= 6) TS_LAUNCH(float, 12, SPAN_GRID(span), span * kChunkPx); else TS_LAUNCH(float, 16, SPAN_GRID(span), span * kChunkPx);
     }

@@ -1,6 +1,6 @@
 """Where a builder wave's time goes (experiment build: -DEVREP_TIMING, EVREP_LIB_PATH=<that .so>).  Phase marks of k_mdes, mean
 us since the wave started: 0 records fetched and grouped (unit_front), 1 window statistics merged, 2 segment heads listed +
-digest, 3 reduced and published (pace entry), 4 pace left, 5 stores issued.
+digest, 3 reduced and published (pace entry), 4 pace left, 5 stores issued, 6 first loads issued, 7 sparse: reduced / dense: first part about to be reduced.
 
     hipcc ... -DEVREP_TIMING -o /tmp/libevrep_timing.so ...; EVREP_LIB_PATH=/tmp/libevrep_timing.so python tools/experiments/phase_times.py [hold ...]
 """
@@ -16,13 +16,16 @@ from event_representation_study_amd.engine import EventBatch
 from event_representation_study_amd.synthetic import make_events
 
 H, W, N, B = 480, 640, 50000, 32
+if os.environ.get("SHAPE"):   # SHAPE=W,H,N,B: another workload (dense windows: 640,480,500000,8; marks 3/4 = first part tile)
+    W, H, N, B = (int(v) for v in os.environ["SHAPE"].split(","))
 eb = EventBatch.from_numpy([make_events(N, W, H, seed=i) for i in range(B)], H, W)
 eb.bin()
-outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(4)]
+outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
 holds = [int(v) for v in sys.argv[1:]] or [0, 600, 670]
 nunit = B * H * ((W + 127) // 128)
-assert nunit * 64 <= (eb.total + 1) * 16, "the spill stream is too small for the marks"
-dbg = eb.workspace[eb.plan.off_sorted2: eb.plan.off_sorted2 + nunit * 64].view(torch.int64).view(nunit, 8)
+assert nunit * 64 <= (eb.total + 1) * 16, "the idle record stream is too small for the marks"
+idle = eb.plan.off_sorted2 if eb.plan.reserved == 2 else eb.plan.off_sorted1   # the stream the builders do not read
+dbg = eb.workspace[idle: idle + nunit * 64].view(torch.int64).view(nunit, 8)
 for o in outs:
     for h in holds:
         check(eb.lib.evrep_plan_set_pacing(ctypes.byref(eb.plan), h), "pacing")
@@ -38,5 +41,5 @@ for o in outs:
         torch.cuda.synchronize()
         d = dbg.cpu().numpy().astype(float) / 100.0
         import numpy as np
-        ph = ["%d: %.2f/%.2f" % (i, d[:, i].mean(), np.percentile(d[:, i], 95)) for i in range(6)]
+        ph = ["%d: %.2f/%.2f" % (i, d[:, i].mean(), np.percentile(d[:, i], 95)) for i in range(8)]
         print("%x hold %4d  %.1f us/launch  phases mean/p95 (us) %s" % (o.data_ptr(), h, a.elapsed_time(b) * 100, "  ".join(ph)), flush=True)

@@ -89,6 +89,77 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     if (tid == 0 && marks) marks[tile] = t1 - t0;
 }
 
+// Compute-loop candidates (LDS garbage in, speed only): NORMV = the two norm-carrying MFMA steps replaced by VALU adds
+// into the accumulators (9 instead of 11 MFMA per block); NPOLY of a block's 32 exponentials as a degree-5 polynomial
+// on the plain VALU (which overlaps the matrix pipe; v_exp_f32 does not).
+__device__ inline float exp2_poly(float x) {
+    const float r = __builtin_rintf(x), f = x - r;
+    float p = 1.535336188319500e-4f;
+    p = __builtin_fmaf(p, f, 1.339887440266574e-3f);
+    p = __builtin_fmaf(p, f, 9.618437357674640e-3f);
+    p = __builtin_fmaf(p, f, 5.550332471162809e-2f);
+    p = __builtin_fmaf(p, f, 2.402264791363012e-1f);
+    p = __builtin_fmaf(p, f, 6.931472028550421e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)r);
+}
+template <int NSS, int NST, bool NORMV, int NPOLY>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void k_cand(GwdTileArgs P, long long *marks) {
+    extern __shared__ float lds[];
+    __shared__ double red[kWaves];
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const long long t0 = wall_clock64();
+    constexpr int KPS = 2 * NSS, KPT = 2 * NST;
+    constexpr int MS = NORMV ? NSS - 1 : NSS, MT = NORMV ? NST - 1 : NST;
+    const int lane = tid & 63, wave = tid >> 6, r0 = wave * 32;
+    float *As = lds, *Bs = lds + KPS * kTile, *At = lds + 2 * KPS * kTile, *Bt = At + KPT * kTile;
+    float as[MS], at[MT];
+    gwd_load_strip<MS>(As, r0, lane, as);
+    gwd_load_strip<MT>(At, r0, lane, at);
+    float ns[16], nt[16];
+    if (NORMV) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ns[r] = As[(KPS - 2) * kTile + row]; nt[r] = At[(KPT - 2) * kTile + row];
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll 1
+    for (int cb = 0; cb < 4; ++cb) {
+        float bs[MS], bt[MT];
+        f32x16 es, et;
+        gwd_load_strip<MS>(Bs, cb * 32, lane, bs);
+        gwd_load_strip<MT>(Bt, cb * 32, lane, bt);
+        if (NORMV) {
+            const float cs = Bs[(KPS - 1) * kTile + cb * 32 + (lane & 31)], ct = Bt[(KPT - 1) * kTile + cb * 32 + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { es[r] = ns[r] + cs; et[r] = nt[r] + ct; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { es[r] = 0.0f; et[r] = 0.0f; }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < MS; ++s_) es = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s_], bs[s_], es, 0, 0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < MT; ++s_) et = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s_], bt[s_], et, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = (2 * r < NPOLY) ? exp2_poly(es[r]) : __builtin_amdgcn_exp2f(es[r]);
+            const float b = (2 * r + 1 < NPOLY) ? exp2_poly(et[r]) : __builtin_amdgcn_exp2f(et[r]);
+            sum += fabsf(a - b);
+        }
+    }
+    double d = (double)sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) red[wave] = d;
+    __syncthreads();
+    if (tid == 0) P.partial[tile] = red[0] + red[1] + red[2] + red[3];
+    const long long t1 = wall_clock64();
+    if (tid == 0 && marks) marks[tile] = t1 - t0;
+}
+
 // The bf16 x 3 split form of the same exponent matrix (each float32 coordinate = hi + mid + lo in bfloat16; the six
 // largest cross terms per dimension laid along K): MS / MT v_mfma_f32_32x32x16_bf16 per block.  Speed only (garbage in).
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -175,6 +246,14 @@ int main(int argc, char **argv) {
     report("compute, no exp", k_var<NSS, NST, 3>);
     report("compute, no MFMA", k_var<NSS, NST, 4>);
     report("compute, MFMA only", k_var<NSS, NST, 5>);
+    report("cand: 11 MFMA, 0 poly", k_cand<NSS, NST, false, 0>);
+    report("cand: 9 MFMA + norm adds", k_cand<NSS, NST, true, 0>);
+    report("cand: 11 MFMA, 8 poly", k_cand<NSS, NST, false, 8>);
+    report("cand: 11 MFMA, 16 poly", k_cand<NSS, NST, false, 16>);
+    report("cand: 11 MFMA, 24 poly", k_cand<NSS, NST, false, 24>);
+    report("cand: 11 MFMA, 32 poly", k_cand<NSS, NST, false, 32>);
+    report("cand: 9 MFMA, 16 poly", k_cand<NSS, NST, true, 16>);
+    report("cand: 9 MFMA, 24 poly", k_cand<NSS, NST, true, 24>);
     lds = (size_t)(2 + 6) * 2 * kTile * 16;
     report("bf16x3 compute (2 + 6 MFMA)", k_bf<2, 6, true>);
     report("bf16x3 compute, no exp", k_bf<2, 6, false>);
