@@ -47,6 +47,20 @@ static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
     return EVREP_OK;
 }
 
+// split-form tiles (clouds of <= kGwdSplitMaxD dimensions): LDS = the column tile's operands
+template <int MS, int MT>
+static int gwd_launch_tiles_split(const GwdTileArgs &P, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (MS + MT) * kTile * 16;
+    k_gwd_tiles_split<MS, MT><<<P.ntiles, kThreads, lds, stream>>>(P);
+    return EVREP_OK;
+}
+template <int MS, int MT>
+static int gwd_launch_tiles_split_batch(const GwdPair *pairs, int P, int64_t tile_cap, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (MS + MT) * kTile * 16;
+    k_gwd_tiles_split_batch<MS, MT><<<dim3((unsigned)tile_cap, (unsigned)P), kThreads, lds, stream>>>(pairs);
+    return EVREP_OK;
+}
+
 template <int NSS, int NST>
 static int gwd_launch_tiles_batch(const GwdPair *pairs, int P, int64_t tile_cap, hipStream_t stream) {
     const size_t lds = (size_t)2 * (2 * NSS + 2 * NST) * kTile * sizeof(float);
@@ -674,16 +688,19 @@ int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox
 
 // ---------------------------------------------------------------------------------------------- GWD
 static int64_t pad_tile(int64_t n) { return (n + kTile - 1) / kTile * kTile; }
+// bytes per point and form of a scaled cloud, whatever its dimension and form: 6 split steps x 32 B > 2 x 17 float32 steps x 4 B
+constexpr size_t kGwdFormBytesMax = 192;
+static_assert(kGwdFormBytesMax >= 6 * 32 && kGwdFormBytesMax >= 2 * 17 * sizeof(float), "kGwdFormBytesMax");
 
 size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m) {
     if (n <= 0 || m <= 0) return 0;
     const int64_t L = n > m ? n : m;
     const int64_t T = pad_tile(L) / kTile;
     size_t o = 0;
-    o += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));         // statistics partial sums
-    o += 2 * up256((size_t)2 * gwd_steps(kGwdMaxD) * pad_tile(n) * sizeof(float));  // augmented cloud s: row + column form
-    o += 2 * up256((size_t)2 * gwd_steps(kGwdMaxD) * pad_tile(m) * sizeof(float));  // augmented cloud t
-    o += up256((size_t)(T * (T + 1) / 2) * sizeof(double));                      // per-tile sums
+    o += up256(((size_t)2 * kStatBlocks * 2 * kGwdMaxD + 2 * kGwdFin) * sizeof(double));   // statistics: partial sums + final
+    o += 2 * up256(kGwdFormBytesMax * (size_t)pad_tile(n));  // scaled cloud s: row + column form
+    o += 2 * up256(kGwdFormBytesMax * (size_t)pad_tile(m));  // scaled cloud t
+    o += up256((size_t)(T * (T + 1) / 2) * kWaves * sizeof(double));             // per-tile, per-wave sums
     return o;
 }
 
@@ -695,12 +712,13 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t L = n > m ? n : m;
     const int T = (int)(pad_tile(L) / kTile);
-    if ((int64_t)T * (T + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
+    if ((int64_t)T * (T + 1) / 2 * kWaves > 0x7fffffff) return EVREP_EINVAL;
     char *p = static_cast<char *>(scratch);
-    double *stat_partial = reinterpret_cast<double *>(p); p += up256((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
+    double *stat_partial = reinterpret_cast<double *>(p); p += up256(((size_t)2 * kStatBlocks * 2 * kGwdMaxD + 2 * kGwdFin) * sizeof(double));
+    double *fin = stat_partial + (size_t)2 * kStatBlocks * 2 * kGwdMaxD;
     const int64_t npad = pad_tile(n), mpad = pad_tile(m);
-    const size_t sbytes = up256((size_t)2 * gwd_steps(kGwdMaxD) * npad * sizeof(float));
-    const size_t tbytes = up256((size_t)2 * gwd_steps(kGwdMaxD) * mpad * sizeof(float));
+    const size_t sbytes = up256(kGwdFormBytesMax * (size_t)npad);
+    const size_t tbytes = up256(kGwdFormBytesMax * (size_t)mpad);
     float *YsA = reinterpret_cast<float *>(p); p += sbytes;
     float *YsB = reinterpret_cast<float *>(p); p += sbytes;
     float *YtA = reinterpret_cast<float *>(p); p += tbytes;
@@ -711,20 +729,31 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
     k_gwd_stats<<<dim3(kStatBlocks, 2), kThreads, 0, stream>>>(Xs, n, ds, Xt, m, dt, stat_partial);
     LAUNCH_CHECK("k_gwd_stats");
     const int sblocks = (int)((npad + kThreads - 1) / kThreads), tblocks = (int)((mpad + kThreads - 1) / kThreads);
-    k_gwd_prep<<<sblocks + tblocks, kThreads, 0, stream>>>(Xs, n, ds, npad, Xt, m, dt, mpad, stat_partial, h, sblocks, YsA, YsB, YtA, YtB);
+    k_gwd_stats_finish<<<2, 64, 0, stream>>>(stat_partial, n, ds, m, dt, h, fin);
+    LAUNCH_CHECK("k_gwd_stats_finish");
+    // the split form spreads a point's chunks over blockIdx.z
+    const int prep_z = gwd_use_split(ds, dt) ? 2 * gwd_split_steps(ds > dt ? ds : dt) : 1;
+    k_gwd_prep<<<dim3(sblocks + tblocks, 1, prep_z), kThreads, 0, stream>>>(Xs, n, ds, npad, Xt, m, dt, mpad, fin, sblocks, YsA, YsB, YtA, YtB);
     LAUNCH_CHECK("k_gwd_prep");
     GwdTileArgs P;
     P.YsA = YsA; P.YsB = YsB; P.YtA = YtA; P.YtB = YtB; P.n = n; P.m = m; P.npad = npad; P.mpad = mpad;
     P.T = T; P.ntiles = T * (T + 1) / 2; P.partial = partial;
     int rc = EVREP_OK;
     const int ss = gwd_steps(ds), st = gwd_steps(dt);
+    if (gwd_use_split(ds, dt)) {
+        const int ms = gwd_split_steps(ds), mt = gwd_split_steps(dt);
+        if (ms == 2 && mt == 2) rc = gwd_launch_tiles_split<2, 2>(P, stream);
+        else if (ms == 2) rc = gwd_launch_tiles_split<2, 6>(P, stream);
+        else if (mt == 2) rc = gwd_launch_tiles_split<6, 2>(P, stream);
+        else rc = gwd_launch_tiles_split<6, 6>(P, stream);
+    } else
 #define GWD_CASE(A, B) if (ss == A && st == B) rc = gwd_launch_tiles<A, B>(P, stream)
     GWD_CASE(3, 3); else GWD_CASE(3, 8); else GWD_CASE(3, 17); else GWD_CASE(8, 3); else GWD_CASE(8, 8);
     else GWD_CASE(8, 17); else GWD_CASE(17, 3); else GWD_CASE(17, 8); else GWD_CASE(17, 17);
 #undef GWD_CASE
     if (rc) return rc;
     LAUNCH_CHECK("k_gwd_tiles");
-    k_gwd_finish<<<1, 1024, 0, stream>>>(partial, P.ntiles, (double)L, cost);
+    k_gwd_finish<<<1, 1024, 0, stream>>>(partial, P.ntiles * kWaves, (double)L, cost);
     LAUNCH_CHECK("k_gwd_finish");
     return EVREP_OK;
 }
@@ -742,7 +771,7 @@ int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row
     if (reinterpret_cast<uintptr_t>(scratch) & 255u) return EVREP_EINVAL;
     const int64_t Lc = n_cap > m_cap ? n_cap : m_cap;
     const int64_t Tc = pad_tile(Lc) / kTile;
-    if (Tc * (Tc + 1) / 2 > 0x7fffffff) return EVREP_EINVAL;
+    if (Tc * (Tc + 1) / 2 * kWaves > 0x7fffffff) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const GwdBatchLayout L = gwd_batch_layout(P, ds, dt, n_cap, m_cap);
     GwdBatchArgs B;
@@ -759,10 +788,21 @@ int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row
     k_gwd_stats_batch<<<dim3(kStatBlocks, 2, P), kThreads, 0, stream>>>(B.pairs, ds, dt);
     LAUNCH_CHECK("k_gwd_stats_batch");
     const int sblocks = (int)((pad_tile(n_cap) + kThreads - 1) / kThreads), tblocks = (int)((pad_tile(m_cap) + kThreads - 1) / kThreads);
-    k_gwd_prep_batch<<<dim3(sblocks + tblocks, P), kThreads, 0, stream>>>(B.pairs, ds, dt, h, sblocks);
+    k_gwd_stats_finish_batch<<<dim3(2, P), 64, 0, stream>>>(B.pairs, ds, dt, h);
+    LAUNCH_CHECK("k_gwd_stats_finish_batch");
+    const int prep_z = gwd_use_split(ds, dt) ? 2 * gwd_split_steps(ds > dt ? ds : dt) : 1;   // a point's chunks over blockIdx.z
+    k_gwd_prep_batch<<<dim3(sblocks + tblocks, P, prep_z), kThreads, 0, stream>>>(B.pairs, ds, dt, sblocks);
     LAUNCH_CHECK("k_gwd_prep_batch");
     int rc = EVREP_OK;
     const int ss = gwd_steps(ds), st = gwd_steps(dt);
+    if (gwd_use_split(ds, dt)) {
+        const int ms = gwd_split_steps(ds), mt = gwd_split_steps(dt);
+        const int64_t cap = Tc * (Tc + 1) / 2;
+        if (ms == 2 && mt == 2) rc = gwd_launch_tiles_split_batch<2, 2>(B.pairs, P, cap, stream);
+        else if (ms == 2) rc = gwd_launch_tiles_split_batch<2, 6>(B.pairs, P, cap, stream);
+        else if (mt == 2) rc = gwd_launch_tiles_split_batch<6, 2>(B.pairs, P, cap, stream);
+        else rc = gwd_launch_tiles_split_batch<6, 6>(B.pairs, P, cap, stream);
+    } else
 #define GWD_CASE(A, Bq) if (ss == A && st == Bq) rc = gwd_launch_tiles_batch<A, Bq>(B.pairs, P, Tc * (Tc + 1) / 2, stream)
     GWD_CASE(3, 3); else GWD_CASE(3, 8); else GWD_CASE(3, 17); else GWD_CASE(8, 3); else GWD_CASE(8, 8);
     else GWD_CASE(8, 17); else GWD_CASE(17, 3); else GWD_CASE(17, 8); else GWD_CASE(17, 17);

@@ -79,39 +79,140 @@ __host__ __device__ inline int gwd_steps(int d) { return d + 2 <= 6 ? 3 : (d + 2
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// One block of the scaling pass of ONE cloud (blk = its index among the cloud's ceil(Npad / 256) blocks).  The block
-// first finishes the cloud statistics from the 64 partial sums itself (fixed order, so all blocks agree bit for bit;
-// no separate one-block kernel), then centres / scales one point per thread and writes both augmented forms,
-// dimension-major float32, zero points beyond N:  YA, YB = [2 * steps][Npad].
-// sigma^2 = mean ||a - abar||^2 = sum_k (E[x_k^2] - E[x_k]^2).
-__device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
-                                     const double *__restrict__ stat_cloud, double h, float *__restrict__ YA,
-                                     float *__restrict__ YB, double *smean, double *ssc) {
-    if (threadIdx.x < 32) {
-        const int k = threadIdx.x;
-        double sx = 0.0, sq = 0.0;
-        if (k < d) {
-            const double *p = stat_cloud + 2 * k;
-#pragma unroll 16
-            for (int j = 0; j < kStatBlocks; ++j) { sx += p[(size_t)j * (2 * kGwdMaxD)]; sq += p[(size_t)j * (2 * kGwdMaxD) + 1]; }
-        }
-        const double mean = sx / (double)N;
-        double var = (k < d) ? sq / (double)N - mean * mean : 0.0;
+// ---- The split form (r03): the same exponent matrix off the bfloat16 matrix pipe, 16x the float32 rate.
+// The float32 MFMA chain and the kernel's v_exp_f32 do not overlap on a SIMD (tools/microbench/gwd_tile_phases.hip: 31 us of
+// MFMA + 15 us of exponentials = 46 us per 12.5k x 14.4k pair, each alone hides behind the other's absence), so the
+// MFMA time itself had to shrink.  Every float32 operand is split EXACTLY into three bfloat16 terms, x = hi + mid + lo
+// (8 + 8 + 8 mantissa bits), and a product a * b is replaced by its six largest cross terms
+//     ah bh + ah bm + am bh + am bm + ah bl + al bh            (dropped: am bl + al bm + al bl < 2^-23 |a b|),
+// laid side by side along the inner dimension of v_mfma_f32_32x32x16_bf16 (exact products, float32 accumulation).  The two
+// norm-carrying steps (-|y_i|^2 * 1, -1 * |y_j|^2) need three terms each.  6 d + 6 slots: d = 4 -> 2 MFMA steps (it was
+// 3 float32 steps of twice the cycles), d = 14 -> 6 (it was 8).  Measured against the float64 oracle the cost keeps its
+// 5e-9-class relative error (tests/test_gpu_gwd*.py; a numpy model of both chains: 2.4e-9 float32, 3.7e-9 split).
+// Used for clouds of up to kGwdSplitMaxD dimensions; wider ones keep the float32 chain.
+constexpr int kGwdSplitMaxD = 15;
+__host__ __device__ inline int gwd_split_steps(int d) { return 6 * d + 6 <= 32 ? 2 : 6; }   // of 16 slots; d <= 4 / d <= 15
+__host__ __device__ inline bool gwd_use_split(int ds, int dt) { return ds <= kGwdSplitMaxD && dt <= kGwdSplitMaxD; }
+// bytes per point and form of the scaled cloud a tile kernel reads
+__host__ __device__ inline size_t gwd_form_bytes(int d, bool split) {
+    return split ? (size_t)gwd_split_steps(d) * 32 : (size_t)2 * gwd_steps(d) * sizeof(float);
+}
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ inline uint32_t gwd_bf16_bits(float x) {   // round to nearest even; the operands are finite
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// term t (0 hi, 1 mid, 2 lo) of the exact three-way split of x, as bfloat16 bits
+__device__ inline uint32_t gwd_split_term(float x, int t) {
+    const uint32_t h = gwd_bf16_bits(x);
+    if (t == 0) return h;
+    const float r1 = x - __uint_as_float(h << 16);          // exact
+    const uint32_t m = gwd_bf16_bits(r1);
+    if (t == 1) return m;
+    return gwd_bf16_bits(r1 - __uint_as_float(m << 16));    // exact difference, then the third rounding
+}
+// Chunk C (slots 8 C .. 8 C + 7) of one point, both forms.  xrow = its float64 coordinates, fin = the cloud's means and
+// scale.  Dimension k = sigma / 6 takes the term pattern (h h m m h l) x (h m h m l h); slots 6 d .. 6 d + 2 carry
+// (-nrm terms) x 1, slots 6 d + 3 .. 6 d + 5 carry -1 x (nrm terms), nrm = the squared norm of the ROUNDED float32
+// coordinates; anything behind is zero.  C is a compile-time value: a chunk reads the two or three coordinates its
+// slots belong to, and only the chunks that hold norm slots (wave-uniform test) read the whole row.
+template <int C>
+__device__ inline void gwd_split_chunk(const double *__restrict__ xrow, const double *__restrict__ fin, double sc, int d,
+                                       bool real, uint4 &za, uint4 &zb) {
+    constexpr int K0 = (8 * C) / 6, K1 = (8 * C + 7) / 6;   // dimensions the slots cover
+    float v[K1 - K0 + 1];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
-        smean[k] = mean;
-        if (k == 0) *ssc = sqrt(1.4426950408889634 / (2.0 * h * h * var));
+    for (int k = K0; k <= K1; ++k) v[k - K0] = (real && k < d) ? (float)((xrow[k] - fin[k]) * sc) : 0.0f;
+    float nrm = 0.0f;
+    if (8 * C + 7 >= 6 * d && real) {   // this chunk holds norm slots
+#pragma unroll
+        for (int k = 0; k < kGwdSplitMaxD; ++k)
+            if (k < d) { const float u = (float)((xrow[k] - fin[k]) * sc); nrm = fmaf(u, u, nrm); }
     }
-    __syncthreads();
+    uint32_t a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int sigma = 8 * C + e;
+        const int k = sigma / 6, t = sigma % 6;   // compile-time after unrolling
+        uint32_t av = 0u, bv = 0u;
+        if (real) {
+            if (sigma < 6 * d) {
+                const int ta = (t == 2 || t == 3) ? 1 : (t == 5 ? 2 : 0), tb = (t == 1 || t == 3) ? 1 : (t == 4 ? 2 : 0);
+                av = gwd_split_term(2.0f * v[k - K0], ta);
+                bv = gwd_split_term(v[k - K0], tb);
+            } else if (sigma < 6 * d + 6) {
+                const int j = sigma - 6 * d;   // 0 .. 5, wave-uniform
+                if (j < 3) { av = gwd_split_term(-nrm, j); bv = 0x3f80u; }   // x 1.0
+                else { av = 0xbf80u; bv = gwd_split_term(nrm, j - 3); }      // -1.0 x
+            }
+        }
+        a[e] = av; b[e] = bv;
+    }
+    za = make_uint4(a[0] | a[1] << 16, a[2] | a[3] << 16, a[4] | a[5] << 16, a[6] | a[7] << 16);
+    zb = make_uint4(b[0] | b[1] << 16, b[2] | b[3] << 16, b[4] | b[5] << 16, b[6] | b[7] << 16);
+}
+
+// The cloud statistics from the 64 partial sums, once per cloud (r03: every block of the scaling pass used to redo this
+// chain of 128 dependent loads): fin[k] = mean of dimension k, fin[kGwdMaxD] = sqrt(log2(e) / (2 h^2 sigma^2)).
+// sigma^2 = mean ||a - abar||^2 = sum_k (E[x_k^2] - E[x_k]^2).  One wave.
+__device__ inline void gwd_stats_finish_body(const double *__restrict__ stat_cloud, int64_t N, int d, double h,
+                                             double *__restrict__ fin) {
+    const int k = threadIdx.x;
+    if (k >= 32) return;
+    double sx = 0.0, sq = 0.0;
+    if (k < d) {
+        const double *p = stat_cloud + 2 * k;
+#pragma unroll 16
+        for (int j = 0; j < kStatBlocks; ++j) { sx += p[(size_t)j * (2 * kGwdMaxD)]; sq += p[(size_t)j * (2 * kGwdMaxD) + 1]; }
+    }
+    const double mean = sx / (double)N;
+    double var = (k < d) ? sq / (double)N - mean * mean : 0.0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    fin[k] = mean;
+    if (k == 0) fin[kGwdMaxD] = sqrt(1.4426950408889634 / (2.0 * h * h * var));
+}
+constexpr int kGwdFin = kGwdMaxD + 1;   // doubles per cloud behind the partial sums
+// grid (2), 64 threads
+__global__ __launch_bounds__(64) void k_gwd_stats_finish(const double *__restrict__ stat_partial, int64_t n, int ds, int64_t m, int dt,
+                                                        double h, double *__restrict__ fin) {
+    const int c = blockIdx.x;
+    gwd_stats_finish_body(stat_partial + (size_t)c * kStatBlocks * (2 * kGwdMaxD), c ? m : n, c ? dt : ds, h, fin + c * kGwdFin);
+}
+
+// One block of the scaling pass of ONE cloud (blk = its index among the cloud's ceil(Npad / 256) blocks): centres /
+// scales one point per thread (fin = the cloud's means and scale, gwd_stats_finish_body) and writes both forms, zero
+// points beyond N.  float32 form: dimension-major YA, YB = [2 * steps][Npad].  Split form: chunk `sub` of the point
+// (the launch spreads the chunks over blockIdx.z), ZA, ZB = [2 * split_steps][Npad] x 8 bfloat16, one 16-byte store each.
+__device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
+                                     const double *__restrict__ fin, bool split, int sub,
+                                     float *__restrict__ YA, float *__restrict__ YB) {
     const int64_t i = (int64_t)blk * kThreads + threadIdx.x;
     if (i >= Npad) return;
-    const double sc = *ssc;
+    const double sc = fin[kGwdMaxD];
     const int kp = 2 * gwd_steps(d);
     const bool real = i < N;
+    if (split) {
+        if (sub >= 2 * gwd_split_steps(d)) return;
+        const double *xrow = X + (real ? i : 0) * d;
+        uint4 za = make_uint4(0u, 0u, 0u, 0u), zb = za;
+        switch (sub) {   // wave-uniform
+#define GWD_CHUNK(C) case C: gwd_split_chunk<C>(xrow, fin, sc, d, real, za, zb); break;
+            GWD_CHUNK(0) GWD_CHUNK(1) GWD_CHUNK(2) GWD_CHUNK(3) GWD_CHUNK(4) GWD_CHUNK(5)
+            GWD_CHUNK(6) GWD_CHUNK(7) GWD_CHUNK(8) GWD_CHUNK(9) GWD_CHUNK(10) GWD_CHUNK(11)
+#undef GWD_CHUNK
+            default: break;
+        }
+        reinterpret_cast<uint4 *>(YA)[(int64_t)sub * Npad + i] = za;
+        reinterpret_cast<uint4 *>(YB)[(int64_t)sub * Npad + i] = zb;
+        return;
+    }
+    if (sub != 0) return;
     float nrm = 0.0f;
     for (int k = 0; k < d; ++k) {
         float v = 0.0f;
-        if (real) v = (float)((X[i * d + k] - smean[k]) * sc);
+        if (real) v = (float)((X[i * d + k] - fin[k]) * sc);
         nrm = fmaf(v, v, nrm);
         YA[(int64_t)k * Npad + i] = 2.0f * v;
         YB[(int64_t)k * Npad + i] = v;
@@ -123,17 +224,16 @@ __device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, in
     for (int k = d + 2; k < kp; ++k) { YA[(int64_t)k * Npad + i] = 0.0f; YB[(int64_t)k * Npad + i] = 0.0f; }
 }
 
-// grid (ceil(npad / 256) + ceil(mpad / 256)), 256 threads: both clouds in one launch.
+// grid (ceil(npad / 256) + ceil(mpad / 256), 1, Z), 256 threads: both clouds in one launch; Z = the chunks per point of the
+// split form (1 for the float32 form).  fin: [2][kGwdFin].
 __global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict__ Xs, int64_t n, int ds, int64_t npad,
                                                       const double *__restrict__ Xt, int64_t m, int dt, int64_t mpad,
-                                                      const double *__restrict__ stat_partial, double h, int sblocks,
+                                                      const double *__restrict__ fin, int sblocks,
                                                       float *__restrict__ YsA, float *__restrict__ YsB,
                                                       float *__restrict__ YtA, float *__restrict__ YtB) {
-    __shared__ double smean[kGwdMaxD];
-    __shared__ double ssc;
     const int c = (int)blockIdx.x >= sblocks ? 1 : 0;  // which cloud this block scales
     gwd_prep_body(c ? Xt : Xs, c ? m : n, c ? dt : ds, c ? mpad : npad, (int)blockIdx.x - (c ? sblocks : 0),
-                  stat_partial + (size_t)c * kStatBlocks * (2 * kGwdMaxD), h, c ? YtA : YsA, c ? YtB : YsB, smean, &ssc);
+                  fin + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z, c ? YtA : YsA, c ? YtB : YsB);
 }
 
 // Operands of one 32-point strip for v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3): lane l holds
@@ -159,7 +259,7 @@ struct GwdTileArgs {
     const float *YsA, *YsB, *YtA, *YtB;  // augmented clouds, [2 * steps][pad]
     int64_t n, m, npad, mpad;
     int32_t T, ntiles;
-    double *partial;  // [ntiles]
+    double *partial;  // [ntiles][kWaves]: one sum per wave of a tile's workgroup
 };
 
 // One workgroup (4 waves) per upper-triangular tile pair (bi <= bj) of the L x L grid, T = Lpad / kTile.
@@ -168,7 +268,7 @@ struct GwdTileArgs {
 // keeps the matrix pipe fed is the NUMBER of resident workgroups, not instruction-level overlap inside one (measured:
 // register-resident operands, double-buffered accumulators and multi-tile workgroups all lowered the occupancy and ran
 // 30-50 % slower).
-// partial[tile] = sum over the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
+// partial[tile][wave] = the sum over the wave's 32 rows of the tile of |Ks_pad - Kt_pad| (off-diagonal tiles counted twice).
 // NSS / NST: inner MFMA steps = gwd_steps(ds), gwd_steps(dt) (compile time).
 // waves per SIMD = workgroups per CU the tile kernels are compiled for
 #define GWD_WAVES(NSS, NST) ((NSS) + (NST) <= 11 ? 5 : 4)
@@ -183,13 +283,18 @@ struct GwdTileShape {
 struct GwdTilePos {
     int bi, bj;
 };
-// (bi, bj), bi <= bj, from the linear upper-triangular index (wave-uniform: scalar ALU; a closed form with a float
-// square root and 64-bit corrections was tried in r03 and cost the kernel 7 us)
+// (bi, bj), bi <= bj, from the linear upper-triangular index: row bi starts at tile bi T - bi (bi - 1) / 2.  A binary
+// search in scalar registers (wave-uniform; the r02 form walked the rows one by one, up to T scalar iterations per tile; a
+// closed form with a float square root and 64-bit corrections cost the kernel 7 us).
 __device__ inline GwdTilePos gwd_tile_pos(int T, int tile) {
-    int t = tile, bi = 0;
-    while (t >= T - bi) { t -= T - bi; ++bi; }
+    int lo = 0, hi = T - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int start = mid * T - ((mid * (mid - 1)) >> 1);
+        if (start <= tile) lo = mid; else hi = mid - 1;
+    }
     GwdTilePos q;
-    q.bi = bi; q.bj = bi + t;
+    q.bi = lo; q.bj = lo + (tile - (lo * T - ((lo * (lo - 1)) >> 1)));
     return q;
 }
 
@@ -228,10 +333,9 @@ __device__ inline void gwd_tile_stage(const float4 (&v)[GwdTileShape<NSS, NST>::
     }
 }
 
-// The tile's sum from the staged rows (the caller's barrier stands between the stage and this).  Ends with the barrier
-// that publishes the wave sums; thread 0 then stores partial[tile].
+// The tile's sums from the staged rows (the caller's barrier stands between the stage and this).
 template <int NSS, int NST>
-__device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTilePos q, const float *lds, double *red, int tid) {
+__device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTilePos q, const float *lds, int tid) {
     using S = GwdTileShape<NSS, NST>;
     const int64_t n = P.n, m = P.m;
     const int64_t i0 = (int64_t)q.bi * kTile, j0 = (int64_t)q.bj * kTile;
@@ -245,6 +349,9 @@ __device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTileP
     float sum = 0.0f;
     const int64_t lim = n < m ? n : m;
     const bool interior = j0 + kTile <= lim;  // every entry exists in both kernels
+    // behind the smaller cloud: the tile lies wholly inside the larger kernel's block and wholly in the other's padding
+    // (a quarter of the tiles of a 12.5k x 14.4k pair; they went through the masked path until r03)
+    const bool one_sided = (has_s != has_t) && j0 + kTile <= (n > m ? n : m);
 #pragma unroll 1
     for (int cb = 0; cb < 4; ++cb) {
         float bs[NSS], bt[NST];
@@ -254,6 +361,9 @@ __device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTileP
         if (interior) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += fabsf(__builtin_amdgcn_exp2f(es[r]) - __builtin_amdgcn_exp2f(et[r]));
+        } else if (one_sided) {   // one kernel covers the whole tile, the other is all padding here: K >= 0, no |.|
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(has_s ? es[r] : et[r]);
         } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
             const int64_t gj = j0 + cb * 32 + (lane & 31);
 #pragma unroll
@@ -265,24 +375,23 @@ __device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTileP
             }
         }
     }
-    // wave sums in float64 (DPP-free butterfly), one LDS word per wave, one store per tile
+    // the wave's sum in float64 (DPP-free butterfly), one store per wave: no LDS word, no closing barrier (r03; the
+    // finishing kernel adds four numbers per tile instead of one)
     double d = (double)sum;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    if (lane == 0) red[wave] = d;
-    __syncthreads();
-    if (tid == 0) P.partial[tile] = (q.bi == q.bj ? 1.0 : 2.0) * (((red[0] + red[1]) + red[2]) + red[3]);
+    if (lane == 0) P.partial[(size_t)tile * kWaves + wave] = (q.bi == q.bj ? 1.0 : 2.0) * d;
 }
 
 // One tile, start to end (the unit the microbenchmark times).
 template <int NSS, int NST>
-__device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds, double *red, int tid) {
+__device__ inline void gwd_tile_body(const GwdTileArgs &P, int tile, float *lds, int tid) {
     const GwdTilePos q = gwd_tile_pos(P.T, tile);
     float4 v[GwdTileShape<NSS, NST>::NIT];
     gwd_tile_fetch<NSS, NST>(P, q, tid, v);
     gwd_tile_stage<NSS, NST>(v, lds, tid);
     __syncthreads();
-    gwd_tile_compute<NSS, NST>(P, tile, q, lds, red, tid);
+    gwd_tile_compute<NSS, NST>(P, tile, q, lds, tid);
 }
 
 // grid (ntiles): one workgroup per tile.  (r03 measured the alternatives once more -- a resident grid striding over the
@@ -293,8 +402,112 @@ template <int NSS, int NST>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GWD_WAVES(NSS, NST))))
 void k_gwd_tiles(GwdTileArgs P) {
     extern __shared__ float lds[];  // As[KPS][kTile] Bs At[KPT][kTile] Bt
-    __shared__ double red[kWaves];
-    gwd_tile_body<NSS, NST>(P, (int)blockIdx.x, lds, red, (int)threadIdx.x);
+    gwd_tile_body<NSS, NST>(P, (int)blockIdx.x, lds, (int)threadIdx.x);
+}
+
+// ---- split-form tiles.  MS / MT = gwd_split_steps(ds), gwd_split_steps(dt).  The column tile's operands are staged in
+// LDS ([MS + MT][2 k-halves][128 points] x 16 bytes, conflict-free ds_read_b128); the wave's own 32 rows come straight
+// from L2 into registers, one 16-byte load per step (a lane's operand of v_mfma_f32_32x32x16_bf16: point l & 31, slots
+// 8 (l >> 5) .. + 8).
+template <int MS, int MT>
+__device__ inline void gwd_tile_body_split(const GwdTileArgs &P, int tile, uint4 *lds, int tid) {
+    constexpr int CH = 2 * (MS + MT);                         // 16-byte chunks per point
+    constexpr int NV = CH * kTile, NIT = (NV + kThreads - 1) / kThreads;
+    const GwdTilePos q = gwd_tile_pos(P.T, tile);
+    const int64_t n = P.n, m = P.m;
+    const int64_t i0 = (int64_t)q.bi * kTile, j0 = (int64_t)q.bj * kTile;
+    const bool has_s = j0 < n, has_t = j0 < m;
+    const uint4 *zsa = reinterpret_cast<const uint4 *>(P.YsA), *zsb = reinterpret_cast<const uint4 *>(P.YsB);
+    const uint4 *zta = reinterpret_cast<const uint4 *>(P.YtA), *ztb = reinterpret_cast<const uint4 *>(P.YtB);
+    const int64_t npad = P.npad, mpad = P.mpad;
+    const int lane = tid & 63, wave = tid >> 6, r0 = wave * 32;
+    {
+        uint4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * kThreads, c = e / kTile, pt = e % kTile;
+            v[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < NV) {
+                const bool s_row = c < 2 * MS;
+                if (s_row ? has_s : has_t)
+                    v[it] = s_row ? zsb[(int64_t)c * npad + j0 + pt] : ztb[(int64_t)(c - 2 * MS) * mpad + j0 + pt];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * kThreads;
+            if (e < NV) lds[e] = v[it];
+        }
+    }
+    // the wave's rows (issued before the barrier: their latency overlaps the stage)
+    bf16x8 as[MS], at[MT];
+    {
+        const int64_t row = i0 + r0 + (lane & 31);
+        const int kh = lane >> 5;
+#pragma unroll
+        for (int s_ = 0; s_ < MS; ++s_) {
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (has_s) w = zsa[(int64_t)(2 * s_ + kh) * npad + row];
+            __builtin_memcpy(&as[s_], &w, 16);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < MT; ++s_) {
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (has_t) w = zta[(int64_t)(2 * s_ + kh) * mpad + row];
+            __builtin_memcpy(&at[s_], &w, 16);
+        }
+    }
+    __syncthreads();
+    const bf16x8 *B = reinterpret_cast<const bf16x8 *>(lds);
+    float sum = 0.0f;
+    const int64_t lim = n < m ? n : m;
+    const bool interior = j0 + kTile <= lim;  // every entry exists in both kernels
+    // behind the smaller cloud: the tile lies wholly inside the larger kernel's block and wholly in the other's padding
+    // (a quarter of the tiles of a 12.5k x 14.4k pair; they went through the masked path until r03)
+    const bool one_sided = (has_s != has_t) && j0 + kTile <= (n > m ? n : m);
+#pragma unroll 1
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = cb * 32 + (lane & 31), kh = lane >> 5;
+        f32x16 es, et;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { es[r] = 0.0f; et[r] = 0.0f; }
+        if (has_s) {
+#pragma unroll
+            for (int s_ = 0; s_ < MS; ++s_)
+                es = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[s_], B[(2 * s_ + kh) * kTile + col], es, 0, 0, 0);
+        }
+        if (has_t) {
+#pragma unroll
+            for (int s_ = 0; s_ < MT; ++s_)
+                et = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[s_], B[(2 * (MS + s_) + kh) * kTile + col], et, 0, 0, 0);
+        }
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += fabsf(__builtin_amdgcn_exp2f(es[r]) - __builtin_amdgcn_exp2f(et[r]));
+        } else if (one_sided) {   // one kernel covers the whole tile, the other is all padding here: K >= 0, no |.|
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(has_s ? es[r] : et[r]);
+        } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
+            const int64_t gj = j0 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gi = i0 + r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(es[r]) : 0.0f;
+                const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(et[r]) : 0.0f;
+                sum += fabsf(a - bb);
+            }
+        }
+    }
+    double d = (double)sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) P.partial[(size_t)tile * kWaves + wave] = (q.bi == q.bj ? 1.0 : 2.0) * d;
+}
+
+template <int MS, int MT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MS + MT <= 8 ? 5 : 4))) void k_gwd_tiles_split(GwdTileArgs P) {
+    extern __shared__ uint4 lds4[];
+    gwd_tile_body_split<MS, MT>(P, (int)blockIdx.x, lds4, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------- batched solves
@@ -306,7 +519,7 @@ void k_gwd_tiles(GwdTileArgs P) {
 struct GwdPair {
     GwdTileArgs a;          // a.partial points at this pair's first tile sum
     const double *Xs, *Xt;
-    double *stat;           // [2][kStatBlocks][2 * kGwdMaxD]
+    double *stat;           // [2][kStatBlocks][2 * kGwdMaxD] partial sums, then [2][kGwdFin] final statistics
     int64_t tile0;          // first tile of the pair in the concatenated list
 };
 
@@ -335,13 +548,13 @@ __host__ __device__ inline GwdBatchLayout gwd_batch_layout(int P, int ds, int dt
     size_t o = 0;
     L.off_pairs = o;  o += up((size_t)P * sizeof(GwdPair));
     L.off_total = o;  o += 256;
-    L.stat_stride = up((size_t)2 * kStatBlocks * 2 * kGwdMaxD * sizeof(double));
+    L.stat_stride = up(((size_t)2 * kStatBlocks * 2 * kGwdMaxD + 2 * kGwdFin) * sizeof(double));   // partial sums + final statistics
     L.off_stat = o;   o += (size_t)P * L.stat_stride;
-    L.ys_bytes = up((size_t)2 * gwd_steps(ds) * gwd_pad_tile(n_cap) * sizeof(float));
-    L.yt_bytes = up((size_t)2 * gwd_steps(dt) * gwd_pad_tile(m_cap) * sizeof(float));
+    L.ys_bytes = up(gwd_form_bytes(ds, gwd_use_split(ds, dt)) * (size_t)gwd_pad_tile(n_cap));
+    L.yt_bytes = up(gwd_form_bytes(dt, gwd_use_split(ds, dt)) * (size_t)gwd_pad_tile(m_cap));
     L.y_stride = 2 * L.ys_bytes + 2 * L.yt_bytes;
     L.off_y = o;      o += (size_t)P * L.y_stride;
-    L.partial_stride = (size_t)(T * (T + 1) / 2);
+    L.partial_stride = (size_t)(T * (T + 1) / 2) * kWaves;
     L.off_partial = o; o += up((size_t)P * L.partial_stride * sizeof(double));
     L.bytes = o;
     return L;
@@ -386,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void k_gwd_batch_setup(GwdBatchArgs B) {
             q.a.n = n; q.a.m = m;
             q.a.npad = gwd_pad_tile(n > 0 ? n : 1); q.a.mpad = gwd_pad_tile(m > 0 ? m : 1);
             q.a.T = T; q.a.ntiles = (int32_t)nt;
-            q.a.partial = B.partial + tile0;
+            q.a.partial = B.partial + tile0 * kWaves;
             q.Xs = B.Xs + (B.xs_row ? B.xs_row[p] : (int64_t)p * B.n_cap) * B.ds;
             q.Xt = B.Xt + (B.xt_row ? B.xt_row[p] : (int64_t)p * B.m_cap) * B.dt;
             q.stat = reinterpret_cast<double *>(B.scratch + L.off_stat + (size_t)p * L.stat_stride);
@@ -410,11 +623,17 @@ __global__ __launch_bounds__(kThreads) void k_gwd_stats_batch(const GwdPair *__r
                    q.stat + (size_t)blockIdx.y * kStatBlocks * (2 * kGwdMaxD), red);
 }
 
-// grid (sblocks_cap + tblocks_cap, P): the scaling pass of pair blockIdx.y; blocks beyond the pair's own paddings leave
-__global__ __launch_bounds__(kThreads) void k_gwd_prep_batch(const GwdPair *__restrict__ pairs, int ds, int dt, double h,
-                                                            int sblocks_cap) {
-    __shared__ double smean[kGwdMaxD];
-    __shared__ double ssc;
+// grid (2, P), 64 threads: the final statistics of cloud blockIdx.x of pair blockIdx.y, behind its partial sums
+__global__ __launch_bounds__(64) void k_gwd_stats_finish_batch(const GwdPair *__restrict__ pairs, int ds, int dt, double h) {
+    const GwdPair &q = pairs[blockIdx.y];
+    if (q.a.ntiles == 0) return;
+    const int c = blockIdx.x;
+    gwd_stats_finish_body(q.stat + (size_t)c * kStatBlocks * (2 * kGwdMaxD), c ? q.a.m : q.a.n, c ? dt : ds, h,
+                          q.stat + (size_t)2 * kStatBlocks * (2 * kGwdMaxD) + c * kGwdFin);
+}
+
+// grid (sblocks_cap + tblocks_cap, P, Z): the scaling pass of pair blockIdx.y; blocks beyond the pair's own paddings leave
+__global__ __launch_bounds__(kThreads) void k_gwd_prep_batch(const GwdPair *__restrict__ pairs, int ds, int dt, int sblocks_cap) {
     const GwdPair &q = pairs[blockIdx.y];
     if (q.a.ntiles == 0) return;
     const int c = (int)blockIdx.x >= sblocks_cap ? 1 : 0;
@@ -422,8 +641,8 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep_batch(const GwdPair *__re
     const int64_t Npad = c ? q.a.mpad : q.a.npad;
     if ((int64_t)blk * kThreads >= Npad) return;
     gwd_prep_body(c ? q.Xt : q.Xs, c ? q.a.m : q.a.n, c ? dt : ds, Npad, blk,
-                  q.stat + (size_t)c * kStatBlocks * (2 * kGwdMaxD), h, const_cast<float *>(c ? q.a.YtA : q.a.YsA),
-                  const_cast<float *>(c ? q.a.YtB : q.a.YsB), smean, &ssc);
+                  q.stat + (size_t)2 * kStatBlocks * (2 * kGwdMaxD) + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z,
+                  const_cast<float *>(c ? q.a.YtA : q.a.YsA), const_cast<float *>(c ? q.a.YtB : q.a.YsB));
 }
 
 // A pair's table entry as wave-uniform values.  Inside the tile loop (global stores, barriers) the compiler cannot prove
@@ -449,12 +668,22 @@ template <int NSS, int NST>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GWD_WAVES(NSS, NST))))
 void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs) {
     extern __shared__ float lds[];
-    __shared__ double red[kWaves];
     GwdTileArgs a;
     int64_t tile0;
     gwd_load_pair_uniform(pairs + blockIdx.y, a, tile0);
     if ((int)blockIdx.x >= a.ntiles) return;
-    gwd_tile_body<NSS, NST>(a, (int)blockIdx.x, lds, red, (int)threadIdx.x);
+    gwd_tile_body<NSS, NST>(a, (int)blockIdx.x, lds, (int)threadIdx.x);
+}
+
+template <int MS, int MT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MS + MT <= 8 ? 5 : 4)))
+void k_gwd_tiles_split_batch(const GwdPair *__restrict__ pairs) {
+    extern __shared__ uint4 lds4[];
+    GwdTileArgs a;
+    int64_t tile0;
+    gwd_load_pair_uniform(pairs + blockIdx.y, a, tile0);
+    if ((int)blockIdx.x >= a.ntiles) return;
+    gwd_tile_body_split<MS, MT>(a, (int)blockIdx.x, lds4, (int)threadIdx.x);
 }
 
 // grid (P), 1024 threads: k_gwd_finish of pair blockIdx.x (the same fixed summation order as the single solve, so a
@@ -462,7 +691,7 @@ void k_gwd_tiles_batch(const GwdPair *__restrict__ pairs) {
 __global__ __launch_bounds__(1024) void k_gwd_finish_batch(const GwdPair *__restrict__ pairs, double *__restrict__ costs) {
     __shared__ double red[16];
     const GwdPair &q = pairs[blockIdx.x];
-    const int count = q.a.ntiles;
+    const int count = q.a.ntiles * kWaves;
     if (count == 0) { if (threadIdx.x == 0) costs[blockIdx.x] = __longlong_as_double(0x7ff8000000000000ll); return; }
     const double *partial = q.a.partial;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     const int tid = threadIdx.x, tile = blockIdx.x;
     const long long t0 = wall_clock64();
     if (VAR == 0) {
-        gwd_tile_body<NSS, NST>(P, tile, lds, red, tid);
+        gwd_tile_body<NSS, NST>(P, tile, lds, tid);
     } else {
         constexpr int KPS = 2 * NSS, KPT = 2 * NST;
         int t = tile, bi = 0;
@@ -219,7 +219,7 @@ int main(int argc, char **argv) {
     GwdTileArgs P;
     P.YsA = YsA; P.YsB = YsB; P.YtA = YtA; P.YtB = YtB; P.n = n; P.m = m; P.npad = npad; P.mpad = mpad;
     P.T = (int)(mpad / kTile); P.ntiles = P.T * (P.T + 1) / 2;
-    CK(hipMalloc(&partial, P.ntiles * 8)); CK(hipMalloc(&marks, P.ntiles * 8));
+    CK(hipMalloc(&partial, (size_t)P.ntiles * 4 * 8)); CK(hipMalloc(&marks, P.ntiles * 8));
     P.partial = partial;
     size_t lds = (size_t)(2 * 2 * NSS + 2 * 2 * NST) * kTile * 4;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -254,6 +254,34 @@ int main(int argc, char **argv) {
     report("cand: 11 MFMA, 32 poly", k_cand<NSS, NST, false, 32>);
     report("cand: 9 MFMA, 16 poly", k_cand<NSS, NST, true, 16>);
     report("cand: 9 MFMA, 24 poly", k_cand<NSS, NST, true, 24>);
+    {   // the library's split-form kernel itself (operands: small random bfloat16 patterns)
+        GwdTileArgs Q = P;
+        uint16_t *z[4];
+        const size_t sb = (size_t)2 * 2 * npad * 8, tb = (size_t)2 * 6 * mpad * 8;   // bfloat16 elements per form
+        std::vector<uint16_t> hz(tb);
+        for (int f = 0; f < 4; ++f) {
+            const size_t cnt = f < 2 ? sb : tb;
+            for (size_t i = 0; i < cnt; ++i) hz[i] = (uint16_t)(0x3c00 + (rand() & 0xff) + ((rand() & 1) << 15));   // |x| ~ 0.008
+            CK(hipMalloc(&z[f], cnt * 2));
+            CK(hipMemcpy(z[f], hz.data(), cnt * 2, hipMemcpyHostToDevice));
+        }
+        Q.YsA = reinterpret_cast<float *>(z[0]); Q.YsB = reinterpret_cast<float *>(z[1]);
+        Q.YtA = reinterpret_cast<float *>(z[2]); Q.YtB = reinterpret_cast<float *>(z[3]);
+        double *part4; CK(hipMalloc(&part4, (size_t)P.ntiles * 4 * 8));
+        Q.partial = part4;
+        auto kern = k_gwd_tiles_split<2, 6>;
+        const size_t l2 = (size_t)2 * (2 + 6) * kTile * 16;
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kThreads, l2));
+        for (int i = 0; i < 3; ++i) kern<<<P.ntiles, kThreads, l2>>>(Q);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a));
+        for (int i = 0; i < 10; ++i) kern<<<P.ntiles, kThreads, l2>>>(Q);
+        CK(hipEventRecord(b));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("k_gwd_tiles_split<2, 6>      %7.1f us per launch, %d workgroups/CU (occupancy query)\n", ms * 100.0, occ);
+    }
     lds = (size_t)(2 + 6) * 2 * kTile * 16;
     report("bf16x3 compute (2 + 6 MFMA)", k_bf<2, 6, true>);
     report("bf16x3 compute, no exp", k_bf<2, 6, false>);
