@@ -72,8 +72,9 @@ SYMBOLS = {
     "evrep_gwd_padded_l1": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _f64, _vp, _vp, _vp]),
     "evrep_gwd_batch_scratch_bytes": (ctypes.c_size_t, [_i32, _i32, _i32, _i64, _i64]),
     "evrep_gwd_padded_l1_batch": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i64, _f64, _vp, _vp, _vp]),
-    "evrep_otmi_event_clouds": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "evrep_otmi_rep_clouds": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "evrep_otmi_scratch_bytes": (ctypes.c_size_t, [_i32]),
+    "evrep_otmi_event_clouds": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "evrep_otmi_rep_clouds": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 
 # evrep_plan_init_ex flags.  The C library reads no environment variable; the A/B switches of the tests and tools

@@ -814,27 +814,48 @@ int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row
     return EVREP_OK;
 }
 
+size_t evrep_otmi_scratch_bytes(int32_t count) {
+    if (count <= 0) return 0;
+    const size_t a = otmi_ev_scratch_bytes(count), b = otmi_rep_scratch_bytes(count);
+    return up256(a > b ? a : b);
+}
+
 int evrep_otmi_event_clouds(const int32_t *events, const int64_t *offsets, int32_t B, int32_t height, int32_t width,
-                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *stream_) {
-    if (!events || !offsets || !Xs || !n_out || !quad_out || B <= 0 || B > 65535 || height <= 1 || width <= 1 || cap <= 0)
+                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *scratch, void *stream_) {
+    if (!events || !offsets || !Xs || !n_out || !quad_out || !scratch || B <= 0 || B > 65535 || height <= 1 || width <= 1 || cap <= 0)
         return EVREP_EINVAL;
-    if (reinterpret_cast<uintptr_t>(events) & 15u) return EVREP_EINVAL;
-    k_otmi_events<<<B, kOtmiThreads, 0, static_cast<hipStream_t>(stream_)>>>(reinterpret_cast<const int4 *>(events), offsets,
-                                                                            height, width, cap, Xs, n_out, quad_out);
-    LAUNCH_CHECK("k_otmi_events");
+    if ((reinterpret_cast<uintptr_t>(events) & 15u) || (reinterpret_cast<uintptr_t>(scratch) & 15u)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int4 *ev = reinterpret_cast<const int4 *>(events);
+    const OtmiEvScratch w = otmi_ev_scratch(scratch, B);
+    const dim3 grid(kOtmiEvSlices, B);
+    k_otmi_ev_stats<<<grid, kOtmiThreads, 0, stream>>>(ev, offsets, height, width, w);
+    LAUNCH_CHECK("k_otmi_ev_stats");
+    k_otmi_ev_plan<<<B, 64, 0, stream>>>(w, quad_out);
+    LAUNCH_CHECK("k_otmi_ev_plan");
+    k_otmi_ev_rows<false><<<grid, kOtmiThreads, 0, stream>>>(ev, offsets, height, width, cap, w, Xs, n_out);
+    LAUNCH_CHECK("k_otmi_ev_rows<count>");
+    k_otmi_ev_rows<true><<<grid, kOtmiThreads, 0, stream>>>(ev, offsets, height, width, cap, w, Xs, n_out);
+    LAUNCH_CHECK("k_otmi_ev_rows<write>");
     return EVREP_OK;
 }
 
 int evrep_otmi_rep_clouds(const void *rep, int32_t rep_dtype, int32_t items, int32_t B, int32_t S, int32_t C,
-                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *stream_) {
-    if (!rep || !quad || !Xt || !m_out || items <= 0 || items > 65535 || B <= 0 || S < 4 || C <= 0 || C + 2 > kGwdMaxD || m_cap <= 0)
+                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *scratch, void *stream_) {
+    if (!rep || !quad || !Xt || !m_out || !scratch || items <= 0 || items > 65535 || B <= 0 || S < 4 || C <= 0 || C + 2 > kGwdMaxD || m_cap <= 0)
         return EVREP_EINVAL;
     if (rep_dtype != EVREP_F64 && rep_dtype != EVREP_F32) return EVREP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(scratch) & 15u) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (rep_dtype == EVREP_F64)
-        k_otmi_rep<double><<<dim3(3, items), kOtmiThreads, 0, stream>>>(static_cast<const double *>(rep), B, S, C, quad, m_cap, Xt, m_out);
-    else
-        k_otmi_rep<float><<<dim3(3, items), kOtmiThreads, 0, stream>>>(static_cast<const float *>(rep), B, S, C, quad, m_cap, Xt, m_out);
+    uint32_t *cnt = static_cast<uint32_t *>(scratch);
+    const dim3 grid(kOtmiRepSlices, 3, items);
+#define OTMI_REP(T)                                                                                                          \
+    do {                                                                                                                     \
+        k_otmi_rep<T, false><<<grid, kOtmiThreads, 0, stream>>>(static_cast<const T *>(rep), B, S, C, quad, m_cap, cnt, Xt, m_out); \
+        k_otmi_rep<T, true><<<grid, kOtmiThreads, 0, stream>>>(static_cast<const T *>(rep), B, S, C, quad, m_cap, cnt, Xt, m_out);  \
+    } while (0)
+    if (rep_dtype == EVREP_F64) OTMI_REP(double); else OTMI_REP(float);
+#undef OTMI_REP
     LAUNCH_CHECK("k_otmi_rep");
     return EVREP_OK;
 }

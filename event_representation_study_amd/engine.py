@@ -516,9 +516,10 @@ def otmi_event_clouds(events, offsets, height, width, cap=None, workspace=None):
     Xs = ws.typed("otmi_xs", (B, 3, int(cap), 4), torch.float64)
     n = ws.typed("otmi_n", (B, 3), torch.int64)
     quad = ws.typed("otmi_quad", (B, 3), torch.int32)
+    scratch = ws.typed("otmi_ev_scratch", (int(lib.evrep_otmi_scratch_bytes(B)),), torch.uint8)
     with torch.cuda.device(dev):
         check(lib.evrep_otmi_event_clouds(_ptr(events), _ptr(off_dev), B, int(height), int(width), int(cap), _ptr(Xs),
-                                          _ptr(n), _ptr(quad), _stream_ptr()), "evrep_otmi_event_clouds")
+                                          _ptr(n), _ptr(quad), _ptr(scratch), _stream_ptr()), "evrep_otmi_event_clouds")
     return Xs, n, quad
 
 
@@ -538,9 +539,10 @@ def otmi_rep_clouds(reps, quad, B, workspace=None, slot="otmi_xt"):
     Xt = ws.typed(slot, (items, 3, m_cap, C + 2), torch.float64)
     m = ws.typed(slot + "_m", (items, 3), torch.int64)
     dt = {torch.float64: _lib.F64, torch.float32: _lib.F32}[reps.dtype]
+    scratch = ws.typed("otmi_rep_scratch", (int(lib.evrep_otmi_scratch_bytes(items)),), torch.uint8)
     with torch.cuda.device(dev):
         check(lib.evrep_otmi_rep_clouds(_ptr(reps), dt, items, int(B), S, C, _ptr(quad), int(m_cap), _ptr(Xt), _ptr(m),
-                                        _stream_ptr()), "evrep_otmi_rep_clouds")
+                                        _ptr(scratch), _stream_ptr()), "evrep_otmi_rep_clouds")
     return Xt, m, m_cap
 
 

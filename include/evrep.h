@@ -261,11 +261,14 @@ int evrep_gwd_padded_l1_batch(int32_t P, const double *Xs, const int64_t *xs_row
  * evrep_otmi_rep_clouds: rep DEVICE (items, S, S, C) letterboxed representations, item i belongs to window i % B ->
  *   for slot k the cut of quadrant quad[i % B][k] (:150-155,177-179), two positional channels (:181-198), rows with
  *   sum |feat| > 0 (:200-202): Xt DEVICE double [items][3][m_cap][C+2], m_out DEVICE int64 [items][3];
- *   m_cap >= (S - S/2 + 1)^2. */
+ *   m_cap >= (S - S/2 + 1)^2.
+ * Both cut their input into slices, one workgroup each, that meet through `scratch`: DEVICE, 16-byte aligned, of
+ * evrep_otmi_scratch_bytes(B) / evrep_otmi_scratch_bytes(items) bytes (no initialisation needed). */
+size_t evrep_otmi_scratch_bytes(int32_t windows_or_items);
 int evrep_otmi_event_clouds(const int32_t *events, const int64_t *offsets, int32_t B, int32_t height, int32_t width,
-                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *stream);
+                            int64_t cap, double *Xs, int64_t *n_out, int32_t *quad_out, void *scratch, void *stream);
 int evrep_otmi_rep_clouds(const void *rep, int32_t rep_dtype, int32_t items, int32_t B, int32_t S, int32_t C,
-                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *stream);
+                          const int32_t *quad, int64_t m_cap, double *Xt, int64_t *m_out, void *scratch, void *stream);
 
 /* Per-channel resize of a channel-last representation (B,H,W,C) -> (B,Ho,Wo,C), what resize_image /
  * resize_image_process do with cv2.resize per channel before a representation is stored or scored
