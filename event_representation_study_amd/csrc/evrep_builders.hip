@@ -703,22 +703,25 @@ __device__ inline void sparse_store(const OutT *vlist, const unsigned char *map,
 // so the segment walks read LDS with ds_read instead of flat loads through a two-address-space pointer.
 // `nseg_pre` >= 0: the front end has listed the segments already (UnitRecs::nseg).
 template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename RecStaged, typename PostHeads, typename Reduce>
-__device__ inline void emit_core(uint32_t nrec, int nseg_pre, KeyAt key_at, RecAt get, RecStaged get_staged, PostHeads post_heads,
-                                 int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg,
-                                 Reduce reduce) {
+__device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, KeyAt key_at, RecAt get, RecStaged get_staged,
+                                 PostHeads post_heads, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
+                                 const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const int PP = w.partpx;  // pixels per part tile (wave-uniform)
     constexpr int V = 16 / (int)sizeof(OutT);
-    // units of <= 64 records (<= 64 non-empty pixels) leave through the sparse emit when a pixel is a whole number of
-    // 16-byte vectors; the others through the part tiles
-    const bool sparse = EVREP_SPARSE_EMIT && (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 &&
-                        (bg == nullptr || bg == w.bg) &&
-                        nrec <= (uint32_t)min(kWave, PP);   // the value list lives in the part tile: PP entries
+    // units of <= 64 NON-EMPTY PIXELS leave through the sparse emit when a pixel is a whole number of 16-byte vectors; the
+    // others through the part tiles.  <= 64 records settle it at once; a unit of up to two staged batches (the reference's
+    // own Gen1 shape: ~69 records in ~53 pixels) is decided once its segment heads are counted (r03).
+    const bool sparse_ok = EVREP_SPARSE_EMIT && (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0 &&
+                           (bg == nullptr || bg == w.bg);
+    const int sparse_cap = min(kWave, PP);   // the value list lives in the part tile: PP entries, one lane each
+    const bool sparse_late = sparse_ok && nrec > (uint32_t)sparse_cap && nrec <= 2u * kWave && all_staged;
+    bool sparse = sparse_ok && nrec <= (uint32_t)sparse_cap;
     // a zero tile is filled at once (it overlaps the record load); a background that had to be
     // loaded is filled after the segment heads are listed, when it has arrived behind the records
-    if (!sparse && (!bg || nrec == 0)) tile_fill(w.tile, min(PP, npix), C, bg);
+    if (!sparse && !sparse_late && (!bg || nrec == 0)) tile_fill(w.tile, min(PP, npix), C, bg);
     const uint32_t empty4 = (uint32_t)PP * 0x01010101u;   // four map bytes naming the background entry
-    if (sparse && !bg && lane * V < EVREP_MAX_CHANNELS)   // a zero background: entry PP = w.bg has to hold it
+    if ((sparse || sparse_late) && !bg && lane * V < EVREP_MAX_CHANNELS)   // a zero background: entry PP = w.bg has to hold it
         reinterpret_cast<float4 *>(w.bg)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (nrec == 0) {  // empty chunk: the background is streamed for every pixel
         if (sparse) {
@@ -760,7 +763,8 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, KeyAt key_at, RecA
         if (nseg > w.segcap) nseg = w.segcap;  // cannot happen: a unit never holds more distinct pixels
         if (lane == 0) w.segs[nseg] = make_uint2(0u, nrec);
     }
-    if (bg && !sparse) tile_fill(w.tile, min(PP, npix), C, bg);
+    if (sparse_late) sparse = nseg <= sparse_cap;   // wave-uniform
+    if (!sparse && (bg || sparse_late)) tile_fill(w.tile, min(PP, npix), C, bg);
     wave_phase();
     post_heads();
     w.mark(2);
@@ -883,7 +887,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
             wave_phase();
         }
     };
-    emit_core<OutT, CMAX>(nrec, u.nseg, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
+    emit_core<OutT, CMAX>(nrec, u.nseg, nrec <= nst, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
 }
 template <typename OutT, int CMAX, typename Digest, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
