@@ -16,3 +16,5 @@ grep "^{" $O/gwd_matrix24.log | tail -1 > $P/gwd_matrix_24windows.json || true
 cp $O/est_bench.json $O/gw_bench_f64.json $O/gw_bench_f32.json $O/precompute.json $P/
 python tools/parse_pmc.py $P/pmc_fetch_counter_collection.csv $P/pmc_write_counter_collection.csv profiles/traffic.json > /dev/null
 cp profiles/traffic.json $P/traffic.json
+grep -v amdgpu.ids $O/gwd_tile_phases.txt > $P/gwd_tile_phases.txt || true
+for f in phase_times phase_times_dense phase_times_gen1; do grep -v amdgpu.ids $O/$f.txt > $P/$f.txt || true; done

@@ -21,7 +21,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/b_sq -o pmc_builders_sq -- python $R/tools/pmc_builders_workload.py > $O/b_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/b_fetch -o pmc_builders_fetch -- python $R/tools/pmc_builders_workload.py > $O/b_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/b_write -o pmc_builders_write -- python $R/tools/pmc_builders_workload.py > $O/b_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gwd_sq -o pmc_gwd -- python $R/tools/gwd_batch_prof.py 36 > $O/gwd_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gwd_sq -o pmc_gwd -- python $R/tools/gwd_batch_prof.py 36 > $O/gwd_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gwd_kt -o gwd -- python $R/tools/gwd_batch_prof.py 144 > $O/gwd_kt.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/gw_sq -o pmc_gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gw_kt -o gw -- python $R/tools/gw_bench.py --outer 1 --sinkhorn 5 > $O/gw_kt.log 2>&1
@@ -34,5 +34,9 @@ python tools/est_bench.py > $O/est_bench.json 2>/dev/null
 python tools/gw_bench.py > $O/gw_bench_f64.json 2>/dev/null
 python tools/gw_bench.py --precision f32 > $O/gw_bench_f32.json 2>/dev/null
 python tools/precompute_reps.py --samples 1024 2>/dev/null | grep "^{" > $O/precompute.json
+tools/microbench/gwd_tile_phases > $O/gwd_tile_phases.txt 2>&1
+EVREP_LIB_PATH=tools/ab/libevrep_timing.so SHAPE=640,480,500000,8 NBUF=1 python tools/experiments/phase_times.py 0 > $O/phase_times_dense.txt 2>&1
+EVREP_LIB_PATH=tools/ab/libevrep_timing.so SHAPE=304,240,50000,32 NBUF=1 python tools/experiments/phase_times.py 0 > $O/phase_times_gen1.txt 2>&1
+EVREP_LIB_PATH=tools/ab/libevrep_timing.so NBUF=2 python tools/experiments/phase_times.py 0 690 > $O/phase_times.txt 2>&1
 find $O -name "*.csv" | head -40
 tail -c 900 $O/bench.json
