@@ -804,7 +804,10 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
         if (lane < nseg) {
             const uint2 sg = w.segs[lane];
             px = (int)sg.x;
-            if (px >= 0 && px < npix) reduce(sg.y, w.segs[lane + 1].y, get, vals); else px = -1;
+            if (px >= 0 && px < npix) {
+                // a fully staged unit walks LDS (ds_read); the two-source form reads through a generic pointer (flat_load)
+                if (all_staged) reduce(sg.y, w.segs[lane + 1].y, get_staged, vals); else reduce(sg.y, w.segs[lane + 1].y, get, vals);
+            } else px = -1;
         }
         for (int part = 0; part * PP < npix; ++part) {
             const int np = min(PP, npix - part * PP);
@@ -841,7 +844,7 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
                 const int q = (int)sg.x - part * PP;
                 if (q < 0 || q >= np) continue;
                 OutT vals[CMAX];
-                reduce(sg.y, w.segs[k + 1].y, get, vals);
+                if (all_staged) reduce(sg.y, w.segs[k + 1].y, get_staged, vals); else reduce(sg.y, w.segs[k + 1].y, get, vals);
                 OutT *mine = w.tile + (size_t)q * C;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) if (c < C) mine[c] = vals[c];

@@ -77,6 +77,25 @@ __device__ inline uint32_t mdes_membership(const MdesWindows &w, int32_t r) {
     return m;
 }
 
+// 16-byte loads from an address known to be in global memory.  Pointers that a kernel reads out of a table in memory are
+// generic to the compiler: it emits flat_load, which also counts against lgkmcnt -- every LDS wait then waits for those
+// loads too.
+using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ inline u32x4_t gload16_raw(const void *p) {
+    return *reinterpret_cast<const u32x4_t __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(p));
+}
+// base (wave-uniform: SGPR pair) + 32-bit byte offset: one address register per lane instead of a 64-bit multiply-add chain
+__device__ inline uint4 gload16_at(const void *base, uint32_t byte_off) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t __attribute__((address_space(1))) *>(
+        reinterpret_cast<const char __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(base)) + byte_off);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline uint4 gload16(const void *p) { const u32x4_t v = gload16_raw(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ inline float4 gload16f(const void *p) {
+    const u32x4_t v = gload16_raw(p);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 __device__ inline int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Stable in-wave multisplit: for every valid lane, `rank` = number of lower valid lanes holding

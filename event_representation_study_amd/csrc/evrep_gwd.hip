@@ -319,7 +319,7 @@ __device__ inline void gwd_tile_fetch(const GwdTileArgs &P, GwdTilePos q, int ti
             const float *base = s_row ? (a_form ? ysa : ysb) : (a_form ? yta : ytb);
             const int64_t pad = s_row ? npad : mpad;
             if (s_row ? has_s : has_t)
-                v[it] = *reinterpret_cast<const float4 *>(base + (int64_t)k * pad + (a_form ? i0 : j0) + c);
+                v[it] = gload16f(base + (int64_t)k * pad + (a_form ? i0 : j0) + c);
         }
     }
 }
@@ -352,6 +352,9 @@ __device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTileP
     // behind the smaller cloud: the tile lies wholly inside the larger kernel's block and wholly in the other's padding
     // (a quarter of the tiles of a 12.5k x 14.4k pair; they went through the masked path until r03)
     const bool one_sided = (has_s != has_t) && j0 + kTile <= (n > m ? n : m);
+    // rows / columns of the tile inside each kernel's own block (masked path)
+    auto inside = [](int64_t N, int64_t o) -> int { const int64_t v = N - o; return v < 0 ? 0 : (v > kTile ? kTile : (int)v); };
+    const int nrow_s = inside(n, i0), ncol_s = inside(n, j0), nrow_t = inside(m, i0), ncol_t = inside(m, j0);
 #pragma unroll 1
     for (int cb = 0; cb < 4; ++cb) {
         float bs[NSS], bt[NST];
@@ -365,12 +368,18 @@ __device__ inline void gwd_tile_compute(const GwdTileArgs &P, int tile, GwdTileP
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(has_s ? es[r] : et[r]);
         } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
-            const int64_t gj = j0 + cb * 32 + (lane & 31);
+            // tile-local limits in 32 bits (the 64-bit compares of r02 cost ~70 instructions per tile, hoisted in front of
+            // every tile's loop by the compiler)
+            // (the lane index is laundered: the masks of this rare path are otherwise formed in front of EVERY tile's loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int lj = cb * 32 + (ln & 31);
+            const bool cs_ok = has_s && lj < ncol_s, ct_ok = has_t && lj < ncol_t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t gi = i0 + r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(es[r]) : 0.0f;
-                const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(et[r]) : 0.0f;
+                const int li = r0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                const float a = (cs_ok && li < nrow_s) ? __builtin_amdgcn_exp2f(es[r]) : 0.0f;
+                const float bb = (ct_ok && li < nrow_t) ? __builtin_amdgcn_exp2f(et[r]) : 0.0f;
                 sum += fabsf(a - bb);
             }
         }
@@ -421,41 +430,43 @@ __device__ inline void gwd_tile_body_split(const GwdTileArgs &P, int tile, uint4
     const uint4 *zta = reinterpret_cast<const uint4 *>(P.YtA), *ztb = reinterpret_cast<const uint4 *>(P.YtB);
     const int64_t npad = P.npad, mpad = P.mpad;
     const int lane = tid & 63, wave = tid >> 6, r0 = wave * 32;
-    {
-        uint4 v[NIT];
+    // Every load of the tile is issued before anything waits: the column tile's chunks (to be staged in LDS), then the
+    // wave's own rows (registers) -- the stage waits for the former only, the rows land behind the barrier.  32-bit byte
+    // offsets from the wave-uniform bases (a cloud form is < 2^31 bytes: evrep_gwd_padded_l1 bounds the tile count).
+    const uint32_t np16 = (uint32_t)npad * 16u, mp16 = (uint32_t)mpad * 16u;
+    uint4 v[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * kThreads, c = e / kTile, pt = e % kTile;
-            v[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < NV) {
-                const bool s_row = c < 2 * MS;
-                if (s_row ? has_s : has_t)
-                    v[it] = s_row ? zsb[(int64_t)c * npad + j0 + pt] : ztb[(int64_t)(c - 2 * MS) * mpad + j0 + pt];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + it * kThreads;
-            if (e < NV) lds[e] = v[it];
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * kThreads, c = e / kTile, pt = e % kTile;
+        v[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < NV) {
+            const bool s_row = c < 2 * MS;
+            if (s_row ? has_s : has_t)
+                v[it] = s_row ? gload16_at(zsb, (uint32_t)c * np16 + ((uint32_t)j0 + (uint32_t)pt) * 16u)
+                              : gload16_at(ztb, (uint32_t)(c - 2 * MS) * mp16 + ((uint32_t)j0 + (uint32_t)pt) * 16u);
         }
     }
-    // the wave's rows (issued before the barrier: their latency overlaps the stage)
     bf16x8 as[MS], at[MT];
     {
-        const int64_t row = i0 + r0 + (lane & 31);
-        const int kh = lane >> 5;
+        const uint32_t row16 = ((uint32_t)i0 + (uint32_t)(r0 + (lane & 31))) * 16u;
+        const uint32_t kh = (uint32_t)(lane >> 5);
 #pragma unroll
         for (int s_ = 0; s_ < MS; ++s_) {
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (has_s) w = zsa[(int64_t)(2 * s_ + kh) * npad + row];
+            if (has_s) w = gload16_at(zsa, (2u * s_ + kh) * np16 + row16);
             __builtin_memcpy(&as[s_], &w, 16);
         }
 #pragma unroll
         for (int s_ = 0; s_ < MT; ++s_) {
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (has_t) w = zta[(int64_t)(2 * s_ + kh) * mpad + row];
+            if (has_t) w = gload16_at(zta, (2u * s_ + kh) * mp16 + row16);
             __builtin_memcpy(&at[s_], &w, 16);
         }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * kThreads;
+        if (e < NV) lds[e] = v[it];
     }
     __syncthreads();
     const bf16x8 *B = reinterpret_cast<const bf16x8 *>(lds);
@@ -465,21 +476,24 @@ __device__ inline void gwd_tile_body_split(const GwdTileArgs &P, int tile, uint4
     // behind the smaller cloud: the tile lies wholly inside the larger kernel's block and wholly in the other's padding
     // (a quarter of the tiles of a 12.5k x 14.4k pair; they went through the masked path until r03)
     const bool one_sided = (has_s != has_t) && j0 + kTile <= (n > m ? n : m);
+    // rows / columns of the tile inside each kernel's own block (masked path)
+    auto inside = [](int64_t N, int64_t o) -> int { const int64_t v = N - o; return v < 0 ? 0 : (v > kTile ? kTile : (int)v); };
+    const int nrow_s = inside(n, i0), ncol_s = inside(n, j0), nrow_t = inside(m, i0), ncol_t = inside(m, j0);
 #pragma unroll 1
     for (int cb = 0; cb < 4; ++cb) {
         const int col = cb * 32 + (lane & 31), kh = lane >> 5;
-        f32x16 es, et;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { es[r] = 0.0f; et[r] = 0.0f; }
+        // (the chains start from the literal zero operand of the first MFMA: no accumulator is initialised by the VALU)
+        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16 es, et;   // a kernel that is absent from the tile (has_s / has_t false) is never read below
         if (has_s) {
 #pragma unroll
             for (int s_ = 0; s_ < MS; ++s_)
-                es = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[s_], B[(2 * s_ + kh) * kTile + col], es, 0, 0, 0);
+                es = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[s_], B[(2 * s_ + kh) * kTile + col], s_ ? es : zero, 0, 0, 0);
         }
         if (has_t) {
 #pragma unroll
             for (int s_ = 0; s_ < MT; ++s_)
-                et = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[s_], B[(2 * (MS + s_) + kh) * kTile + col], et, 0, 0, 0);
+                et = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[s_], B[(2 * (MS + s_) + kh) * kTile + col], s_ ? et : zero, 0, 0, 0);
         }
         if (interior) {
 #pragma unroll
@@ -488,12 +502,16 @@ __device__ inline void gwd_tile_body_split(const GwdTileArgs &P, int tile, uint4
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(has_s ? es[r] : et[r]);
         } else {  // edge tile: zero padding outside each kernel's own n x n / m x m block
-            const int64_t gj = j0 + col;
+            // (the lane index is laundered: the masks of this rare path are otherwise formed in front of EVERY tile's loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int lcol = cb * 32 + (ln & 31);
+            const bool cs_ok = has_s && lcol < ncol_s, ct_ok = has_t && lcol < ncol_t;   // tile-local limits, 32 bits
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t gi = i0 + r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float a = (has_s && gi < n && gj < n) ? __builtin_amdgcn_exp2f(es[r]) : 0.0f;
-                const float bb = (has_t && gi < m && gj < m) ? __builtin_amdgcn_exp2f(et[r]) : 0.0f;
+                const int li = r0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                const float a = (cs_ok && li < nrow_s) ? __builtin_amdgcn_exp2f(es[r]) : 0.0f;
+                const float bb = (ct_ok && li < nrow_t) ? __builtin_amdgcn_exp2f(et[r]) : 0.0f;
                 sum += fabsf(a - bb);
             }
         }
