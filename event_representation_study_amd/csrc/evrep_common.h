@@ -90,6 +90,19 @@ __device__ inline uint4 gload16_at(const void *base, uint32_t byte_off) {
         reinterpret_cast<const char __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(base)) + byte_off);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ inline double gload_f64(const double *p) {
+    return *reinterpret_cast<const double __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ inline void gstore16(void *p, uint4 v) {
+    u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    *reinterpret_cast<u32x4_t __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(p)) = w;
+}
+__device__ inline void gstore_f32(float *p, float v) {
+    *reinterpret_cast<float __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(p)) = v;
+}
+__device__ inline void gstore_f64(double *p, double v) {
+    *reinterpret_cast<double __attribute__((address_space(1))) *>(reinterpret_cast<uintptr_t>(p)) = v;
+}
 __device__ inline uint4 gload16(const void *p) { const u32x4_t v = gload16_raw(p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ inline float4 gload16f(const void *p) {
     const u32x4_t v = gload16_raw(p);

@@ -22,7 +22,7 @@ constexpr int kStatBlocks = 64;  // partial-sum blocks per cloud
 // Block `blk` of kStatBlocks sums x and x^2 per dimension over its slice of one cloud
 // (float64, one pass; the clouds hold O(1e4) points of magnitude <= 255, so sum(x^2)/N - mean^2
 // keeps ~1e-11 relative accuracy, far inside the 1e-5 budget).  dst: this cloud's [kStatBlocks][2*kGwdMaxD].
-__device__ inline void gwd_stats_body(const double *__restrict__ X, int64_t N, int d, int blk, double *__restrict__ dst,
+__device__ __forceinline__ void gwd_stats_body(const double *__restrict__ X, int64_t N, int d, int blk, double *__restrict__ dst,
                                       double (*red)[2 * kGwdMaxD]) {
     const int64_t per = (N + kStatBlocks - 1) / kStatBlocks;
     const int64_t i0 = (int64_t)blk * per, i1 = (i0 + per < N) ? i0 + per : N;
@@ -33,7 +33,7 @@ __device__ inline void gwd_stats_body(const double *__restrict__ X, int64_t N, i
         const double *row = X + i * d;
 #pragma unroll
         for (int k = 0; k < kGwdMaxD; ++k)
-            if (k < d) { const double v = row[k]; s[k] += v; q[k] += v * v; }
+            if (k < d) { const double v = gload_f64(row + k); s[k] += v; q[k] += v * v; }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -49,7 +49,7 @@ __device__ inline void gwd_stats_body(const double *__restrict__ X, int64_t N, i
     if (threadIdx.x < 2 * d) {
         double a = 0.0;
         for (int w = 0; w < kWaves; ++w) a += red[w][threadIdx.x];
-        dst[(size_t)blk * (2 * kGwdMaxD) + threadIdx.x] = a;
+        gstore_f64(dst + (size_t)blk * (2 * kGwdMaxD) + threadIdx.x, a);
     }
 }
 
@@ -123,12 +123,12 @@ __device__ inline void gwd_split_chunk(const double *__restrict__ xrow, const do
     constexpr int K0 = (8 * C) / 6, K1 = (8 * C + 7) / 6;   // dimensions the slots cover
     float v[K1 - K0 + 1];
 #pragma unroll
-    for (int k = K0; k <= K1; ++k) v[k - K0] = (real && k < d) ? (float)((xrow[k] - fin[k]) * sc) : 0.0f;
+    for (int k = K0; k <= K1; ++k) v[k - K0] = (real && k < d) ? (float)((gload_f64(xrow + k) - gload_f64(fin + k)) * sc) : 0.0f;
     float nrm = 0.0f;
     if (8 * C + 7 >= 6 * d && real) {   // this chunk holds norm slots
 #pragma unroll
         for (int k = 0; k < kGwdSplitMaxD; ++k)
-            if (k < d) { const float u = (float)((xrow[k] - fin[k]) * sc); nrm = fmaf(u, u, nrm); }
+            if (k < d) { const float u = (float)((gload_f64(xrow + k) - gload_f64(fin + k)) * sc); nrm = fmaf(u, u, nrm); }
     }
     uint32_t a[8], b[8];
 #pragma unroll
@@ -156,7 +156,7 @@ __device__ inline void gwd_split_chunk(const double *__restrict__ xrow, const do
 // The cloud statistics from the 64 partial sums, once per cloud (r03: every block of the scaling pass used to redo this
 // chain of 128 dependent loads): fin[k] = mean of dimension k, fin[kGwdMaxD] = sqrt(log2(e) / (2 h^2 sigma^2)).
 // sigma^2 = mean ||a - abar||^2 = sum_k (E[x_k^2] - E[x_k]^2).  One wave.
-__device__ inline void gwd_stats_finish_body(const double *__restrict__ stat_cloud, int64_t N, int d, double h,
+__device__ __forceinline__ void gwd_stats_finish_body(const double *__restrict__ stat_cloud, int64_t N, int d, double h,
                                              double *__restrict__ fin) {
     const int k = threadIdx.x;
     if (k >= 32) return;
@@ -164,14 +164,14 @@ __device__ inline void gwd_stats_finish_body(const double *__restrict__ stat_clo
     if (k < d) {
         const double *p = stat_cloud + 2 * k;
 #pragma unroll 16
-        for (int j = 0; j < kStatBlocks; ++j) { sx += p[(size_t)j * (2 * kGwdMaxD)]; sq += p[(size_t)j * (2 * kGwdMaxD) + 1]; }
+        for (int j = 0; j < kStatBlocks; ++j) { sx += gload_f64(p + (size_t)j * (2 * kGwdMaxD)); sq += gload_f64(p + (size_t)j * (2 * kGwdMaxD) + 1); }
     }
     const double mean = sx / (double)N;
     double var = (k < d) ? sq / (double)N - mean * mean : 0.0;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
-    fin[k] = mean;
-    if (k == 0) fin[kGwdMaxD] = sqrt(1.4426950408889634 / (2.0 * h * h * var));
+    gstore_f64(fin + k, mean);
+    if (k == 0) gstore_f64(fin + kGwdMaxD, sqrt(1.4426950408889634 / (2.0 * h * h * var)));
 }
 constexpr int kGwdFin = kGwdMaxD + 1;   // doubles per cloud behind the partial sums
 // grid (2), 64 threads
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(64) void k_gwd_stats_finish(const double *__restric
 // scales one point per thread (fin = the cloud's means and scale, gwd_stats_finish_body) and writes both forms, zero
 // points beyond N.  float32 form: dimension-major YA, YB = [2 * steps][Npad].  Split form: chunk `sub` of the point
 // (the launch spreads the chunks over blockIdx.z), ZA, ZB = [2 * split_steps][Npad] x 8 bfloat16, one 16-byte store each.
-__device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
+__device__ __forceinline__ void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
                                      const double *__restrict__ fin, bool split, int sub,
                                      float *__restrict__ YA, float *__restrict__ YB) {
     const int64_t i = (int64_t)blk * kThreads + threadIdx.x;
     if (i >= Npad) return;
-    const double sc = fin[kGwdMaxD];
+    const double sc = gload_f64(fin + kGwdMaxD);
     const int kp = 2 * gwd_steps(d);
     const bool real = i < N;
     if (split) {
@@ -204,24 +204,24 @@ __device__ inline void gwd_prep_body(const double *__restrict__ X, int64_t N, in
 #undef GWD_CHUNK
             default: break;
         }
-        reinterpret_cast<uint4 *>(YA)[(int64_t)sub * Npad + i] = za;
-        reinterpret_cast<uint4 *>(YB)[(int64_t)sub * Npad + i] = zb;
+        gstore16(reinterpret_cast<uint4 *>(YA) + (int64_t)sub * Npad + i, za);
+        gstore16(reinterpret_cast<uint4 *>(YB) + (int64_t)sub * Npad + i, zb);
         return;
     }
     if (sub != 0) return;
     float nrm = 0.0f;
     for (int k = 0; k < d; ++k) {
         float v = 0.0f;
-        if (real) v = (float)((X[i * d + k] - fin[k]) * sc);
+        if (real) v = (float)((gload_f64(X + i * d + k) - gload_f64(fin + k)) * sc);
         nrm = fmaf(v, v, nrm);
-        YA[(int64_t)k * Npad + i] = 2.0f * v;
-        YB[(int64_t)k * Npad + i] = v;
+        gstore_f32(YA + (int64_t)k * Npad + i, 2.0f * v);
+        gstore_f32(YB + (int64_t)k * Npad + i, v);
     }
-    YA[(int64_t)d * Npad + i] = real ? -nrm : 0.0f;
-    YB[(int64_t)d * Npad + i] = real ? 1.0f : 0.0f;
-    YA[(int64_t)(d + 1) * Npad + i] = real ? -1.0f : 0.0f;
-    YB[(int64_t)(d + 1) * Npad + i] = real ? nrm : 0.0f;
-    for (int k = d + 2; k < kp; ++k) { YA[(int64_t)k * Npad + i] = 0.0f; YB[(int64_t)k * Npad + i] = 0.0f; }
+    gstore_f32(YA + (int64_t)d * Npad + i, real ? -nrm : 0.0f);
+    gstore_f32(YB + (int64_t)d * Npad + i, real ? 1.0f : 0.0f);
+    gstore_f32(YA + (int64_t)(d + 1) * Npad + i, real ? -1.0f : 0.0f);
+    gstore_f32(YB + (int64_t)(d + 1) * Npad + i, real ? nrm : 0.0f);
+    for (int k = d + 2; k < kp; ++k) { gstore_f32(YA + (int64_t)k * Npad + i, 0.0f); gstore_f32(YB + (int64_t)k * Npad + i, 0.0f); }
 }
 
 // grid (ceil(npad / 256) + ceil(mpad / 256), 1, Z), 256 threads: both clouds in one launch; Z = the chunks per point of the
