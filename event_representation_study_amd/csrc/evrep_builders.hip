@@ -548,7 +548,11 @@ template <typename OutT>
 __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT> &w) {
     const int nrec = (int)(u.ce - u.cs), lane = threadIdx.x;
     const int n = min(nrec, w.nstage);
-    if (n <= kWave || w.nstage <= 2 * kEvStage) return;   // wave-uniform; only the builders that ask for a deep stage (unit_cfg)
+    // wave-uniform.  A 128-record stage (every builder on windows of > 28 records per unit) is only filled when it takes
+    // the WHOLE unit -- then the unit is "fully staged" exactly as it is after the key-sorted pass, and builders whose
+    // arithmetic depends on that (TimeSurface's factorised exponentials) give the same bits under every binning pass;
+    // the 256-record stage of the builders that ask for it (unit_cfg) is filled as far as it goes.
+    if (n <= kWave || (w.nstage <= 2 * kEvStage && nrec > w.nstage)) return;
     // stages of up to 256 records: three batches behind the register batch
     const Rec *src = u.sorted + u.cs + lane;
     const bool h1 = kWave + lane < n, h2 = 2 * kWave + lane < n, h3 = 3 * kWave + lane < n;

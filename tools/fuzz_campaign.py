@@ -20,7 +20,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
     if os.environ.get("FUZZ_BIG"):   # the reference's sensors: the 4096-event blocks, the two-round stage of 1280x720
         W, H = [(640, 480), (1280, 720), (304, 240), (346, 260)][int(rng.integers(0, 4))]
         B = int(rng.integers(1, 4))
-        dens = float(rng.choice([0.01, 0.05, 0.16, 0.25, 0.4]))
+        dens = float(rng.choice([0.01, 0.05, 0.16, 0.25, 0.4, 1.0, 1.7]))   # the last two: dense units, the 256-record stage of the classic passes
     else:
         W = int(rng.choice([1, 7, 64, 127, 128, 129, 200, 256, 300, 640, 1000]))
         H = int(rng.integers(1, 60))
