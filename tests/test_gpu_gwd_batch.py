@@ -52,15 +52,18 @@ def test_batch_equals_single_solves_bit_for_bit(oracle):
     assert np.isnan(c3[1]) and np.isnan(c3[3]) and np.array_equal(c3[[0, 2, 4]], single[[0, 2, 4]])
 
 
-def test_device_point_clouds_equal_the_host_harness_bit_for_bit():
+@pytest.mark.parametrize("sizes,S", [((6000, 6701, 7402), 240),
+                                     # windows longer / shorter than slices x threads of the sliced harness kernels, an odd cut
+                                     ((50000, 1500, 33001), 239)])
+def test_device_point_clouds_equal_the_host_harness_bit_for_bit(sizes, S):
     from event_representation_study_amd import engine as eng
     from event_representation_study_amd.representations.representation_search.compute_otmi import otmi_point_clouds
     from event_representation_study_amd.synthetic import make_events
-    H, W, S, C = 240, 304, 240, 5
+    H, W, C = 240, 304, 5
     rng = np.random.default_rng(11)
     wins, reps = [], []
     for b in range(3):
-        ev = make_events(6000 + 701 * b, W, H, seed=40 + b, polarity="pm1" if b != 1 else "01")
+        ev = make_events(sizes[b], W, H, seed=40 + b, polarity="pm1" if b != 1 else "01")
         if b == 2:                      # a skewed window: most events in the last quadrant, which is then the skipped one
             ev[: len(ev) // 2, 0] = rng.integers(W // 2 + 3, W, len(ev) // 2)
             ev[: len(ev) // 2, 1] = rng.integers(H // 2 + 3, H, len(ev) // 2)
