@@ -967,13 +967,13 @@ __host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int c
 #ifndef KS_WAVES_1024
 #define KS_WAVES_1024 8
 #endif
-template <int TPB>
+template <int TPB, int PL = 8>   // PL = events per lane: a workgroup orders TPB * PL events
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024 ? KS_WAVES_1024 : KS_WAVES_512))) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int kpr, int nblk, int cap,
                                                              uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
                                                              Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    constexpr int kChunk = TPB * kBsPerLane, kNW = TPB / kWave, kPerWave = kBsPerLane * kWave;
+    constexpr int kChunk = TPB * PL, kNW = TPB / kWave, kPerWave = PL * kWave;
     const int NK = H * kpr;
     Rec8 *stage = reinterpret_cast<Rec8 *>(smem_raw);                       // [cap], output order, 8-byte records
     uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kChunk] rank inside the block, arrival order
@@ -992,10 +992,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     const int w0 = wave * kPerWave;                       // first block-local index of the wave
     const int lo32 = (int)lo;
     const int4 *evb = ev + beg + lo;
-    int4 e[kBsPerLane];
-    int tprev[kBsPerLane];
+    int4 e[PL];
+    int tprev[PL];
 #pragma unroll
-    for (int i = 0; i < kBsPerLane; ++i) {
+    for (int i = 0; i < PL; ++i) {
         const int li = w0 + i * kWave + lane;
         e[i] = make_int4(-1, -1, INT32_MAX, 0);
         tprev[i] = INT32_MIN;
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     }
     BlockStats st;
     stats_identity(st);
-    uint32_t ko[kBsPerLane];  // key | arrival << 16, then the record's place in the block; 0xffffffff = not placed
+    uint32_t ko[PL];  // key | arrival << 16, then the record's place in the block; 0xffffffff = not placed
     uint32_t sneg = 0;
     bool cut = false;
     const int a0 = lo32 + w0, a1 = min(lo32 + w0 + kPerWave, lo32 + nblock);  // the wave's rank range
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     const uint32_t memb_u = cut ? 0u : (full | (part ? (mdes_membership(mw, a0) & part) : 0u));
     const int HW = H * W;  // < 2^30
 #pragma unroll
-    for (int i = 0; i < kBsPerLane; ++i) {
+    for (int i = 0; i < PL; ++i) {
         const int li = w0 + i * kWave + lane;
         const bool in = li < nblock;
         const int up = __builtin_amdgcn_update_dpp(0, e[i].z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -1100,16 +1100,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     // arrival order -> time order inside every key group
     const uint32_t mine0 = (uint32_t)(w0 + lane);
 #pragma unroll
-    for (int i = 0; i < kBsPerLane; ++i)
+    for (int i = 0; i < PL; ++i)
         if (ko[i] != 0xffffffffu) rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
     __syncthreads();
     {
         // the eight group walks of a lane advance together: eight independent LDS reads in flight per step instead of
         // one dependent read per step (the walk is latency-bound: 8 -> 2 us per block on the headline windows)
-        uint32_t gb[kBsPerLane], g[kBsPerLane], sm[kBsPerLane];
+        uint32_t gb[PL], g[PL], sm[PL];
         uint32_t gmax = 0;
 #pragma unroll
-        for (int i = 0; i < kBsPerLane; ++i) {
+        for (int i = 0; i < PL; ++i) {
             gb[i] = 0; g[i] = 0; sm[i] = 0;
             if (ko[i] != 0xffffffffu) {
                 const uint32_t key = ko[i] & 0xffffu;
@@ -1123,18 +1123,18 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         gmax = (uint32_t)wave_max((int)gmax);
         for (uint32_t j = 0; j < gmax; ++j) {
 #pragma unroll
-            for (int i = 0; i < kBsPerLane; ++i)
+            for (int i = 0; i < PL; ++i)
                 if (j < g[i]) sm[i] += (uint32_t)rankbuf[gb[i] + j] < mine0 + (uint32_t)(i * kWave) ? 1u : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < kBsPerLane; ++i)
+        for (int i = 0; i < PL; ++i)
             if (ko[i] != 0xffffffffu) ko[i] = gb[i] + sm[i];
     }
     Rec8 *dst = reinterpret_cast<Rec8 *>(sorted1) + beg + lo;   // the block's own slot, 8 bytes per record
     for (uint32_t pb = 0; pb < total && !(KS_DEBUG & 2); pb += (uint32_t)cap) {
         if (pb) __syncthreads();  // the previous round has left the stage
 #pragma unroll
-        for (int i = 0; i < kBsPerLane; ++i) {
+        for (int i = 0; i < PL; ++i) {
             const uint32_t pos = ko[i] - pb;  // 0xffffffff - pb >= cap for every pb < 8192
             if (pos < (uint32_t)cap) {  // placed records are in frame: their column is x, or (x + y*W) mod W for an x >= W
                 int col = e[i].x;

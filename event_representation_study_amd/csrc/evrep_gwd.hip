@@ -5,9 +5,9 @@
 // Nothing n^2 touches HBM: the two Gaussian kernels are generated tile by tile from the point
 // coordinates (LDS-resident) and folded into the |.| sum on the fly.  sigma needs no n^2 pass:
 // mean_ij ||a_i - a_j||^2 = 2 * mean_i ||a_i - abar||^2.  The squared distances come off the matrix
-// cores (v_mfma_f32_32x32x2_f32 on augmented coordinates, exact float32) while the VALU only does the two
-// exp2, the |.| and the accumulate of every entry; both K matrices are symmetric, so only
-// upper-triangular tiles are evaluated.
+// cores (augmented coordinates; v_mfma_f32_32x32x16_bf16 on exact three-way bfloat16 splits of the float32 operands for
+// clouds of <= 15 dimensions, v_mfma_f32_32x32x2_f32 beyond) while the VALU only does the two exp2, the |.| and the
+// accumulate of every entry; both K matrices are symmetric, so only upper-triangular tiles are evaluated.
 #include "evrep_common.h"
 
 namespace evrep {
