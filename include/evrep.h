@@ -234,12 +234,16 @@ int evrep_probe_store(void *out, size_t bytes, void *stream);
 /* OTMI(Xs, Xt, h).solve()[1] (representation_search/compute_otmi.py:61-93) in closed form for
  * POT's max_iter=0 path: mean over the LxL zero-padded grid of |Ks - Kt|.
  * Xs DEVICE double [n,ds], Xt DEVICE double [m,dt] (ds, dt <= 32); scratch DEVICE of
- * evrep_gwd_scratch_bytes(n, m); cost DEVICE double [1]. */
+ * evrep_gwd_scratch_bytes(n, m), 256-byte aligned; cost DEVICE double [1].
+ * Arithmetic: float64 statistics; the pairwise exponents in float32 accuracy on the matrix cores -- clouds of <= 15
+ * dimensions (both) as exact three-way bfloat16 splits of the float32 operands (v_mfma_f32_32x32x16_bf16), wider ones as
+ * float32 MFMA chains; exponentials in float32; sums in float64.  Measured 5e-9 relative against the float64 value, the
+ * reference's budget is 1e-5. */
 size_t evrep_gwd_scratch_bytes(int64_t n, int64_t m);
 int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *Xt, int64_t m, int32_t dt,
                         double h, void *scratch, double *cost, void *stream);
 
-/* P solves at once: costs[p] = evrep_gwd_padded_l1 of the pair p, bit for bit, in five launches for ALL pairs (a single
+/* P solves at once: costs[p] = evrep_gwd_padded_l1 of the pair p, bit for bit, in six launches for ALL pairs (a single
  * solve is four launches, three of them tiny).  The clouds' sizes are read on the DEVICE, so pairs produced by
  * evrep_otmi_event_clouds / evrep_otmi_rep_clouds are scored without a host read-back.
  * Xs DEVICE double: pair p's source cloud = rows [xs_row[p], xs_row[p] + n[p]) of ds columns (xs_row NULL: p * n_cap);
