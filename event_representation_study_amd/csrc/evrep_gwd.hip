@@ -434,32 +434,32 @@ __device__ inline void gwd_tile_body_split(const GwdTileArgs &P, int tile, uint4
     // wave's own rows (registers) -- the stage waits for the former only, the rows land behind the barrier.  32-bit byte
     // offsets from the wave-uniform bases (a cloud form is < 2^31 bytes: evrep_gwd_padded_l1 bounds the tile count).
     const uint32_t np16 = (uint32_t)npad * 16u, mp16 = (uint32_t)mpad * 16u;
+    // thread tid stages point tid & 127 of chunks (tid >> 7) + 2 it: whether a chunk belongs to cloud s or t is a
+    // compile-time property of `it`, a load's offset is one addition away from the previous one
+    static_assert(kThreads == 2 * kTile && NV == NIT * kThreads, "two chunks per round of the workgroup");
     uint4 v[NIT];
+    {
+        const uint32_t half = (uint32_t)tid >> 7, pt16 = ((uint32_t)j0 + ((uint32_t)tid & 127u)) * 16u;
+        const uint32_t s0 = half * np16 + pt16, t0 = half * mp16 + pt16;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + it * kThreads, c = e / kTile, pt = e % kTile;
-        v[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < NV) {
-            const bool s_row = c < 2 * MS;
-            if (s_row ? has_s : has_t)
-                v[it] = s_row ? gload16_at(zsb, (uint32_t)c * np16 + ((uint32_t)j0 + (uint32_t)pt) * 16u)
-                              : gload16_at(ztb, (uint32_t)(c - 2 * MS) * mp16 + ((uint32_t)j0 + (uint32_t)pt) * 16u);
+        for (int it = 0; it < NIT; ++it) {
+            if (it < MS) v[it] = has_s ? gload16_at(zsb, s0 + (uint32_t)(2 * it) * np16) : make_uint4(0u, 0u, 0u, 0u);
+            else v[it] = has_t ? gload16_at(ztb, t0 + (uint32_t)(2 * (it - MS)) * mp16) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
     bf16x8 as[MS], at[MT];
     {
         const uint32_t row16 = ((uint32_t)i0 + (uint32_t)(r0 + (lane & 31))) * 16u;
         const uint32_t kh = (uint32_t)(lane >> 5);
+        const uint32_t s0 = kh * np16 + row16, t0 = kh * mp16 + row16;
 #pragma unroll
         for (int s_ = 0; s_ < MS; ++s_) {
-            uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (has_s) w = gload16_at(zsa, (2u * s_ + kh) * np16 + row16);
+            const uint4 w = has_s ? gload16_at(zsa, s0 + (uint32_t)(2 * s_) * np16) : make_uint4(0u, 0u, 0u, 0u);
             __builtin_memcpy(&as[s_], &w, 16);
         }
 #pragma unroll
         for (int s_ = 0; s_ < MT; ++s_) {
-            uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (has_t) w = gload16_at(zta, (2u * s_ + kh) * mp16 + row16);
+            const uint4 w = has_t ? gload16_at(zta, t0 + (uint32_t)(2 * s_) * mp16) : make_uint4(0u, 0u, 0u, 0u);
             __builtin_memcpy(&at[s_], &w, 16);
         }
     }

@@ -244,7 +244,7 @@ int evrep_gwd_padded_l1(const double *Xs, int64_t n, int32_t ds, const double *X
                         double h, void *scratch, double *cost, void *stream);
 
 /* P solves at once: costs[p] = evrep_gwd_padded_l1 of the pair p, bit for bit, in six launches for ALL pairs (a single
- * solve is four launches, three of them tiny).  The clouds' sizes are read on the DEVICE, so pairs produced by
+ * solve is five launches, four of them tiny).  The clouds' sizes are read on the DEVICE, so pairs produced by
  * evrep_otmi_event_clouds / evrep_otmi_rep_clouds are scored without a host read-back.
  * Xs DEVICE double: pair p's source cloud = rows [xs_row[p], xs_row[p] + n[p]) of ds columns (xs_row NULL: p * n_cap);
  * likewise Xt / xt_row / m / dt.  xs_row, n, xt_row, m DEVICE int64 [P].  n_cap, m_cap: upper bounds of n[p], m[p]
