@@ -52,6 +52,8 @@ SYMBOLS = {
     "evrep_bin_events": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp]),
     "evrep_probe_store": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp]),
     "evrep_mdes": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _I32P, _I32P, _I32P, _f64, _i32, _vp, _vp]),
+    "evrep_mdes_sbt_windows": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "evrep_mdes_ex": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _I32P, _I32P, _I32P, _f64, _i32, _vp, _vp, _vp, _vp]),
     "evrep_optimized": (ctypes.c_int, [_PP, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
     "evrep_event_stack": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
     "evrep_time_surface": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _vp, _f64, _i32, _f64, _i32, _vp, _vp]),

@@ -914,6 +914,10 @@ __device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, 
 struct MdesParams {
     int32_t C;
     int32_t win[EVREP_MAX_CHANNELS], func[EVREP_MAX_CHANNELS], agg[EVREP_MAX_CHANNELS];
+    // "SBT" stacking (evrep_mdes_ex): the caller's windows as rank ranges, [B][8][2] {lo, hi}, and their polarity /
+    // out-of-frame flags, [B][2] {neg_flags, oob_flags with a stride of 8 bits per polarity class}; nullptr = "SBN"
+    const int32_t *bounds;
+    const uint32_t *wflags;
 };
 
 // Descriptor sources: RuntimeDesc reads the caller's triples from the kernel arguments;
@@ -922,6 +926,7 @@ struct MdesParams {
 template <int N>
 struct RuntimeDesc {  // N = compile-time capacity (4, 8, 12, 16): register arrays are sized by it
     static constexpr int kMaxC = N;
+    static constexpr bool kCustomWindows = true;   // may run over the caller's windows ("SBT", evrep_mdes_ex)
     __device__ static inline int C(const MdesParams &P) { return P.C; }
     __device__ static inline int win(const MdesParams &P, int c) { return P.win[c]; }
     __device__ static inline int func(const MdesParams &P, int c) { return P.func[c]; }
@@ -943,6 +948,7 @@ struct Ergo12Table {
 template <typename T>
 struct StaticDesc {
     static constexpr int kMaxC = T::kC;
+    static constexpr bool kCustomWindows = false;
     __device__ static inline int C(const MdesParams &) { return T::kC; }
     __device__ static inline int win(const MdesParams &, int c) { return T::kWin[c]; }
     __device__ static inline int func(const MdesParams &, int c) { return T::kFunc[c]; }
@@ -961,7 +967,23 @@ __device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double 
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
-    const MdesWindows mw = mdes_windows(n_win);
+    // "SBT": eight windows handed over as rank ranges (k_mdes_sbt_windows).  Never with the compile-time ERGO-12 descriptors;
+    // the loaded values are made wave-uniform explicitly (readfirstlane), or every per-channel bound below moves from the
+    // scalar to the vector registers (+25 VGPRs, an occupancy step).
+    const bool custom = D::kCustomWindows && P.bounds != nullptr;
+    MdesWindows mw = mdes_windows(n_win);
+    uint32_t neg_flags = m.neg_flags, oob_flags = m.oob_flags;
+    const int fstride = custom ? 8 : 7, wmax = custom ? 7 : 6;
+    if (custom) {
+        const int32_t *bw = P.bounds + (size_t)g.b * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mw.lo[i] = __builtin_amdgcn_readfirstlane(bw[2 * i]);
+            mw.hi[i] = __builtin_amdgcn_readfirstlane(bw[2 * i + 1]);
+        }
+        neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * g.b]);
+        oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * g.b + 1]);
+    }
     w.mark(1);
 
     // per-channel uniform setup
@@ -972,20 +994,20 @@ __device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double 
         lo[c] = 0; hi[c] = 0; want[c] = kWantAny; active[c] = false;
         if (c < C) {
             const int wi = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
-            bool ok = wi >= 0 && wi <= 6 && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
+            bool ok = wi >= 0 && wi <= wmax && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
             int l = 0, h = 0;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) if (wi == i) { l = mw.lo[i]; h = mw.hi[i]; }
+            for (int i = 0; i < 8; ++i) if (wi == i) { l = mw.lo[i]; h = mw.hi[i]; }
             int wn = kWantAny, field = 0;
             if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { wn = 1; field = 1; }
             if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
                 // rows with p == -1; if the window has none, rows with p == 0 (operations.py:59-61,78-80)
-                const bool has_neg = ok && ((m.neg_flags >> (wi & 7)) & 1u);
+                const bool has_neg = ok && ((neg_flags >> (wi & 7)) & 1u);
                 wn = has_neg ? -1 : 0;
                 field = has_neg ? 2 : 3;
             }
             // an out-of-range index inside the selected rows raises in torch_scatter -> zero channel
-            if (ok && ((m.oob_flags >> (7 * field + (wi & 7))) & 1u)) ok = false;
+            if (ok && ((oob_flags >> (fstride * field + (wi & 7))) & 1u)) ok = false;
             lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
         }
     }
@@ -1101,6 +1123,84 @@ __global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__res
     mdes_emit_unit<OutT, D>(P, C, W, scale, u, g, n_win, m, dst, w);
 }
 
+
+// "SBT" stacking (mixed_density_event_stack.py:76-107): eight windows cut by the normalised time t_s = (t - tmin) / (tmax -
+// tmin) -- w0 all, w1..w3 i/3 <= t_s <= (i+1)/3 (both ends inclusive), w4..w7 t_s <= 1/2, 1/4, 1/8, 1/16.  On ascending
+// timestamps (which every builder here requires) a window is a rank range: lo = #(t_s < a), hi = #(t_s <= b), counted with the
+// reference's own float64 comparisons (a NaN t_s -- a window of one timestamp -- fails them all: empty windows, as there).
+// grid (B), 1024 threads: bounds [B][8][2], wflags [B][2] = {bit w: window w holds a p == -1 event; bit 8 k + w: window w
+// holds an out-of-frame event of polarity class k (0 any, 1 p == 1, 2 p == -1, 3 p == 0)}.
+__global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int H, int W,
+                                                          int32_t *__restrict__ bounds, uint32_t *__restrict__ wflags) {
+    __shared__ int cnt[10];
+    __shared__ uint32_t fl[2];
+    __shared__ int lo_s[8], hi_s[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t beg = off[b];
+    const int n = (int)(off[b + 1] - beg);
+    const int4 *e = ev + beg;
+    if (tid < 10) cnt[tid] = 0;
+    if (tid < 2) fl[tid] = 0u;
+    __syncthreads();
+    if (n > 0) {
+        const int64_t tmin = e[0].z, tmax = e[n - 1].z;
+        const double interval = (double)(tmax - tmin);
+        const double ef = 1.0 / 3.0;
+        int c[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) c[k] = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const double ts = (double)((int64_t)e[i].z - tmin) / interval;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                c[k] += ts < (double)k * ef ? 1 : 0;            // the events in front of window 1 + k
+                c[3 + k] += ts <= (double)(k + 1) * ef ? 1 : 0;   // ... up to its end
+            }
+            double factor = 1.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { factor = factor / 2.0; c[6 + k] += ts <= factor ? 1 : 0; }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            int v = c[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0 && v) atomicAdd(&cnt[k], v);
+        }
+    }
+    __syncthreads();
+    if (tid < 8) {
+        int l = 0, h = 0;
+        if (tid == 0) h = n;
+        else if (tid < 4) { l = cnt[tid - 1]; h = cnt[3 + tid - 1]; if (h < l) h = l; }
+        else h = cnt[6 + tid - 4];
+        lo_s[tid] = l; hi_s[tid] = h;
+        bounds[(size_t)b * 16 + 2 * tid] = l;
+        bounds[(size_t)b * 16 + 2 * tid + 1] = h;
+    }
+    __syncthreads();
+    uint32_t neg = 0u, oob = 0u;
+    const int64_t HW = (int64_t)H * W;
+    for (int i = tid; i < n; i += 1024) {
+        const int4 r = e[i];
+        uint32_t memb = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) memb |= (i >= lo_s[k] && i < hi_s[k]) ? (1u << k) : 0u;
+        if (r.w == -1) neg |= memb;
+        // in-frame test on the flat index x + y * W, as the reference's scatter sees it (k_block_keysort)
+        bool valid = (uint32_t)r.x < (uint32_t)W && (uint32_t)r.y < (uint32_t)H;
+        if (!valid) { const int64_t key = (int64_t)r.x + (int64_t)r.y * W; valid = key >= 0 && key < HW; }
+        if (!valid) {
+            const int cls = r.w == 1 ? 1 : (r.w == -1 ? 2 : (r.w == 0 ? 3 : 0));
+            oob |= memb | (cls ? (memb << (8 * cls)) : 0u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { neg |= __shfl_xor(neg, o, 64); oob |= __shfl_xor(oob, o, 64); }
+    if ((tid & 63) == 0) { if (neg) atomicOr(&fl[0], neg); if (oob) atomicOr(&fl[1], oob); }
+    __syncthreads();
+    if (tid < 2) wflags[2 * b + tid] = fl[tid];
+}
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]

@@ -417,20 +417,38 @@ static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_byte
     return ticks < 50.0 ? 0 : (int)(ticks + 0.5);
 }
 
+int evrep_mdes_sbt_windows(const int32_t *events, const int64_t *offsets, int32_t B, int32_t H, int32_t W, int32_t *bounds,
+                           uint32_t *flags, void *stream_) {
+    if (!events || !offsets || !bounds || !flags || B <= 0 || B > 65535 || H <= 0 || W <= 0) return EVREP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(events) & 15u) return EVREP_EINVAL;
+    k_mdes_sbt_windows<<<B, 1024, 0, static_cast<hipStream_t>(stream_)>>>(reinterpret_cast<const int4 *>(events), offsets, H, W, bounds, flags);
+    LAUNCH_CHECK("k_mdes_sbt_windows");
+    return EVREP_OK;
+}
+
 int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
                const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
                void *out, void *stream_) {
+    return evrep_mdes_ex(plan, events, offsets, workspace, C, window, func, agg, scale, out_dtype, out, nullptr, nullptr, stream_);
+}
+
+int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
+                  const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
+                  void *out, const int32_t *bounds, const uint32_t *flags, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (C <= 0 || C > EVREP_MAX_CHANNELS || !window || !func || !agg || !out) return EVREP_EINVAL;
     if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
+    if ((bounds == nullptr) != (flags == nullptr)) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MdesParams P;
     memset(&P, 0, sizeof(P));
     P.C = C;
+    P.bounds = bounds;
+    P.wflags = flags;
     for (int c = 0; c < C; ++c) { P.win[c] = window[c]; P.func[c] = func[c]; P.agg[c] = agg[c]; }
     // the ERGO-12 triples get the kernel instance with compile-time descriptors
-    bool ergo = C == Ergo12Table::kC;
+    bool ergo = C == Ergo12Table::kC && bounds == nullptr;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
     UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));

@@ -55,7 +55,7 @@ __device__ inline Rec rec8_unpack(const Rec8 q, int row_base, int base_col, cons
 // The 7 "SBN" windows of MixedDensityEventStack.create_windows
 // (representation_search/mixed_density_event_stack.py:48-74) as [lo, hi) rank ranges.
 struct MdesWindows {
-    int32_t lo[7], hi[7];
+    int32_t lo[8], hi[8];   // entry 7 only exists under the "SBT" stacking (eight windows cut by time, evrep_mdes_ex)
 };
 
 __host__ __device__ inline MdesWindows mdes_windows(int64_t n64) {
@@ -66,6 +66,7 @@ __host__ __device__ inline MdesWindows mdes_windows(int64_t n64) {
     for (int i = 0; i < 3; ++i) { w.lo[1 + i] = i * third; w.hi[1 + i] = (i + 1) * third; }
     int32_t cur = n, start = 0;
     for (int i = 0; i < 3; ++i) { cur /= 2; start += cur; w.lo[4 + i] = start; w.hi[4 + i] = n; }
+    w.lo[7] = 0; w.hi[7] = 0;
     return w;
 }
 

@@ -131,9 +131,22 @@ class EventBatch:
             return _lib.F32
         raise ValueError("dtype must be torch.float64 or torch.float32")
 
-    def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64, out=None):
+    def sbt_windows(self):
+        """The eight "SBT" windows of every window of the batch as rank ranges + their flags (device tensors).  Formed per
+        call: a pooled batch is refilled with other events between calls."""
+        bounds = torch.empty((self.B, 8, 2), dtype=torch.int32, device=self.device)
+        flags = torch.empty((self.B, 2), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_mdes_sbt_windows(_ptr(self.events), _ptr(self.offsets), self.B, self.H, self.W,
+                                                  _ptr(bounds), _ptr(flags), _stream_ptr()), "evrep_mdes_sbt_windows")
+        return bounds, flags
+
+    def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64, out=None, stacking="SBN"):
         """MixedDensityEventStack.stack for every window -> (B, H, W, C).  ``None`` entries give the
-        reference's failed-channel zeros.  More than 16 channels are built 16 at a time."""
+        reference's failed-channel zeros.  More than 16 channels are built 16 at a time.
+        stacking "SBN": windows 0..6 cut by event count (the reference's choice); "SBT": windows 0..7 cut by time."""
+        if stacking not in ("SBN", "SBT"):
+            raise ValueError("stacking_type %r" % (stacking,))
         self.bin()
         C = len(windows)
         w = [-1 if v is None else int(v) for v in windows]
@@ -141,12 +154,15 @@ class EventBatch:
         a = [-1 if v is None else (_lib.AGGS.index(v) if isinstance(v, str) else int(v)) for v in aggs]
         if C <= _lib.MAX_CHANNELS:
             out = self._out(out, C, dtype)
+            null = ctypes.c_void_p(None)
+            bounds, flags = self.sbt_windows() if stacking == "SBT" else (None, None)
             with torch.cuda.device(self.device):
-                check(self.lib.evrep_mdes(*self._args(), C, _lib.int32_array(w), _lib.int32_array(f),
-                                          _lib.int32_array(a), float(scale), self._dt(dtype), _ptr(out),
-                                          _stream_ptr()), "evrep_mdes")
+                check(self.lib.evrep_mdes_ex(*self._args(), C, _lib.int32_array(w), _lib.int32_array(f),
+                                             _lib.int32_array(a), float(scale), self._dt(dtype), _ptr(out),
+                                             _ptr(bounds) if bounds is not None else null,
+                                             _ptr(flags) if flags is not None else null, _stream_ptr()), "evrep_mdes_ex")
             return out
-        parts = [self.mdes(w[i:i + 16], f[i:i + 16], a[i:i + 16], scale, dtype) for i in range(0, C, 16)]
+        parts = [self.mdes(w[i:i + 16], f[i:i + 16], a[i:i + 16], scale, dtype, stacking=stacking) for i in range(0, C, 16)]
         res = torch.cat(parts, dim=3)
         if out is not None:
             out.copy_(res)

@@ -81,9 +81,10 @@ class SampleBatch:
     def optimized(self, scale=1.0, dtype=torch.float64):
         return self.batch.optimized(scale=scale, dtype=dtype, out=self.out(12, dtype))
 
-    def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64):
+    def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64, stacking="SBN"):
         C = len(windows)
-        return self.batch.mdes(windows, funcs, aggs, scale, dtype, out=self.out(C, dtype) if C <= _lib.MAX_CHANNELS else None)
+        return self.batch.mdes(windows, funcs, aggs, scale, dtype, out=self.out(C, dtype) if C <= _lib.MAX_CHANNELS else None,
+                               stacking=stacking)
 
     def event_stack(self, stack_size=12, premap=True, scale=1.0):
         return self.batch.event_stack(stack_size, premap, scale, out=self.out(stack_size, torch.float32))

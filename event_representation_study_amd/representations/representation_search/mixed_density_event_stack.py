@@ -16,15 +16,17 @@ class MixedDensityEventStack(object):
     def stack(self, event_sequence):
         """(H, W, stack_size) float64.  A channel whose triple is unusable (``None`` window, unknown
         function, out-of-frame events in its window) is all zeros, like the reference's try/except."""
-        if self.stacking_type != "SBN":
-            raise NotImplementedError("only the 'SBN' stacking the reference selects is implemented")
+        # "SBN": 7 windows cut by event count (:58-74); "SBT": 8 windows cut by normalised time (:76-107).  Any other string
+        # leaves the reference with the one full window, so every index but 0 / -1 fails its channel.
+        nwin = {"SBN": 7, "SBT": 8}.get(self.stacking_type, 1)
         windows, funcs, aggs = self.indexes_functions_aggregations
         sb = sample_batch(event_sequence, self.height, self.width, truncate=True, rebase_t=True)   # astype + t - t.min(), :26-33
         from ... import _lib
-        def window(v):      # anything that cannot index the 7-window list fails the channel (-> zeros)
-            ok = isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -7 <= int(v) <= 6
-            return (int(v) % 7) if ok else None
+        def window(v):      # anything that cannot index the window list fails the channel (-> zeros)
+            ok = isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -nwin <= int(v) <= nwin - 1
+            return (int(v) % nwin) if ok else None
         w = [window(v) for v in list(windows)[: self.stack_size]]
         f = [v if v in _lib.FUNCS else None for v in list(funcs)[: self.stack_size]]
         a = [v if v in _lib.AGGS else None for v in list(aggs)[: self.stack_size]]
-        return finish(sb, sb.mdes(w, f, a, scale=1.0), allow_oob=True, what="MixedDensityEventStack")
+        return finish(sb, sb.mdes(w, f, a, scale=1.0, stacking="SBT" if self.stacking_type == "SBT" else "SBN"), allow_oob=True,
+                      what="MixedDensityEventStack")

@@ -117,6 +117,17 @@ int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *off
                int32_t C, const int32_t *window, const int32_t *func, const int32_t *agg, double scale,
                int32_t out_dtype, void *out, void *stream);
 
+/* The "SBT" stacking of MixedDensityEventStack (mixed_density_event_stack.py:76-107): EIGHT windows cut by the normalised
+ * time t_s instead of by event count -- w0 all, w1..w3 i/3 <= t_s <= (i+1)/3 (inclusive both ends), w4..w7 t_s <= 1/2, 1/4,
+ * 1/8, 1/16.  evrep_mdes_sbt_windows forms them for B windows (timestamps ascending, as every builder requires) as rank
+ * ranges: bounds DEVICE int32 [B][8][2] {lo, hi}, flags DEVICE uint32 [B][2] (which windows hold p == -1 / out-of-frame
+ * events).  evrep_mdes_ex = evrep_mdes with window[c] in 0..7 over those windows; bounds == flags == NULL: evrep_mdes. */
+int evrep_mdes_sbt_windows(const int32_t *events, const int64_t *offsets, int32_t B, int32_t H, int32_t W, int32_t *bounds,
+                           uint32_t *flags, void *stream);
+int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
+                  const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
+                  void *out, const int32_t *bounds, const uint32_t *flags, void *stream);
+
 /* get_optimized_representation (optimized_representation.py:86-134): the ERGO-12 triples. */
 int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                     double scale, int32_t out_dtype, void *out, void *stream);

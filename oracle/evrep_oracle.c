@@ -61,20 +61,23 @@ void oracle_mdes_windows(int64_t n, int64_t lo[7], int64_t hi[7]) {
 /* A4: one Operations(func, aggregation)(events[window]) call (operations.py:15-89) with the
  * torch_scatter semantics restated: sum accumulates sequentially in event order in float64;
  * mean = sum / max(count,1); max leaves empty pixels at 0; variance = mean(src^2) - mean(src)^2. */
-static int mdes_channel(const int32_t *ev, const double *t_s, int64_t lo, int64_t hi, int H, int W,
+static int mdes_channel(const int32_t *ev, const double *t_s, int64_t lo, int64_t hi, const unsigned char *mask, int H, int W,
                         int func, int agg, double *sum, double *sum2, double *cnt, double *chan /* H*W */) {
+    /* mask != NULL ("SBT" stacking): the window is the events i in [lo, hi) with mask[i] set -- a boolean selection in array
+     * order, as the reference's x[np.logical_and(...)] is */
     int64_t hw = (int64_t)H * W;
     int want = 0; /* 0 = all, +1 = p == 1, -1 = p == -1 (fallback p == 0) */
     if (func == F_TIMESTAMP_POS || func == F_COUNT_POS) want = 1;
     if (func == F_TIMESTAMP_NEG || func == F_COUNT_NEG) {
         want = -1;
         int any = 0;
-        for (int64_t i = lo; i < hi; ++i) if (ev[4 * i + 3] == -1) { any = 1; break; }
+        for (int64_t i = lo; i < hi; ++i) if ((!mask || mask[i]) && ev[4 * i + 3] == -1) { any = 1; break; }
         if (!any) want = -2; /* operations.py:59-61,78-80: no -1 rows -> use p == 0 rows */
     }
     /* index check first: torch scatter raises on any out-of-range index -> zero channel */
     for (int64_t i = lo; i < hi; ++i) {
         int p = ev[4 * i + 3];
+        if (mask && !mask[i]) continue;
         if ((want == 1 && p != 1) || (want == -1 && p != -1) || (want == -2 && p != 0)) continue;
         int64_t idx = (int64_t)ev[4 * i] + (int64_t)ev[4 * i + 1] * W;
         if (idx < 0 || idx >= hw) return ORACLE_EINDEX;
@@ -86,6 +89,7 @@ static int mdes_channel(const int32_t *ev, const double *t_s, int64_t lo, int64_
     if (is_max) for (int64_t k = 0; k < hw; ++k) sum[k] = -1.7976931348623157e308;
     for (int64_t i = lo; i < hi; ++i) {
         int p = ev[4 * i + 3];
+        if (mask && !mask[i]) continue;
         if ((want == 1 && p != 1) || (want == -1 && p != -1) || (want == -2 && p != 0)) continue;
         int64_t idx = (int64_t)ev[4 * i] + (int64_t)ev[4 * i + 1] * W;
         double v;
@@ -141,11 +145,50 @@ int oracle_mdes(const int32_t *ev, int64_t n, int H, int W, int C, const int *wi
     for (int c = 0; c < C; ++c) {
         int rc = ORACLE_EINDEX;
         if (win[c] >= 0 && win[c] <= 6 && func[c] >= 0 && func[c] <= 6 && agg[c] >= 0 && agg[c] <= 3)
-            rc = mdes_channel(ev, t_s, lo[win[c]], hi[win[c]], H, W, func[c], agg[c], sum, sum2, cnt, chan);
+            rc = mdes_channel(ev, t_s, lo[win[c]], hi[win[c]], NULL, H, W, func[c], agg[c], sum, sum2, cnt, chan);
         if (rc != ORACLE_OK) memset(chan, 0, sizeof(double) * hw);
         for (int64_t k = 0; k < hw; ++k) out[k * C + c] = chan[k];
     }
     free(t_s); free(sum); free(sum2); free(cnt); free(chan);
+    return ORACLE_OK;
+}
+
+/* A3, stacking_type == "SBT" (mixed_density_event_stack.py:76-107): EIGHT windows cut by the normalised time t_s instead of
+ * by event count.  w0 = all; w1..w3 = i/3 <= t_s <= (i+1)/3 (both ends inclusive, thresholds formed as python forms them:
+ * equispaced_factor = 1/3, i * equispaced_factor); w4..w7 = t_s <= 1/2, 1/4, 1/8, 1/16 (each cut of the previous selection:
+ * the same as the plain comparison).  Selections are boolean masks in array order.  mask_out (optional): [8][n]. */
+int oracle_mdes_sbt(const int32_t *ev, int64_t n, int H, int W, int C, const int *win, const int *func,
+                    const int *agg, double *out, unsigned char *mask_out) {
+    int64_t hw = (int64_t)H * W;
+    if (n <= 0) return ORACLE_EARG;
+    double *t_s = (double *)malloc(sizeof(double) * n);
+    double *sum = (double *)malloc(sizeof(double) * hw), *sum2 = (double *)malloc(sizeof(double) * hw);
+    double *cnt = (double *)malloc(sizeof(double) * hw), *chan = (double *)malloc(sizeof(double) * hw);
+    unsigned char *mask = (unsigned char *)malloc((size_t)8 * n);
+    int64_t tmin = ev[2], tmax = ev[2];
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t t = ev[4 * i + 2];
+        if (t < tmin) tmin = t;
+        if (t > tmax) tmax = t;
+    }
+    double interval = (double)(tmax - tmin);
+    for (int64_t i = 0; i < n; ++i) t_s[i] = (double)((int64_t)ev[4 * i + 2] - tmin) / interval;
+    const double ef = 1.0 / 3.0;
+    for (int64_t i = 0; i < n; ++i) {
+        mask[i] = 1;
+        for (int k = 0; k < 3; ++k) mask[(size_t)(1 + k) * n + i] = (t_s[i] <= (double)(k + 1) * ef && t_s[i] >= (double)k * ef) ? 1 : 0;
+        double factor = 1.0;
+        for (int k = 0; k < 4; ++k) { factor = factor / 2.0; mask[(size_t)(4 + k) * n + i] = t_s[i] <= factor ? 1 : 0; }
+    }
+    for (int c = 0; c < C; ++c) {
+        int rc = ORACLE_EINDEX;
+        if (win[c] >= 0 && win[c] <= 7 && func[c] >= 0 && func[c] <= 6 && agg[c] >= 0 && agg[c] <= 3)
+            rc = mdes_channel(ev, t_s, 0, n, mask + (size_t)win[c] * n, H, W, func[c], agg[c], sum, sum2, cnt, chan);
+        if (rc != ORACLE_OK) memset(chan, 0, sizeof(double) * hw);
+        for (int64_t k = 0; k < hw; ++k) out[k * C + c] = chan[k];
+    }
+    if (mask_out) memcpy(mask_out, mask, (size_t)8 * n);
+    free(t_s); free(sum); free(sum2); free(cnt); free(chan); free(mask);
     return ORACLE_OK;
 }
 

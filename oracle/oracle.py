@@ -85,6 +85,19 @@ def mdes(ev, H, W, windows, funcs, aggs):
     return out
 
 
+def mdes_sbt(ev, H, W, windows, funcs, aggs, return_masks=False):
+    """MixedDensityEventStack(..., stacking_type="SBT").stack -> (H, W, C) float64: eight windows cut by normalised time."""
+    ev = _ev(ev)
+    C = len(windows)
+    w = [-1 if v is None else int(v) for v in windows]
+    f = [-1 if v is None else FUNCS.index(v) for v in funcs]
+    a = [-1 if v is None else AGGS.index(v) for v in aggs]
+    out = np.empty((H, W, C), dtype=np.float64)
+    masks = np.empty((8, ev.shape[0]), dtype=np.uint8)
+    _chk(lib().oracle_mdes_sbt(_p(ev), ctypes.c_int64(ev.shape[0]), H, W, C, _ints(w), _ints(f), _ints(a), _p(out), _p(masks)))
+    return (out, masks) if return_masks else out
+
+
 def ergo12(ev, H, W, out=None):
     """get_optimized_representation -> (H, W, 12) float64.  `out`: optional result buffer to reuse (the threaded
     CPU baseline of bench.py: a fresh 29.5 MB array per window makes the host's page-fault path the benchmark)."""

@@ -47,6 +47,39 @@ def test_golden_mdes_all_triples(eng, enc):
     assert_bit_equal(got, g["rep"], enc)
 
 
+@pytest.mark.parametrize("name", ["sbt_all_triples_40x30_n3001_pm1", "sbt_all_triples_40x30_n3001_01",
+                                  "sbt_shortspan_40x30_n2000_pm1", "sbt_latestart_40x30_n1500_pm1"])
+def test_golden_mdes_sbt(eng, name):
+    """stacking_type="SBT": evrep_mdes_sbt_windows + evrep_mdes_ex against the reference's own output, bit for bit."""
+    g = load_golden(name)
+    eb = _batch(eng, g["events"], int(g["H"]), int(g["W"]))
+    got = eb.mdes(list(g["windows"]), [str(s) for s in g["funcs"]], [str(s) for s in g["aggs"]], stacking="SBT")[0].cpu().numpy()
+    assert_bit_equal(got, g["rep"], name)
+
+
+def test_mdes_sbt_batch_against_oracle(eng, oracle):
+    """Several windows per launch, float32 output, an out-of-frame event inside some windows only, a window of one timestamp
+    (t_s = NaN: every window but the first is empty), both stackings from one binning pass."""
+    H, W = 37, 150
+    rng = np.random.default_rng(8)
+    wins = [make_events(n, W, H, seed=90 + i, polarity="pm1" if i % 2 else "01") for i, n in enumerate((5000, 333, 2, 1200))]
+    wins[0][4000, 0] = W + 7                  # out of frame, polarity as drawn, late in the window
+    wins[0][4000, 1] = H + 3
+    wins[3][:, 2] = 77                        # one timestamp
+    triples = [(w, f, a) for w in range(8) for f in ("timestamp", "polarity", "count_neg", "timestamp_pos")
+               for a in ("sum", "mean", "max", "variance")][:48]
+    wi, fu, ag = [t[0] for t in triples], [t[1] for t in triples], [t[2] for t in triples]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    got = eb.mdes(wi, fu, ag, stacking="SBT").cpu().numpy()
+    got32 = eb.mdes(wi[:16], fu[:16], ag[:16], stacking="SBT", dtype=torch.float32).cpu().numpy()
+    sbn = eb.mdes([w % 7 for w in wi[:16]], fu[:16], ag[:16]).cpu().numpy()
+    for b, ev in enumerate(wins):
+        ref = oracle.mdes_sbt(ev, H, W, wi, fu, ag)
+        assert_bit_equal(got[b], ref, "window %d" % b)
+        assert_bit_equal(got32[b], ref[..., :16].astype(np.float32), "window %d float32" % b)
+        assert_bit_equal(sbn[b], oracle.mdes(ev, H, W, [w % 7 for w in wi[:16]], fu[:16], ag[:16]), "window %d SBN" % b)
+
+
 def test_golden_mdes_none_channels(eng):
     g = load_golden("mdes_none_channels_40x30_n999")
     eb = _batch(eng, g["events"], int(g["H"]), int(g["W"]))

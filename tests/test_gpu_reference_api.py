@@ -169,6 +169,10 @@ def test_optimized_and_mdes_classes():
     triples = (list(a["windows"]), [str(s) for s in a["funcs"]], [str(s) for s in a["aggs"]])
     m = MixedDensityEventStack(len(triples[0]), 3001, int(a["H"]), int(a["W"]), triples, "SBN")
     assert_bit_equal(m.stack(to_structured(a["events"])), a["rep"])
+    t = load_golden("sbt_shortspan_40x30_n2000_pm1")                      # stacking_type "SBT": windows cut by time
+    triples = (list(t["windows"]), [str(s) for s in t["funcs"]], [str(s) for s in t["aggs"]])
+    m = MixedDensityEventStack(len(triples[0]), 2000, int(t["H"]), int(t["W"]), triples, "SBT")
+    assert_bit_equal(m.stack(to_structured(t["events"])), t["rep"])
     z = load_golden("mdes_none_channels_40x30_n999")
     m = MixedDensityEventStack(4, 999, 30, 40, ([0, None, 6, None], ["count", None, "polarity", None],
                                                   ["sum", None, "sum", None]), "SBN")
