@@ -19,7 +19,12 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     xi = field_to_int64(x, "x", truncate=True)                     # int(i), int(j)
     yi = field_to_int64(y, "y", truncate=True)
     if len(xi) and (xi.min() < 1 or yi.min() < 1):
-        raise NotImplementedError("events2ToreFeature: x, y below 1 (numpy negative-index wrap) are not supported")
+        # the reference indexes [i - 1, j - 1] (tore.py:25,41): a coordinate below 1 is a NEGATIVE numpy index and wraps to
+        # the far side of the frame; beyond the frame numpy raises IndexError (twice: the except branch repeats the access)
+        if xi.min() < 1 - Wf or yi.min() < 1 - Hf:
+            raise IndexError("events2ToreFeature: index out of bounds for the %dx%d frame" % (Wf, Hf))
+        xi = np.where(xi < 1, xi + Wf, xi)
+        yi = np.where(yi < 1, yi + Hf, yi)
     # the sample time may arrive as a Python number, a numpy scalar, a 0-d array or a 0-d tensor: normalise first (a
     # non-integral one handed as a 0-d array must not be truncated by int())
     st = float(np.asarray(sampleTimes.cpu() if isinstance(sampleTimes, torch.Tensor) else sampleTimes).reshape(()))

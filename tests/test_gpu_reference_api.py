@@ -157,6 +157,18 @@ def test_tore_function():
     np.testing.assert_allclose(rep_t, oracle.tore(x, y, ev[:, 2], ev[:, 3], T, 3, (y.max(), x.max())), rtol=1e-6, atol=1e-6)
 
 
+def test_tore_coordinates_below_one_wrap_like_numpy():
+    """1-based x, y < 1 are negative numpy indices in the reference (tore.py:25,41: [i - 1, j - 1]) and wrap to the far side of
+    the frame; golden from the reference's own function (tests/golden/make_golden_sbt.py).  Beyond the frame: IndexError."""
+    from event_representation_study_amd.representations.tore import events2ToreFeature
+    g = load_golden("tore_wrap_20x15_n600")
+    rep = events2ToreFeature(g["x"], g["y"], g["ts"], g["pol"], int(g["sample_time"]), int(g["k"]), (int(g["H"]), int(g["W"])))
+    assert rep.shape == g["tore"].shape and rep.dtype == np.float32
+    np.testing.assert_allclose(rep, g["tore"], rtol=1e-6, atol=1e-6)
+    with pytest.raises(IndexError):
+        events2ToreFeature(np.array([-20, 3]), np.array([1, 2]), np.array([0, 5]), np.array([1, -1]), 6, 3, (15, 20))
+
+
 def test_optimized_and_mdes_classes():
     from event_representation_study_amd.representations.optimized_representation import get_optimized_representation
     from event_representation_study_amd.representations.representation_search.mixed_density_event_stack import \
