@@ -12,8 +12,8 @@ READ (``File``): what h5py's defaults (libver "earliest") produce, which is how 
 Gen1 / gen4 event datasets (precompute_reps.py:307-308,408-409) and ev-licious ``events/{x,y,p,t}``
 (ev-licious/src/evlicious/io/utils/h5_writer.py:29-67): superblock 0/1, v1 object headers with continuation
 blocks, symbol-table groups, fixed-point / IEEE datatypes, compact / contiguous / chunked (v1 B-tree) layouts,
-deflate and shuffle filters.  ev-licious compresses with Blosc (filter 32001), which needs the ``blosc`` module at
-read time -- absent here, so such a dataset raises NotImplementedError rather than returning wrong data.
+deflate and shuffle filters, and Blosc (filter 32001: what ev-licious compresses with -- zstd, bit shuffle), decoded by
+blosc_lite.py.
 
 Validated in tests/test_h5lite_cpu.py against real HDF5 (libhdf5 1.10.6 / h5py 3.3 of the image's conda
 environment) when that is present, and against committed files that h5py wrote (tests/golden/h5/).
@@ -158,12 +158,10 @@ class Dataset:
             elif fid == 3:                                     # fletcher32: checksum appended
                 raw = raw[:-4]
             elif fid == 32001:
-                try:
-                    import blosc
-                except ImportError:
-                    raise NotImplementedError("dataset %r is Blosc-compressed (HDF5 filter 32001, ev-licious' default): "
-                                              "the `blosc` module is needed to read it" % self.name)
-                raw = blosc.decompress(raw)
+                # ev-licious' default (h5_writer.py:8-26).  The chunk is one Blosc 1 frame: decoded by blosc_lite (pinned against
+                # frames of the real libblosc; zstd / lz4 through the system's shared libraries)
+                from . import blosc_lite
+                raw = blosc_lite.decompress(raw)
             else:
                 raise NotImplementedError("HDF5 filter %d is not supported" % fid)
         return raw

@@ -32,6 +32,40 @@ def test_reader_on_evlicious_layout_written_by_h5py():
         assert int(f["events"]["divider"][()]) == 1 and f.get("events/nope") is None and "events/x" in f
 
 
+def test_blosc_frames_of_the_real_libblosc():
+    """blosc_lite against 126 frames the real libblosc 1.21.0 produced (make_blosc_fixtures.py): u2 / i1 / i8 / f4 / i4 x no /
+    byte / bit shuffle x zstd / lz4 / lz4hc / zlib, one element to several blocks, split and unsplit blocks, stored
+    ("memcpyed") frames, bit-shuffled blocks whose element count is no multiple of eight (c-blosc copies those)."""
+    from event_representation_study_amd import blosc_lite
+    fr = np.load(os.path.join(H5, "blosc_frames.npz"))
+    ex = np.load(os.path.join(H5, "blosc_frames_expected.npz"))
+    kinds = set()
+    for k in fr.files:
+        frame = fr[k].tobytes()
+        got = np.frombuffer(blosc_lite.decompress(frame), dtype=ex[k].dtype)
+        np.testing.assert_array_equal(got, ex[k], err_msg=k)
+        kinds.add((frame[2] >> 5, frame[2] & 0x7))
+    assert {(4, 4), (4, 1), (4, 0), (1, 1), (3, 4)} <= kinds          # (codec format, shuffle bits) really present
+    with pytest.raises(ValueError):
+        blosc_lite.decompress(b"\x02\x01\x80\x08" + b"\x00" * 8)
+    bad = bytearray(fr["f025"].tobytes())
+    bad[2] &= 0x1f                                                    # claim blosclz: not decoded here, loudly
+    with pytest.raises(NotImplementedError):
+        blosc_lite.decompress(bytes(bad))
+
+
+def test_reader_on_the_evlicious_container_with_its_blosc_filter():
+    """ev-licious' own file: events/{x,y,p,t} chunked, resizable, HDF5 filter 32001 with its compression_opts (zstd, level 1,
+    bit shuffle; h5_writer.py:8-44), written by the real libhdf5 with chunks the real libblosc compressed."""
+    e = dict(np.load(os.path.join(H5, "blosc_expected.npz")))
+    with h5lite.File(os.path.join(H5, "events_evlicious_blosc.h5")) as f:
+        for k, dt in (("x", "<u2"), ("y", "<u2"), ("p", "|i1"), ("t", "<i8")):
+            d = f["events/" + k]
+            assert d.shape == (40000,) and d.dtype == np.dtype(dt)
+            np.testing.assert_array_equal(d[:], e["evl_" + k])
+        assert int(f["events/width"][()]) == 1280 and int(f["events/height"][()]) == 720 and int(f["events/divider"][()]) == 1
+
+
 def test_reader_on_gen4_layout_written_by_h5py():
     e = dict(np.load(os.path.join(H5, "expected.npz")))
     f = h5lite.File(os.path.join(H5, "events_gen4_layout.h5"))
