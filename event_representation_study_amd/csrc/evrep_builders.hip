@@ -632,16 +632,19 @@ __device__ inline WindowMeta meta_finish(const BinView &bv, const int64_t *__res
         st.ymin = r.q1.x; st.ymax = r.q1.y; st.neg_flags = (uint32_t)r.q1.z; st.oob_flags = (uint32_t)r.q1.w;
         st.status = (uint32_t)r.q2.x; st.n_valid = r.q2.y;
     }
-    // The events of a window are time-sorted (EVREP_ST_UNSORTED input is rejected by every host wrapper), and the blocks cut
-    // the window in index order: the window's first timestamp is block 0's minimum, its last one the last block's maximum --
-    // two readlanes instead of two DPP reductions on every builder wave's critical path.  (The status word still reports an
-    // unsorted window; its tensors are undefined either way.)
+    // The events of a window are normally time-sorted, and the blocks cut the window in index order: the window's first
+    // timestamp is block 0's minimum, its last one the last block's maximum -- two readlanes instead of two DPP reductions
+    // on every builder wave's critical path.  A window the status word reports as unsorted takes the reductions (below).
     m.tmin = nb > 0 ? __builtin_amdgcn_readlane(st.tmin, 0) : INT32_MAX;
     m.tmax = nb > 0 ? __builtin_amdgcn_readlane(st.tmax, nb - 1) : INT32_MIN;
     m.xmin = wave_min(st.xmin); m.xmax = wave_max(st.xmax);
     m.ymin = wave_min(st.ymin); m.ymax = wave_max(st.ymax);
     m.neg_flags = wave_or(st.neg_flags); m.oob_flags = wave_or(st.oob_flags);
     m.status = wave_or(st.status); m.n_valid = wave_sum(st.n_valid);
+    if (m.status & EVREP_ST_UNSORTED) {   // wave-uniform, rare: t.min() / t.max() of a window in any order (MDES accepts it)
+        m.tmin = wave_min(st.tmin);
+        m.tmax = wave_max(st.tmax);
+    }
     return m;
 }
 __device__ inline WindowMeta window_meta(const BinView &bv, const int64_t *__restrict__ off, int b) {

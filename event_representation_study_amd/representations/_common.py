@@ -130,7 +130,7 @@ def sample_batch(event_sequence, height, width, truncate=False, rebase_t=False):
     return SampleBatch(ctx, n)
 
 
-def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None):
+def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None, allow_unsorted=False):
     """Status + result in ONE synchronisation.  dev_out: the (1, H, W, C) device tensor a builder filled.  Returns the
     (H, W, C) numpy array (TORE: the bounding-box frame) or raises what the reference raises."""
     ctx, b = sb.ctx, sb.batch
@@ -142,7 +142,7 @@ def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None):
     host.copy_(dev_out[0], non_blocking=True)
     torch.cuda.current_stream(b.device).synchronize()
     meta = ctx.meta_pinned.numpy()
-    _raise_for_status_word(int(meta[8]) & 0xffffffff, b, allow_oob, what)
+    _raise_for_status_word(int(meta[8]) & 0xffffffff, b, allow_oob, what, allow_unsorted)
     arr = host.numpy()
     if tore_k is not None:          # the events' bounding box, origin-shifted (gen1_transforms.py:61-64): a prefix of the buffer
         xmin, xmax, ymin, ymax = int(meta[2]), int(meta[3]), int(meta[4]), int(meta[5])
@@ -154,12 +154,15 @@ def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None):
     return arr if RESULT_RING_DEPTH > 0 else arr.copy()
 
 
-def _raise_for_status_word(st, batch, allow_oob, what):
+def _raise_for_status_word(st, batch, allow_oob, what, allow_unsorted=False):
     if st & _lib.ST_EMPTY:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")  # t.min() on no events
     if (st & _lib.ST_OOB) and not allow_oob:
         raise IndexError("%s: event coordinates outside the %dx%d frame" % (what, batch.W, batch.H))
-    if st & _lib.ST_UNSORTED:
+    if (st & _lib.ST_UNSORTED) and not allow_unsorted:
+        # MixedDensityEventStack works in ARRAY order (windows by index, scatter in index order, t.min() / t.max()): the
+        # kernels do the same whatever the timestamps' order, so its wrappers pass allow_unsorted; the other builders'
+        # semantics on unsorted input differ from what the FIFO / last-event kernels compute
         raise NotImplementedError("%s: timestamps must be ascending (the reference's adapters deliver them so)" % what)
 
 

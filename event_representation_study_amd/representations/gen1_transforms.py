@@ -33,7 +33,7 @@ def _voxel_grid(events, transform, height, width, num_events):
 
 def _optimized(events, transform, height, width, num_events):
     sb = sample_batch(events, height, width, truncate=True, rebase_t=True)   # MDES.stack's own casts (:26-33)
-    return finish(sb, sb.optimized(scale=float(SCALE)), allow_oob=True, what="MixedDensityEventStack")
+    return finish(sb, sb.optimized(scale=float(SCALE)), allow_oob=True, what="MixedDensityEventStack", allow_unsorted=True)
 
 
 def _event_stack(events, transform, height, width, num_events):

@@ -10,4 +10,4 @@ def get_optimized_representation(reshaped_return_data, num_events, height, width
     # x, y, p -> int32, t -> int64 and t - t.min(), as MixedDensityEventStack.stack does (:26-33); n_imagenet hands
     # all-float64 fields (imagenet.py:1002-1006)
     sb = sample_batch(reshaped_return_data, height, width, truncate=True, rebase_t=True)
-    return finish(sb, sb.optimized(scale=1.0), allow_oob=True, what="get_optimized_representation")
+    return finish(sb, sb.optimized(scale=1.0), allow_oob=True, what="get_optimized_representation", allow_unsorted=True)

@@ -29,4 +29,4 @@ class MixedDensityEventStack(object):
         f = [v if v in _lib.FUNCS else None for v in list(funcs)[: self.stack_size]]
         a = [v if v in _lib.AGGS else None for v in list(aggs)[: self.stack_size]]
         return finish(sb, sb.mdes(w, f, a, scale=1.0, stacking="SBT" if self.stacking_type == "SBT" else "SBN"), allow_oob=True,
-                      what="MixedDensityEventStack")
+                      what="MixedDensityEventStack", allow_unsorted=self.stacking_type != "SBT")   # "SBT" cuts by time: rank ranges need order

@@ -43,7 +43,7 @@ extern "C" {
 /* per-window status bits (evrep_read_status) */
 #define EVREP_ST_EMPTY 1u      /* window has no events (reference: ValueError on t.min()) */
 #define EVREP_ST_OOB 2u        /* some x + y*W outside [0, H*W) (reference: IndexError in put / zero channel in MDES) */
-#define EVREP_ST_UNSORTED 4u   /* timestamps not ascending (reference behaviour differs; unsupported) */
+#define EVREP_ST_UNSORTED 4u   /* timestamps not ascending: evrep_mdes / evrep_optimized work in array order as the reference does; the other builders' tensors are undefined */
 #define EVREP_ST_FLAT_TIME 8u  /* t[-1] == t[0] (reference divides by zero) */
 
 /* MDES function / aggregation codes (representation_search/operations.py:42-87, :16-34) */

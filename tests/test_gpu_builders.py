@@ -157,8 +157,43 @@ def test_status_bits_and_exceptions(eng):
     assert st[3] & _lib.ST_EMPTY
     bb = eb.bbox()
     assert tuple(bb[0]) == (ok[:, 0].min(), ok[:, 1].min(), ok[:, 0].max(), ok[:, 1].max())
+    # MixedDensityEventStack takes timestamps in any order, as the reference does (array order rules) -- the other builders do not
+    from event_representation_study_amd.representations import gen1_transforms
+    from conftest import assert_bit_equal as abe
+    import oracle as orc
+    abe(get_optimized_representation(to_structured(unsorted), 500, H, W), orc.ergo12(unsorted, H, W))
     with pytest.raises(NotImplementedError):
-        get_optimized_representation(to_structured(unsorted), 500, H, W)
+        gen1_transforms.get_item_transform(to_structured(unsorted), "ToTimesurface", None, H, W, 500, 50000)
+
+
+def test_mdes_unsorted_timestamps(eng, monkeypatch):
+    """Timestamps in any order: golden from the reference's own MixedDensityEventStack / get_optimized_representation, under
+    every binning pass (the window's time range is then a reduction over all blocks, not first / last), plus a batch in
+    which only one window is unsorted, against the oracle."""
+    import oracle as orc
+    g = load_golden("mdes_unsorted_40x30_n2500_pm1")
+    ev, H, W = g["events"], int(g["H"]), int(g["W"])
+    trip = (list(g["windows"]), [str(s) for s in g["funcs"]], [str(s) for s in g["aggs"]])
+    for var in (None, "EVREP_BIN_KEY_SORTED", "EVREP_BIN_CLASSIC", "EVREP_BIN_THREE_KERNEL"):
+        for v in ("EVREP_BIN_KEY_SORTED", "EVREP_BIN_CLASSIC", "EVREP_BIN_THREE_KERNEL"):
+            monkeypatch.delenv(v, raising=False)
+        if var:
+            monkeypatch.setenv(var, "1")
+        eb = _batch(eng, ev, H, W)
+        assert_bit_equal(eb.mdes(*trip)[0].cpu().numpy(), g["rep"], str(var))
+        assert_bit_equal(eb.optimized()[0].cpu().numpy(), g["ergo12"], str(var))
+    for v in ("EVREP_BIN_KEY_SORTED", "EVREP_BIN_CLASSIC", "EVREP_BIN_THREE_KERNEL"):
+        monkeypatch.delenv(v, raising=False)
+    # a larger frame, several blocks per window: the extremes sit in the middle blocks
+    H2, W2 = 120, 200
+    wins = [make_events(n, W2, H2, seed=60 + i) for i, n in enumerate((30000, 9000, 12000))]
+    rng = np.random.default_rng(3)
+    wins[1][:, 2] = wins[1][rng.permutation(len(wins[1])), 2]
+    wins[2][5000, 2] = wins[2][-1, 2] + 1000          # one late event early in the array: t.max() is not the last timestamp
+    eb = eng.EventBatch.from_numpy(wins, H2, W2)
+    got = eb.optimized().cpu().numpy()
+    for b, w in enumerate(wins):
+        assert_bit_equal(got[b], orc.ergo12(w, H2, W2), "window %d" % b)
 
 
 def test_mdes_arbitrary_polarity_values(eng, oracle):
