@@ -1676,8 +1676,8 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
         int n_any = 0, n_pos = 0, n_neg = 0;
         double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
         for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);
-            const double tn = tw[e.y];
+            const Rec e = get(j);   // digest: {t_n lo, t_n hi, rank, p}
+            const double tn = __hiloint2double(e.y, e.x);
             if (n_any == 0 || tn > mx_any) mx_any = tn;
             if (n_any == 0 || tn < mn_any) mn_any = tn;
             ++n_any;
@@ -1709,7 +1709,14 @@ __global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
             vals[c] = v;
         }
     };
-    emit_chunk<float, CM>(u, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    // the record's normalised time is gathered from the caller's array by the DIGEST -- one load per record, all lanes at once,
+    // staged in place of the fields the walks do not need -- instead of one dependent global load per step of the divergent
+    // segment walks (r03)
+    auto digest = [&](const Rec &r) -> Rec {
+        const double tn = tw[r.y];
+        return make_int4(__double2loint(tn), __double2hiint(tn), r.y, r.w);
+    };
+    emit_chunk<float, CM>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1753,8 +1760,8 @@ __global__ __launch_bounds__(kWave) void k_est(BinView bv,
 #pragma unroll
         for (int i = 0; i < kEstMaxBins; ++i) { lo_half[i] = 0.0f; hi_half[i] = 0.0f; }
         for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);
-            const float tn = tw[e.y];
+            const Rec e = get(j);   // digest: {t_n bits, rank, t, p}
+            const float tn = __int_as_float(e.x);
 #pragma unroll
             for (int i = 0; i < kEstMaxBins; ++i) {
                 if (i < P.C) {
@@ -1775,7 +1782,9 @@ __global__ __launch_bounds__(kWave) void k_est(BinView bv,
             vals[c] = v;
         }
     };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, reduce);
+    // the normalised time is gathered by the digest, one load per record with all lanes busy, not inside the walks (see k_polstats)
+    auto digest = [&](const Rec &r) -> Rec { return make_int4(__float_as_int(tw[r.y]), r.y, r.z, r.w); };
+    emit_chunk<float, EVREP_MAX_CHANNELS>(u, digest, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
