@@ -47,4 +47,18 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
         if ev[-1, 2] != ev[0, 2]:
             assert np.array_equal(a["ergo12"][b], oracle.ergo12(ev, H, W), equal_nan=True), (seed, "ergo12 vs oracle", W, H, len(ev))
         assert np.array_equal(a["es"][b], oracle.event_stack(ev, H, W)), (seed, "event stack vs oracle")
+    if n % 4 == 0:   # r03: the "SBT" stacking (windows cut by time) and MDES on timestamps in any order, against the oracle
+        trip = ([0, 1, 2, 3, 4, 5, 6, 7, 2, 5], ["count", "timestamp", "polarity", "count_neg", "timestamp_pos", "count_pos", "timestamp_neg", "polarity", "timestamp", "count"],
+                ["sum", "mean", "variance", "sum", "max", "mean", "mean", "max", "variance", "mean"])
+        sbt = au.mdes(*trip, stacking="SBT").cpu().numpy()
+        for b, ev in enumerate(wins):
+            if ev[-1, 2] != ev[0, 2]:
+                assert np.array_equal(sbt[b], oracle.mdes_sbt(ev, H, W, *trip), equal_nan=True), (seed, "SBT vs oracle", W, H, len(ev))
+        shuf = [ev.copy() for ev in wins]
+        for ev in shuf:
+            ev[:, 2] = ev[np.random.default_rng(seed).permutation(len(ev)), 2]
+        us = eng.EventBatch.from_numpy(shuf, H, W).optimized().cpu().numpy()
+        for b, ev in enumerate(shuf):
+            if ev[:, 2].max() != ev[:, 2].min():
+                assert np.array_equal(us[b], oracle.ergo12(ev, H, W), equal_nan=True), (seed, "unsorted ergo12 vs oracle", W, H, len(ev))
 print("fuzz campaign: %d cases ok in %.0f s" % (n, time.time() - t0))
