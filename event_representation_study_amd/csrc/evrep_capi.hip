@@ -515,8 +515,10 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     TsCuts *cuts = WS(TsCuts, off_cuts);
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
     LAUNCH_CHECK("k_ts_cuts");
-    // sparse windows (practically every unit fully staged): the kernel with the factorised exponentials compiled in
-    const bool ts_fact = (double)plan->max_events_per_window <= 30.0 * (double)plan->H * plan->nchunk;
+    // windows whose units are practically all fully staged (<= 128 records: everything the key-sorted pass is chosen for, r03;
+    // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
+    // when ITS unit is fully staged, whatever the binning pass (Gen1 shape 88 -> 80 us)
+    const bool ts_fact = (double)plan->max_events_per_window <= kKeySortedMaxPerUnit * (double)plan->H * plan->nchunk;
     if (out_dtype == EVREP_F64) {
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20, 0, false, false);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
