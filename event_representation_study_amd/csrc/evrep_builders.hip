@@ -1365,14 +1365,16 @@ __global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int
     const int C = 2 * S;
     WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
     w.arm(uc.hold);
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    // the window's cuts, held in registers with compile-time indices only (no scratch)
-    const TsCuts *cp = cuts + g.b;
+    // the window's cuts, held in registers with compile-time indices only (no scratch); read BEFORE the unit's front end, so
+    // that their latency runs beside the run-table / record loads instead of behind them (r03)
+    int chunk0;
+    const TsCuts *cp = cuts + unit_geom(H, W, nchunk, uc.span, chunk0).b;
     struct { int idx[(CM / 2)], tcut[(CM / 2)], live[(CM / 2)]; } cu;
 #pragma unroll
     for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
+    ChunkGeom g;
+    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
     // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
     // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
     const double inv_tau = 1.0 / tau;
@@ -1568,13 +1570,19 @@ __global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, Bi
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds<double> w(smem, bins, uc.span * kChunkPx, uc.stage);
     w.arm(uc.hold);
+    // the window's first / last timestamp: two dependent load levels (extent, then events) issued BEFORE the unit's own two
+    // levels (run tables, then records), not behind them (r03: they were a third and fourth step of the wave's latency chain)
+    int chunk0;
+    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
+    const int64_t beg = off[b0];
+    const int64_t n_win = off[b0 + 1] - beg;
+    int tz0 = 0, tz1 = 0;
+    if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
     ChunkGeom g;
     const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
     double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
-    const int64_t beg = off[g.b];
-    const int64_t n_win = off[g.b + 1] - beg;
     double t0 = 0.0, den = 1.0;
-    if (n_win > 0) { t0 = (double)ev[beg].z; den = (double)ev[beg + n_win - 1].z - t0; }
+    if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
     // explicit [t0_us, t1_us] of ev-licious' events_to_voxel_grid (utils.py:60-63), mode 2 only
     if (t_range) { t0 = (double)t_range[2 * g.b]; den = (double)(t_range[2 * g.b + 1] - t_range[2 * g.b]); }
     // the fractional bin position of an event: one float64 division
