@@ -178,6 +178,8 @@ class Dataset:
             if addr == UNDEF:
                 return np.zeros(shape, dt)
             return np.frombuffer(r.b, dt, count, addr).reshape(shape).copy()
+        if kind != "chunked":
+            raise NotImplementedError("data layout %r" % (kind,))
         _, btree, cdims = kind, self._layout[1], self._layout[2]
         out = np.zeros(shape, dt)
         if btree == UNDEF:
@@ -209,7 +211,63 @@ class Dataset:
         walk(btree)
         return out
 
+    def _chunk_index(self):
+        """[(offsets, address, size, filter mask)] of a chunked dataset, read once: a window of a Gen1 recording is a
+        slice [event_idx - N, event_idx) of datasets of 10^7..10^8 events (gen1_2yolo.py:188-198), not the whole of them."""
+        if getattr(self, "_index", None) is None:
+            r, rank = self.file._r, len(self.shape)
+            index = []
+
+            def walk(addr):
+                if bytes(r.b[addr:addr + 4]) != b"TREE":
+                    raise ValueError("bad chunk B-tree node at %d" % addr)
+                level, used = r.u(addr + 5, 1), r.u(addr + 6, 2)
+                p = addr + 24
+                ksz = 8 + 8 * (rank + 1)
+                for _ in range(used):
+                    size, mask = r.u(p, 4), r.u(p + 4, 4)
+                    offs = tuple(r.u(p + 8 + 8 * d, 8) for d in range(rank))
+                    child = r.u(p + ksz, 8)
+                    p += ksz + 8
+                    if level > 0:
+                        walk(child)
+                    else:
+                        index.append((offs, child, size, mask))
+            if self._layout[1] != UNDEF:
+                walk(self._layout[1])
+            index.sort()
+            self._index = index
+        return self._index
+
+    def read_rows(self, start, stop):
+        """rows [start, stop) along axis 0 -- only the chunks that hold them are read and decoded"""
+        n0 = self.shape[0] if self.shape else 0
+        start, stop = max(0, min(int(start), n0)), max(0, min(int(stop), n0))
+        if stop <= start:
+            return np.zeros((0,) + tuple(self.shape[1:]), self.dtype)
+        if self._layout[0] != "chunked":
+            return self.read()[start:stop]
+        r, dt, shape = self.file._r, self.dtype, self.shape
+        rank = len(shape)
+        cshape = tuple(self._layout[2][:rank])
+        cbytes = int(np.prod(cshape)) * dt.itemsize
+        out = np.zeros((stop - start,) + tuple(shape[1:]), dt)
+        for offs, addr, size, mask in self._chunk_index():
+            if offs[0] >= stop or offs[0] + cshape[0] <= start:
+                continue
+            raw = self._apply_filters(bytes(r.b[addr:addr + size]), mask, cbytes)
+            chunk = np.frombuffer(raw, dt, int(np.prod(cshape))).reshape(cshape)
+            lo, hi = max(start, offs[0]), min(stop, offs[0] + cshape[0], shape[0])
+            rest_out = tuple(slice(o, min(o + c, s_)) for o, c, s_ in zip(offs[1:], cshape[1:], shape[1:]))
+            rest_in = tuple(slice(0, s_.stop - s_.start) for s_ in rest_out)
+            out[(slice(lo - start, hi - start),) + rest_out] = chunk[(slice(lo - offs[0], hi - offs[0]),) + rest_in]
+        return out
+
     def __getitem__(self, key):
+        # a plain slice along axis 0 (what the reference's loaders take: handle["x"][idx0:idx1]) reads its chunks only
+        if isinstance(key, slice) and key.step in (None, 1) and self.shape and self._layout[0] == "chunked":
+            a, b, _ = key.indices(self.shape[0])
+            return self.read_rows(a, b)
         return self.read()[key]
 
     def __array__(self, dtype=None, copy=None):

@@ -157,6 +157,20 @@ def test_tore_function():
     np.testing.assert_allclose(rep_t, oracle.tore(x, y, ev[:, 2], ev[:, 3], T, 3, (y.max(), x.max())), rtol=1e-6, atol=1e-6)
 
 
+def test_gen1_container_to_builder(oracle=None):
+    """Windows cut from the reference's Gen1 container layout feed the batched builder (bit-exact against the oracle)."""
+    import oracle as orc
+    from event_representation_study_amd.engine import EventBatch
+    from event_representation_study_amd.gen1_h5 import Gen1H5Events
+    d = Gen1H5Events(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5", "gen1_layout.h5"), num_events=3000)
+    wins = d.windows(range(0, len(d), 3))
+    for w in wins:
+        w[:, 3] = 2 * w[:, 3] - 1                                    # p in {0, 1} -> {-1, +1}, as the dispatcher's callers map it
+    got = EventBatch.from_numpy(wins, d.height, d.width).optimized().cpu().numpy()
+    for b, w in enumerate(wins):
+        assert_bit_equal(got[b], orc.ergo12(w, d.height, d.width), "window %d" % b)
+
+
 def test_tore_coordinates_below_one_wrap_like_numpy():
     """1-based x, y < 1 are negative numpy indices in the reference (tore.py:25,41: [i - 1, j - 1]) and wrap to the far side of
     the frame; golden from the reference's own function (tests/golden/make_golden_sbt.py).  Beyond the frame: IndexError."""

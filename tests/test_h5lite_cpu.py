@@ -66,6 +66,32 @@ def test_reader_on_the_evlicious_container_with_its_blosc_filter():
         assert int(f["events/width"][()]) == 1280 and int(f["events/height"][()]) == 720 and int(f["events/divider"][()]) == 1
 
 
+def test_gen1_container_windows_and_partial_reads():
+    """The reference's Gen1 layout (gen1_2yolo.py:72-82,168-198), written by real h5py: sample idx = the num_events events in
+    front of the idx-th labelled timestamp, recordings in name order, t rebased; only the chunks a slice touches are decoded."""
+    from event_representation_study_amd.gen1_h5 import Gen1H5Events
+    ex = np.load(os.path.join(H5, "gen1_layout_expected.npz"))
+    d = Gen1H5Events(os.path.join(H5, "gen1_layout.h5"), num_events=3000)
+    assert len(d) == 14 and (d.height, d.width) == (240, 304)
+    for i in range(len(d)):
+        w = d.window(i)
+        assert w.dtype == np.int32 and w.shape[1] == 4
+        np.testing.assert_array_equal(w, ex["w%02d" % i])
+    assert len(d.window(0)) == 1500                                  # fewer events than the window in front of the first label
+    assert d.locate(7)[0] == 0 and d.locate(6)[0] == 6 and d.locate(7)[1] != d.locate(6)[1]
+    with pytest.raises(IndexError):
+        d.window(14)
+    # partial reads: slices along axis 0 agree with the whole dataset, whatever the chunk boundaries
+    with h5lite.File(os.path.join(H5, "gen1_layout.h5")) as f:
+        t = f[d._file_names[0] + "/events/t"]
+        whole = t.read()
+        for a, b in ((0, 1), (2047, 2049), (4096, 4096), (5000, 19999), (19990, 30000), (0, 20000)):
+            np.testing.assert_array_equal(t[a:b], whole[a:b])
+        np.testing.assert_array_equal(t[::3], whole[::3])           # anything else falls back to the full read
+    with h5lite.File(os.path.join(H5, "events_evlicious_blosc.h5")) as f:
+        np.testing.assert_array_equal(f["events/t"][3000:9001], np.load(os.path.join(H5, "blosc_expected.npz"))["evl_t"][3000:9001])
+
+
 def test_reader_on_gen4_layout_written_by_h5py():
     e = dict(np.load(os.path.join(H5, "expected.npz")))
     f = h5lite.File(os.path.join(H5, "events_gen4_layout.h5"))
