@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_gwd_stats_finish(const double *__restric
 // points beyond N.  float32 form: dimension-major YA, YB = [2 * steps][Npad].  Split form: chunk `sub` of the point
 // (the launch spreads the chunks over blockIdx.z), ZA, ZB = [2 * split_steps][Npad] x 8 bfloat16, one 16-byte store each.
 __device__ __forceinline__ void gwd_prep_body(const double *__restrict__ X, int64_t N, int d, int64_t Npad, int blk,
-                                     const double *__restrict__ fin, bool split, int sub,
+                                     const double *__restrict__ fin, bool split, int sub, int nsub,
                                      float *__restrict__ YA, float *__restrict__ YB) {
     const int64_t i = (int64_t)blk * kThreads + threadIdx.x;
     if (i >= Npad) return;
@@ -194,18 +194,20 @@ __device__ __forceinline__ void gwd_prep_body(const double *__restrict__ X, int6
     const int kp = 2 * gwd_steps(d);
     const bool real = i < N;
     if (split) {
-        if (sub >= 2 * gwd_split_steps(d)) return;
         const double *xrow = X + (real ? i : 0) * d;
-        uint4 za = make_uint4(0u, 0u, 0u, 0u), zb = za;
-        switch (sub) {   // wave-uniform
+        const int nchunks = 2 * gwd_split_steps(d);
+        for (int c = sub; c < nchunks; c += nsub) {   // nsub = gridDim.z: how far the launch spreads a point's chunks
+            uint4 za = make_uint4(0u, 0u, 0u, 0u), zb = za;
+            switch (c) {   // wave-uniform
 #define GWD_CHUNK(C) case C: gwd_split_chunk<C>(xrow, fin, sc, d, real, za, zb); break;
-            GWD_CHUNK(0) GWD_CHUNK(1) GWD_CHUNK(2) GWD_CHUNK(3) GWD_CHUNK(4) GWD_CHUNK(5)
-            GWD_CHUNK(6) GWD_CHUNK(7) GWD_CHUNK(8) GWD_CHUNK(9) GWD_CHUNK(10) GWD_CHUNK(11)
+                GWD_CHUNK(0) GWD_CHUNK(1) GWD_CHUNK(2) GWD_CHUNK(3) GWD_CHUNK(4) GWD_CHUNK(5)
+                GWD_CHUNK(6) GWD_CHUNK(7) GWD_CHUNK(8) GWD_CHUNK(9) GWD_CHUNK(10) GWD_CHUNK(11)
 #undef GWD_CHUNK
-            default: break;
+                default: break;
+            }
+            gstore16(reinterpret_cast<uint4 *>(YA) + (int64_t)c * Npad + i, za);
+            gstore16(reinterpret_cast<uint4 *>(YB) + (int64_t)c * Npad + i, zb);
         }
-        gstore16(reinterpret_cast<uint4 *>(YA) + (int64_t)sub * Npad + i, za);
-        gstore16(reinterpret_cast<uint4 *>(YB) + (int64_t)sub * Npad + i, zb);
         return;
     }
     if (sub != 0) return;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep(const double *__restrict_
                                                       float *__restrict__ YtA, float *__restrict__ YtB) {
     const int c = (int)blockIdx.x >= sblocks ? 1 : 0;  // which cloud this block scales
     gwd_prep_body(c ? Xt : Xs, c ? m : n, c ? dt : ds, c ? mpad : npad, (int)blockIdx.x - (c ? sblocks : 0),
-                  fin + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z, c ? YtA : YsA, c ? YtB : YsB);
+                  fin + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z, (int)gridDim.z, c ? YtA : YsA, c ? YtB : YsB);
 }
 
 // Operands of one 32-point strip for v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3): lane l holds
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(kThreads) void k_gwd_prep_batch(const GwdPair *__re
     const int64_t Npad = c ? q.a.mpad : q.a.npad;
     if ((int64_t)blk * kThreads >= Npad) return;
     gwd_prep_body(c ? q.Xt : q.Xs, c ? q.a.m : q.a.n, c ? dt : ds, Npad, blk,
-                  q.stat + (size_t)2 * kStatBlocks * (2 * kGwdMaxD) + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z,
+                  q.stat + (size_t)2 * kStatBlocks * (2 * kGwdMaxD) + c * kGwdFin, gwd_use_split(ds, dt), (int)blockIdx.z, (int)gridDim.z,
                   const_cast<float *>(c ? q.a.YtA : q.a.YsA), const_cast<float *>(c ? q.a.YtB : q.a.YsB));
 }
 
