@@ -948,6 +948,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_waves_per_e
 #ifndef KS_DEBUG
 #define KS_DEBUG 0  // timing experiments only (tools/experiments): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
 #endif
+constexpr int kKsHotGroup = 16;   // key groups of more records (per block) are ordered by per-wave counters, not by the repair walk
 __host__ __device__ inline size_t block_keysort_lds_bytes(int NK, int cap, int chunk) {
     return (size_t)cap * sizeof(Rec8) + (size_t)chunk * sizeof(uint16_t) + (size_t)(NK + 4) * sizeof(uint32_t);
 }
@@ -980,6 +981,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     uint32_t *base = reinterpret_cast<uint32_t *>(rankbuf + kChunk);        // [NK + 1] counts -> exclusive offsets
     __shared__ int bstats[12];  // the block's statistics, merged by one LDS atomic per wave and field (BlockStats order)
     __shared__ uint32_t tmp[kNW];
+    __shared__ uint32_t nhot_s;  // key groups of more than kKsHotGroup records in this block (see "hot groups" below)
     int b, blk;
     if (!decode_window_block(B, nblk, b, blk)) return;
     const int64_t beg = off[b];
@@ -1005,6 +1007,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         }
     }
     for (int i = threadIdx.x; i <= NK; i += TPB) base[i] = 0;
+    if (threadIdx.x == 0) nhot_s = 0u;
     if (threadIdx.x < 12) {
         const int f = threadIdx.x;  // tmin, tmax, xmin, xmax, ymin, ymax, neg, oob, status, n_valid, pad, pad
         bstats[f] = (f == 0 || f == 2 || f == 4) ? INT32_MAX : ((f == 1 || f == 3 || f == 5) ? INT32_MIN : 0);
@@ -1089,19 +1092,74 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     for (int k = 0; k < per; ++k) if (k0 + k < NK) local += base[k0 + k];
     uint32_t total;
     uint32_t run = block_exclusive_scan<kNW>(local, tmp, &total);
+    // (offsets are < 2^14: the upper half of a key's word carries its hot-group slot + 1, 0 = an ordinary group)
     for (int k = 0; k < per; ++k)
-        if (k0 + k < NK) { const uint32_t c = base[k0 + k]; base[k0 + k] = run; run += c; }
+        if (k0 + k < NK) {
+            const uint32_t c = base[k0 + k];
+            uint32_t tag = 0u;
+            if (c > (uint32_t)kKsHotGroup) tag = (atomicAdd(&nhot_s, 1u) + 1u) << 16;
+            base[k0 + k] = run | tag;
+            run += c;
+        }
     if (threadIdx.x == 0) base[NK] = total;
     if (threadIdx.x < 12) reinterpret_cast<int *>(stats + (size_t)b * nblk + blk)[threadIdx.x] = bstats[threadIdx.x];
     __syncthreads();
     uint32_t *tb = table + ((size_t)b * nblk + blk) * ((size_t)NK + 1);
     if (!(KS_DEBUG & 8))
-        for (int k = threadIdx.x; k <= NK; k += TPB) tb[k] = base[k];
+        for (int k = threadIdx.x; k <= NK; k += TPB) tb[k] = base[k] & 0xffffu;
+    const uint32_t nhot = nhot_s;   // block-uniform (written before the barrier above)
     // arrival order -> time order inside every key group
     const uint32_t mine0 = (uint32_t)(w0 + lane);
+    uint32_t hs[PL];   // hot-group slot + 1 of the record's key, 0 = ordinary group (or not placed)
 #pragma unroll
-    for (int i = 0; i < PL; ++i)
-        if (ko[i] != 0xffffffffu) rankbuf[base[ko[i] & 0xffffu] + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
+    for (int i = 0; i < PL; ++i) {
+        hs[i] = 0u;
+        if (ko[i] != 0xffffffffu) {
+            const uint32_t bw = base[ko[i] & 0xffffu];
+            hs[i] = bw >> 16;
+            if (!hs[i]) rankbuf[(bw & 0xffffu) + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
+        }
+    }
+    // Hot groups (r04).  The repair below reads g ranks per member of a g-record group -- fine for the 2-4 records a key holds
+    // on uniform windows, quadratic for a key that collects hundreds (a moving edge parallel to the sensor rows puts 4 % of a
+    // window into one 128-pixel chunk: binning of 32 such windows 88 us instead of 20).  A group of more than kKsHotGroup
+    // records is ordered the way k_block_rowsort orders its rows instead: one counter per (wave, hot group) -- there are at
+    // most kChunk / (kKsHotGroup + 1) hot groups, so the counters fit the record stage, which is idle until the write-out --
+    // an exclusive prefix over the waves, and a ballot multisplit inside the wave, batch by batch (rank = wave-major, then
+    // batch, then lane: exactly the block rank order).  Linear in the group's size.
+    if (nhot) {
+        constexpr int kHs = kChunk / 16;                                // slots per wave row; nhot < kHs
+        uint32_t *hcnt = reinterpret_cast<uint32_t *>(stage);           // [kNW][kHs], cap * 8 >= kNW * kHs * 4
+        for (uint32_t t = lane; t < nhot; t += kWave) hcnt[wave * kHs + t] = 0u;
+        wave_phase_lds();
+#pragma unroll
+        for (int i = 0; i < PL; ++i)
+            if (hs[i]) atomicAdd(&hcnt[wave * kHs + hs[i] - 1u], 1u);
+        __syncthreads();
+        if (threadIdx.x < nhot) {
+            uint32_t acc = 0;
+            for (int w = 0; w < kNW; ++w) { const uint32_t c = hcnt[w * kHs + threadIdx.x]; hcnt[w * kHs + threadIdx.x] = acc; acc += c; }
+        }
+        __syncthreads();
+        const int hbits = bits_for((int)nhot);
+        volatile uint32_t *vh = hcnt + wave * kHs;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+            const bool hot = hs[i] != 0u;
+            if (!__any(hot)) continue;
+            const uint32_t slot = hot ? hs[i] - 1u : 0u;
+            uint32_t rk; bool last;
+            wave_match(slot, hbits, hot, lane, rk, last);
+            uint32_t pos = 0;
+            if (hot) {
+                pos = vh[slot] + rk;
+                ko[i] = (base[ko[i] & 0xffffu] & 0xffffu) + pos;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (hot && last) vh[slot] = pos + 1;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     __syncthreads();
     {
         // the eight group walks of a lane advance together: eight independent LDS reads in flight per step instead of
@@ -1111,10 +1169,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             gb[i] = 0; g[i] = 0; sm[i] = 0;
-            if (ko[i] != 0xffffffffu) {
+            if (ko[i] != 0xffffffffu && !hs[i]) {
                 const uint32_t key = ko[i] & 0xffffu;
-                gb[i] = base[key];
-                g[i] = base[key + 1] - gb[i];
+                gb[i] = base[key] & 0xffffu;
+                g[i] = (base[key + 1] & 0xffffu) - gb[i];
                 if (KS_DEBUG & 1) { sm[i] = ko[i] >> 16; g[i] = 0; }
                 if (g[i] == 1) g[i] = 0;  // alone in its group
                 gmax = max(gmax, g[i]);
@@ -1128,8 +1186,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         }
 #pragma unroll
         for (int i = 0; i < PL; ++i)
-            if (ko[i] != 0xffffffffu) ko[i] = gb[i] + sm[i];
+            if (ko[i] != 0xffffffffu && !hs[i]) ko[i] = gb[i] + sm[i];
     }
+    if (nhot) __syncthreads();   // the hot-group counters live in the stage: every wave has read its own before the write-out
     Rec8 *dst = reinterpret_cast<Rec8 *>(sorted1) + beg + lo;   // the block's own slot, 8 bytes per record
     for (uint32_t pb = 0; pb < total && !(KS_DEBUG & 2); pb += (uint32_t)cap) {
         if (pb) __syncthreads();  // the previous round has left the stage

@@ -1,15 +1,24 @@
 """Shared helpers of the per-sample wrappers (B = 1 batches on the current HIP device).
 
-r03: a per-sample call no longer allocates.  One pooled context per (process, device, H, W, size bucket) keeps the plan and
-its workspace, a pinned staging buffer for the events, the device event buffer, the output tensors and a ring of pinned
-result buffers; a call is  host convert -> async H2D -> bin -> build -> async copy of the window statistics -> async D2H of
-the result -> ONE stream synchronisation -> the status word is checked and the exception the reference raises is raised.
-The array a wrapper returns is a view of a pinned ring slot: it stays valid for the next RESULT_RING_DEPTH - 1 calls of the
-same shape (the reference's callers resize / convert it at once); pass ``out=`` for a copy into your own array, or set
-``EVREP_RESULT_RING=0`` for a fresh array per call (one more host copy of the result).
+A per-sample call does not allocate device memory.  One pooled context per (process, host thread, device, stream, H, W, size
+bucket, plan flags, pacing) keeps the plan and its workspace, a pinned staging buffer for the events (the window's two
+offsets travel in front of them: ONE H2D per call), the device buffers, the output tensors and a pool of pinned result
+buffers; a call is  host convert -> async H2D -> bin -> build -> async copy of the window statistics -> async D2H of the
+result -> ONE stream synchronisation -> the status word is checked and the exception the reference raises is raised.
+
+**What a wrapper returns is the caller's own (r04).**  "outputs are fresh arrays" -- a caller may keep any number
+of results (a list comprehension over samples, a caching dataset, a collate over a batch).  The array handed out is a view of a
+pinned pool buffer, and a pool buffer is handed out again only when nothing outside refers to it any more (numpy keeps every
+view's ``base`` pointing at the buffer's master array, so the master's reference count says so exactly); while
+``RESULT_POOL_DEPTH`` buffers of a shape are all still held by the caller, further results are plain fresh numpy arrays (one
+more host copy).  A caller that drops each result before the next call (the reference's resize / ``torch.tensor()`` flows)
+keeps the pooled speed; nobody sees a buffer change under their feet.  ``out=`` copies into the caller's own array;
+``device_out=True`` (``get_item_transform_cuda``) skips the D2H and returns a fresh ``(H, W, C)`` CUDA tensor.
 """
 import ctypes
 import os
+import sys
+import threading
 
 import numpy as np
 import torch
@@ -18,24 +27,43 @@ from .. import _lib
 from ..engine import EventBatch, _ptr, _require_gpu, _stream_ptr
 from ..synthetic import from_structured, narrow_to_int32
 
-RESULT_RING_DEPTH = int(os.environ.get("EVREP_RESULT_RING", "8"))
+RESULT_POOL_DEPTH = int(os.environ.get("EVREP_RESULT_POOL", os.environ.get("EVREP_RESULT_RING", "8")))
 _CONTEXTS = {}
+_CONTEXTS_LOCK = threading.Lock()
+
+
+class _ResultSlot:
+    """One pinned result buffer.  ``master`` is the numpy array every handed-out view has as its ``base``; the slot is
+    free when only this object refers to it."""
+
+    def __init__(self, shape, dtype, pin=True):
+        self.tensor = torch.empty(shape, dtype=dtype, pin_memory=pin)
+        self.master = self.tensor.numpy()
+        self.idle = sys.getrefcount(self.master)        # the references this object itself accounts for
+
+    def free(self):
+        return sys.getrefcount(self.master) <= self.idle
 
 
 class _SampleContext:
     """Everything a B = 1 call needs, allocated once."""
 
-    def __init__(self, height, width, cap, device):
+    def __init__(self, height, width, cap, device, plan_flags, pacing):
         self.cap = int(cap)
         self.device = device
-        self.ev_pinned = torch.empty((self.cap, 4), dtype=torch.int32, pin_memory=True)
-        self.ev_dev = torch.empty((self.cap, 4), dtype=torch.int32, device=device)
-        self.off_pinned = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+        # [offsets: 2 x int64 = one 16-byte row][events: cap rows]: one pinned buffer, one device buffer, one H2D
+        self.buf_pinned = torch.zeros((self.cap + 1, 4), dtype=torch.int32, pin_memory=True)
+        self.buf_dev = torch.zeros((self.cap + 1, 4), dtype=torch.int32, device=device)
+        self.ev_pinned = self.buf_pinned[1:]
+        self.ev_dev = self.buf_dev[1:]
+        self.off_pinned = self.buf_pinned[0].view(torch.int64)          # (2,) int64
         self.batch = EventBatch(self.ev_dev, torch.tensor([0, self.cap], dtype=torch.int64), height, width,
-                                max_events_per_window=self.cap)
+                                max_events_per_window=self.cap, plan_flags=plan_flags, pacing=pacing)
+        self.batch.offsets = self.buf_dev[0].view(torch.int64)          # the device offsets live in front of the events
         self.meta_pinned = torch.zeros(16, dtype=torch.int32, pin_memory=True)      # one 64-byte WindowMeta
         self.outs = {}          # (C, dtype) -> (1, H, W, C) device tensor
-        self.rings = {}         # (shape, dtype) -> [pinned tensors], position
+        self.pools = {}         # (shape, dtype) -> [_ResultSlot]
+        self.staging = {}       # (shape, dtype) -> pinned tensor never handed out (results beyond the pool's depth)
 
     def out(self, C, dtype):
         key = (int(C), dtype)
@@ -43,15 +71,22 @@ class _SampleContext:
             self.outs[key] = torch.empty((1, self.batch.H, self.batch.W, int(C)), dtype=dtype, device=self.device)
         return self.outs[key]
 
-    def ring_slot(self, shape, dtype):
+    def result_slot(self, shape, dtype):
+        """A pinned buffer nobody outside refers to, or None when the caller still holds all of this shape's."""
+        pool = self.pools.setdefault((tuple(shape), dtype), [])
+        for slot in pool:
+            if slot.free():
+                return slot
+        if len(pool) < RESULT_POOL_DEPTH:
+            pool.append(_ResultSlot(tuple(shape), dtype))
+            return pool[-1]
+        return None
+
+    def staging_buffer(self, shape, dtype):
         key = (tuple(shape), dtype)
-        ring = self.rings.setdefault(key, [[], -1])
-        depth = max(RESULT_RING_DEPTH, 1)
-        if len(ring[0]) < depth:
-            ring[0].append(torch.empty(shape, dtype=dtype, pin_memory=True))
-            return ring[0][-1]
-        ring[1] = (ring[1] + 1) % depth
-        return ring[0][ring[1]]
+        if key not in self.staging:
+            self.staging[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
+        return self.staging[key]
 
 
 def _context(height, width, n):
@@ -59,10 +94,17 @@ def _context(height, width, n):
     cap = 4096
     while cap < n:
         cap *= 2
-    key = (os.getpid(), str(dev), int(height), int(width), cap)      # per process: a HIP context does not survive fork()
-    ctx = _CONTEXTS.get(key)
+    flags, pacing = _lib.plan_flags_from_env(), _lib.pacing_from_env()
+    # per process (a HIP context does not survive fork()), per host thread and per stream: two threads or two streams never
+    # share a staging buffer, an output tensor or a workspace
+    key = (os.getpid(), threading.get_ident(), str(dev), int(torch.cuda.current_stream(dev).cuda_stream), int(height),
+           int(width), cap, flags, pacing)
+    with _CONTEXTS_LOCK:
+        ctx = _CONTEXTS.get(key)
     if ctx is None:
-        ctx = _CONTEXTS[key] = _SampleContext(height, width, cap, dev)
+        ctx = _SampleContext(height, width, cap, dev, flags, pacing)
+        with _CONTEXTS_LOCK:
+            _CONTEXTS[key] = ctx
     return ctx
 
 
@@ -70,11 +112,14 @@ class SampleBatch:
     """One pooled window: ``.batch`` is the resident EventBatch (its builders take ``out=``), ``.out(C, dtype)`` the pooled
     output tensor, ``finish()`` the one synchronisation."""
 
-    def __init__(self, ctx, n):
+    def __init__(self, ctx, n, device_out=False):
         self.ctx, self.batch, self.n = ctx, ctx.batch, int(n)
         self.H, self.W = ctx.batch.H, ctx.batch.W
+        self.device_out = bool(device_out)
 
     def out(self, C, dtype):
+        if self.device_out:     # the caller keeps this tensor: a fresh one (torch's caching allocator: no hipMalloc in steady state)
+            return torch.empty((1, self.H, self.W, int(C)), dtype=dtype, device=self.ctx.device)
         return self.ctx.out(C, dtype)
 
     # the builders of EventBatch with the pooled output tensor as default destination
@@ -108,8 +153,9 @@ class SampleBatch:
         return out
 
 
-def sample_batch(event_sequence, height, width, truncate=False, rebase_t=False):
-    """Structured x,y,t,p record array (or (n,4) array) -> the pooled one-window batch, events on their way to the GPU."""
+def sample_batch(event_sequence, height, width, truncate=False, rebase_t=False, device_out=False):
+    """Structured x,y,t,p record array (or (n,4) array) -> the pooled one-window batch, events on their way to the GPU.
+    device_out: the builders write into a FRESH device tensor and finish() returns it (no D2H)."""
     _require_gpu()                 # no CPU fallback: without the HIP library or a GPU the wrappers raise
     _lib.load()
     if isinstance(event_sequence, np.ndarray) and event_sequence.dtype.names:
@@ -123,27 +169,37 @@ def sample_batch(event_sequence, height, width, truncate=False, rebase_t=False):
     stream.synchronize()          # the previous call's H2D has left the staging buffer (its own finish() synchronised: free)
     ctx.ev_pinned[:n].numpy()[...] = ev
     ctx.off_pinned[1] = n
-    ctx.ev_dev[:n].copy_(ctx.ev_pinned[:n], non_blocking=True)
-    b.offsets.copy_(ctx.off_pinned, non_blocking=True)
+    ctx.buf_dev[:n + 1].copy_(ctx.buf_pinned[:n + 1], non_blocking=True)     # offsets + events: one H2D
     b.offsets_host = ctx.off_pinned.clone()
     b._binned = False
-    return SampleBatch(ctx, n)
+    return SampleBatch(ctx, n, device_out)
 
 
 def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None, allow_unsorted=False):
     """Status + result in ONE synchronisation.  dev_out: the (1, H, W, C) device tensor a builder filled.  Returns the
-    (H, W, C) numpy array (TORE: the bounding-box frame) or raises what the reference raises."""
+    (H, W, C) numpy array (TORE: the bounding-box frame) -- the caller's own, see the module docstring -- or, for a
+    ``device_out`` sample, the CUDA tensor itself; raises what the reference raises."""
     ctx, b = sb.ctx, sb.batch
     b.bin()
     with torch.cuda.device(b.device):
         _lib.check(b.lib.evrep_copy_window_meta_async(ctypes.byref(b.plan), _ptr(b.workspace), _ptr(ctx.meta_pinned),
                                                       _stream_ptr()), "evrep_copy_window_meta_async")
-    host = ctx.ring_slot(tuple(dev_out.shape[1:]), dev_out.dtype)
-    host.copy_(dev_out[0], non_blocking=True)
+    shape = tuple(dev_out.shape[1:])
+    slot = host = None
+    if not sb.device_out:
+        slot = ctx.result_slot(shape, dev_out.dtype) if out is None else None
+        host = slot.tensor if slot is not None else ctx.staging_buffer(shape, dev_out.dtype)
+        host.copy_(dev_out[0], non_blocking=True)
     torch.cuda.current_stream(b.device).synchronize()
     meta = ctx.meta_pinned.numpy()
     _raise_for_status_word(int(meta[8]) & 0xffffffff, b, allow_oob, what, allow_unsorted)
-    arr = host.numpy()
+    if sb.device_out:
+        res = dev_out[0]
+        if tore_k is not None:
+            hb, wb = int(meta[5]) - int(meta[4]) + 1, int(meta[3]) - int(meta[2]) + 1
+            res = res.reshape(-1)[: hb * wb * 2 * tore_k].view(hb, wb, 2 * tore_k)
+        return res
+    arr = slot.master.view() if slot is not None else host.numpy()      # a view whose base is the slot's master array
     if tore_k is not None:          # the events' bounding box, origin-shifted (gen1_transforms.py:61-64): a prefix of the buffer
         xmin, xmax, ymin, ymax = int(meta[2]), int(meta[3]), int(meta[4]), int(meta[5])
         hb, wb = ymax - ymin + 1, xmax - xmin + 1
@@ -151,7 +207,7 @@ def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None, 
     if out is not None:
         np.copyto(out, arr)
         return out
-    return arr if RESULT_RING_DEPTH > 0 else arr.copy()
+    return arr if slot is not None else arr.copy()      # the pool is exhausted (the caller holds it all): a plain fresh array
 
 
 def _raise_for_status_word(st, batch, allow_oob, what, allow_unsorted=False):

@@ -6,3 +6,8 @@ from . import gen1_transforms
 def get_item_transform(reshaped_return_data, representation_name, transform, height, width, num_events):
     return gen1_transforms.get_item_transform(reshaped_return_data, representation_name, transform, height, width,
                                               num_events, None)
+
+
+def get_item_transform_cuda(reshaped_return_data, representation_name, transform, height, width, num_events):
+    return gen1_transforms.get_item_transform_cuda(reshaped_return_data, representation_name, transform, height, width,
+                                                   num_events, None)

@@ -16,12 +16,12 @@ class ToVoxelGrid:
         self.sensor_size = sensor_size
         self.n_time_bins = int(n_time_bins)
 
-    def build_hwt(self, events, scale=1.0):
+    def build_hwt(self, events, scale=1.0, device_out=False):
         """(H, W, T) float64 on the host, `scale` folded into the kernel (what the dispatcher wants)."""
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
         if self.n_time_bins > 16:
             raise NotImplementedError("ToVoxelGrid: n_time_bins > 16")
-        sb = sample_batch(events, H, W)
+        sb = sample_batch(events, H, W, device_out=device_out)
         return finish(sb, sb.voxel(bins=self.n_time_bins, mode=1, scale=float(scale)), what="ToVoxelGrid")
 
     def __call__(self, events):
@@ -36,11 +36,18 @@ class ToImage:
     def __init__(self, sensor_size):
         self.sensor_size = sensor_size
 
-    def __call__(self, events):
+    def _build(self, events, device_out):
         W, H = int(self.sensor_size[0]), int(self.sensor_size[1])
-        sb = sample_batch(events, H, W)
+        sb = sample_batch(events, H, W, device_out=device_out)
         # counts of p == 0 ("count_neg" falls back to p == 0 when no -1 is present) and of p == 1
         import torch
         rep = sb.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"], dtype=torch.float32)
         frames = rep[0].permute(2, 0, 1).to(torch.int16).contiguous()[None]     # counts are exact in float32
         return finish(sb, frames, what="ToImage")
+
+    def __call__(self, events):
+        return self._build(events, False)
+
+    def build_cuda(self, events):
+        """The (2, H, W) int16 frame as a CUDA tensor (get_item_transform_cuda)."""
+        return self._build(events, True)

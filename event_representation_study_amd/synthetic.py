@@ -104,3 +104,79 @@ def from_structured(rec, truncate=False, rebase_t=False):
             v = v - v.min()
         ev[:, k] = int64_to_int32(v, name)
     return ev
+
+
+# ----------------------------------------------------------------------------------------------
+# Non-uniform streams (r04).  Real event windows are edge-clustered; the SURVEY 8(d) contract above (x, y ~ U) is the
+# headline's workload, these two are what the sweep measures beside it (tools/bench_sweep.py, bench.py `sweep`).
+# ----------------------------------------------------------------------------------------------
+def _finish(x, y, t, n, rng, polarity, single_polarity=None):
+    ev = np.empty((n, 4), dtype=np.int32)
+    ev[:, 0], ev[:, 1] = x, y
+    t = t.astype(np.int32)
+    if n:
+        t -= t[0]
+    ev[:, 2] = t
+    pol = rng.integers(0, 2, size=n).astype(np.int32)
+    if polarity == "pm1":
+        pol = 2 * pol - 1
+    elif polarity != "01":
+        raise ValueError(polarity)
+    if single_polarity is not None:
+        pol[:] = single_polarity
+    ev[:, 3] = pol
+    return ev
+
+
+def make_events_moving_circle(n, width, height, seed=0, span_us=50000, polarity="pm1", flow=(10.0, 0.0),
+                              circle_radius=5.0, starting_point=(10.0, 10.0)):
+    """The reference's own fake stream -- ev-licious ``generate_fake_events``
+    (ev-licious/src/evlicious/io/utils/fake_events.py:5-29): every event lies on the rim of a circle that moves with
+    the optical flow, ``x = u0 + t*vx + r cos(a)``, ``y = v0 + t*vy + r sin(a)``, ``t ~ sort(U[0,1))``, ``a ~ U[0, 2pi)``
+    -- restated with a seeded generator and scaled from its 30x30 default frame to ``width x height`` (all lengths times
+    ``min(width, height) / 30``), so the default flow (10, 0) sweeps a third of the frame and every event stays in frame
+    (the reference masks out-of-frame events; none arise here for width >= height).  The rim's tangent rows collect ~4 %
+    of the window each: a handful of 128-pixel units hold a thousand records while most of the frame is empty."""
+    rng = np.random.default_rng(seed)
+    s = min(width, height) / 30.0
+    time = np.sort(rng.random(n))
+    angle = rng.random(n) * 2.0 * np.pi
+    u0, v0 = starting_point[0] * s, starting_point[1] * s
+    x = (u0 + time * flow[0] * s + np.cos(angle) * circle_radius * s).astype(np.int64)
+    y = (v0 + time * flow[1] * s + np.sin(angle) * circle_radius * s).astype(np.int64)
+    np.clip(x, 0, width - 1, out=x)      # a caller's own flow / start may leave the frame: clamp instead of dropping,
+    np.clip(y, 0, height - 1, out=y)     # so that the window keeps its n events
+    return _finish(x, y, time * span_us, n, rng, polarity)
+
+
+def make_events_edges(n, width, height, seed=0, span_us=50000, polarity="pm1", hot_fraction=0.8, hot_pixels=0.05,
+                      n_edges=12, thickness=3):
+    """Edge-cluster model: ``hot_fraction`` of the events fall (uniformly) on the pixels of ``n_edges`` straight edges of
+    ``thickness`` pixels and random position / orientation that together cover ``hot_pixels`` of the frame, the rest is
+    uniform background.  With the defaults 80 % of the events lie on 5 % of the pixels (2.6 events per edge pixel for a
+    640x480 window of 50 000 events): near-horizontal edges give row chunks of several hundred records, near-vertical
+    ones a few hot pixels in many chunks."""
+    rng = np.random.default_rng(seed)
+    target = int(hot_pixels * width * height)
+    mask = np.zeros((height, width), dtype=bool)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for k in range(n_edges):
+        # edge k: the pixels within thickness/2 of a segment through a random point, random direction, of the length
+        # that gives the edge its share of the target area
+        cx, cy = rng.random() * width, rng.random() * height
+        th = rng.random() * np.pi
+        half = 0.5 * target / (n_edges * thickness)
+        dx, dy = np.cos(th), np.sin(th)
+        along = (xx - cx) * dx + (yy - cy) * dy
+        across = -(xx - cx) * dy + (yy - cy) * dx
+        mask |= (np.abs(along) <= half) & (np.abs(across) <= thickness / 2.0)
+    hot = np.flatnonzero(mask.reshape(-1))
+    n_hot = int(round(hot_fraction * n)) if hot.size else 0
+    pix = np.concatenate([hot[rng.integers(0, max(hot.size, 1), size=n_hot)],
+                          rng.integers(0, width * height, size=n - n_hot)])
+    rng.shuffle(pix)
+    t = np.sort(rng.integers(0, span_us, size=n))
+    return _finish(pix % width, pix // width, t, n, rng, polarity)
+
+
+GENERATORS = {"uniform": make_events, "circle": make_events_moving_circle, "edges": make_events_edges}

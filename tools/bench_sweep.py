@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from event_representation_study_amd.engine import EventBatch  # noqa: E402
-from event_representation_study_amd.synthetic import make_events  # noqa: E402
+from event_representation_study_amd.synthetic import GENERATORS  # noqa: E402
 
 
 def timed(fn, iters):
@@ -41,12 +41,20 @@ CONFIGS = {
 HBM_PEAK_GBPS = 8000.0
 
 
+def split_tag(tag):
+    """"c2@circle" -> ("c2", "circle"): a geometry of CONFIGS and an event distribution of synthetic.GENERATORS
+    (uniform -- SURVEY 8(d)'s contract -- when none is named)."""
+    base, _, dist = tag.partition("@")
+    return base, (dist or "uniform")
+
+
 def sweep(tags=("gen1", "c2", "c2-dense", "c3", "c3-1M"), iters=20, builders=None, device="cuda:0"):
     """Rows of the sweep as dicts (bench.py's `sweep` leg calls this with fewer iterations)."""
     rows = []
     for tag in tags:
-        W, H, N, B = CONFIGS[tag]
-        wins = [make_events(N, W, H, seed=7000 + i) for i in range(B)]
+        base, dist = split_tag(tag)
+        W, H, N, B = CONFIGS[base]
+        wins = [GENERATORS[dist](N, W, H, seed=7000 + i) for i in range(B)]
         eb = EventBatch.from_numpy(wins, H, W, device=device)
         t_bin = timed(lambda: eb.rebin(), iters)
         tnorm = torch.rand(eb.total, dtype=torch.float64, device=device)  # one normalised time per event
@@ -68,7 +76,7 @@ def sweep(tags=("gen1", "c2", "c2-dense", "c3", "c3-1M"), iters=20, builders=Non
             ms = timed(lambda: fn(out), iters)
             elem = out.element_size()
             alg = B * (16 * N + elem * H * W * C)
-            rows.append({"config": tag, "W": W, "H": H, "events_per_window": N, "batch": B, "builder": name,
+            rows.append({"config": base, "distribution": dist, "W": W, "H": H, "events_per_window": N, "batch": B, "builder": name,
                          "binning_pass": int(eb.plan.reserved), "bin_ms": round(t_bin, 4), "build_ms": round(ms, 4),
                          "algorithmic_bytes": alg, "build_GBps": round(alg / ms / 1e6, 1),
                          "build_frac_of_8TBps": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 3),
@@ -80,8 +88,9 @@ def sweep(tags=("gen1", "c2", "c2-dense", "c3", "c3-1M"), iters=20, builders=Non
 
 
 def main():
-    tags = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
-    for row in sweep(tags):
+    tags = [a for a in sys.argv[1:] if split_tag(a)[0] in CONFIGS and split_tag(a)[1] in GENERATORS] or list(CONFIGS)
+    only = [a[2:] for a in sys.argv[1:] if a.startswith("b=")] or None     # b=optimized_f64 b=event_stack_f32 ...
+    for row in sweep(tags, builders=only):
         print(json.dumps(row), flush=True)
 
 
