@@ -972,9 +972,11 @@ template <int TPB, int PL = 8>   // PL = events per lane: a workgroup orders TPB
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024 ? KS_WAVES_1024 : KS_WAVES_512))) void k_block_keysort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int kpr, int nblk, int cap,
                                                              uint32_t *__restrict__ table, BlockStats *__restrict__ stats,
-                                                             Rec *__restrict__ sorted1, int64_t *__restrict__ nwin) {
+                                                             Rec *__restrict__ sorted1, int64_t *__restrict__ nwin,
+                                                             uint32_t *__restrict__ hot) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr int kChunk = TPB * PL, kNW = TPB / kWave, kPerWave = PL * kWave;
+    if (blockIdx.x == 0 && threadIdx.x < 128) hot[threadIdx.x * 16] = 0u;   // the builders' hot lists (2 x 64 sublist counters) start empty
     const int NK = H * kpr;
     Rec8 *stage = reinterpret_cast<Rec8 *>(smem_raw);                       // [cap], output order, 8-byte records
     uint16_t *rankbuf = reinterpret_cast<uint16_t *>(stage + cap);          // [kChunk] rank inside the block, arrival order

@@ -62,9 +62,11 @@ struct UnitCfg {
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
 // average record count per chunk, see unit_cfg() in evrep_capi.hip.
 
-// LDS carve of one builder wave.
-template <typename OutT>
+// LDS carve of one builder wave.  HOT_: the wave belongs to a HOT launch (run_units): it may run the paths of units that
+// do not fit the stage (the spill sort of unit_records, emit_rounds); a main launch defers such units instead.
+template <typename OutT, bool HOT_ = false>
 struct WaveLds {
+    static constexpr bool kHot = HOT_;
     OutT *tile;   // kPartPx * C elements, output layout (pixel-major, channel-minor)
     OutT *bg;     // EVREP_MAX_CHANNELS background values (the empty-pixel value of every channel)
     uint2 *segs;  // (pixel offset inside the chunk, first record index); entry nseg = sentinel
@@ -72,6 +74,12 @@ struct WaveLds {
     int segcap;   // capacity of segs (pixels a unit can hold: span * kChunkPx, one more chunk for TORE's shift)
     int nstage;
     int partpx;   // pixels of the part tile
+    // the HOT stage (r04, emit_rounds): a unit of more records than `nstage` stages them, piece by piece, across the tile
+    // AND the record stage (`bigcap` records; 448 for the float64 12-channel builder).  The background vector lies between
+    // the two and stays what it is (TimeSurface reads it inside its walks): slot j >= bigsplit skips it.
+    Rec *big;
+    int bigcap, bigsplit, bigskip;
+    __device__ inline Rec *big_at(uint32_t j) const { return big + j + (j >= (uint32_t)bigsplit ? (uint32_t)bigskip : 0u); }
     // Store pacing (r03).  The resident waves of a store-bound builder OFFER more write traffic than HBM serves (19 waves
     // per CU x 12 KiB each, ready ~3.4 us after they start: 13 TB/s).  On most physical placements of a ~1 GB output
     // tensor that oversubscription collapses the write rate to 5.6-5.9 TB/s (tools/microbench/placement_patterns{3,4}.hip:
@@ -109,9 +117,13 @@ struct WaveLds {
 #endif
         size_t o = 0;
         tile = reinterpret_cast<OutT *>(smem + o);  o += align16((size_t)partpx_ * C * sizeof(OutT));
+        bigsplit = (int)(o / sizeof(Rec));
         bg = reinterpret_cast<OutT *>(smem + o);    o += align16((size_t)EVREP_MAX_CHANNELS * sizeof(OutT));
+        bigskip = (int)(o / sizeof(Rec)) - bigsplit;
         evbuf = reinterpret_cast<Rec *>(smem + o);  o += (size_t)nstage_ * sizeof(Rec);
         segs = reinterpret_cast<uint2 *>(smem + o);
+        big = reinterpret_cast<Rec *>(smem);
+        bigcap = (int)(o / sizeof(Rec)) - bigskip;
     }
 };
 
@@ -222,6 +234,12 @@ struct BinView {
     const WindowMeta *meta;     // classic: [B]
     Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
     int nblk, fused, chunk_shift;  // events per block run = 1 << chunk_shift (a runtime 64-bit division costs ~130 scalar instructions)
+    // Hot units (r04): TWO lists, [0] / [1] = their counts, [4 + l * hot_cap ...] = the unit ids of list l, at most hot_cap
+    // each.  A main launch appends the units that do not fit its stage to list `hot_sel`; the hot launch behind it works that
+    // list off and clears the OTHER one, which the next builder call (the host alternates hot_sel) appends to (run_units)
+    uint32_t *hot;
+    uint32_t hot_cap;
+    int hot_sel;
 #ifdef EVREP_TIMING
     unsigned long long *dbg;
 #endif
@@ -238,6 +256,10 @@ struct UnitRecs {
     // (w.segs holds nseg entries + the sentinel); record `lane` (r0) belongs at stage position `pos` -- emit_chunk stages
     // its DIGEST there directly.  nseg < 0: not grouped (the segment heads are found from the staged pixel ids).
     int nseg, pos;
+    // the unit holds more records than the wave's stage and was handed to the builder's HOT launch (run_units): nothing to emit
+    bool deferred;
+    int part;   // hot launch: the 64-pixel part of the unit this wave emits (run_units)
+    uint32_t pst, pen;   // hot launch, per lane: the segment of pixel part * 64 + lane in the unit's spill slot
 };
 
 // inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts), no LDS crossbar
@@ -263,12 +285,65 @@ __device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
     return (uint32_t)x;
 }
 
+// Hot units (r04).  Every builder is TWO launches of the same body: the MAIN launch (one wave per unit, the grid of the frame)
+// emits every unit whose records fit its stage and appends the others' ids to the hot list; the HOT launch behind it (a fixed
+// grid of one-wave workgroups striding over the list, a stage of kHotStage records, registers to spare) emits those.  One
+// kernel would have to carry the hot paths' registers (the spill sort's batches, emit_rounds' ring) through every wave of the
+// frame: the float64 12-channel builder went from 75 to 115 VGPRs -- an occupancy step of the headline launch -- when they were
+// inlined into it.  On uniform windows the list is empty and the hot launch ends at once (~1.5 us of the step).
+// There are two lists and the builder calls on a plan alternate between them (evrep_capi.hip, hot_view): a hot launch cannot
+// clear the list it reads (a workgroup that is late would find it empty) without a count of the workgroups that are done --
+// one device-scope atomic per workgroup, 12 ns each on one address: 25 us per launch, measured -- so it clears the OTHER
+// list, which nothing touches while it runs and which the next call's main launch appends to.  The binning pass clears both.
+// A hot item is ONE 64-pixel part of a unit (id * 8 + part): the wave sorts the part's records out of the unit's, stages and
+// walks them with one lane per pixel -- half the latency chain of a whole 128-pixel unit, twice the waves to spread.
+constexpr int kHotStage = 256;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
+constexpr int kHotGrid = 4096;    // workgroups of a hot launch
+constexpr int kHotParts = 8;      // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
+// Each of the two lists is kHotLists SUBLISTS with a counter of its own, 64 bytes apart: a clustered batch defers ten thousand
+// units, and device-scope atomics on ONE address retire at ~12 ns each (120 us of a 150 us launch, measured); a unit goes to
+// the sublist its id hashes to.  A sublist holds four times its fair share; a full one sends the unit to the next.
+constexpr int kHotLists = 64;
+constexpr int kHotHdrWords = 2 * kHotLists * 16;
+__host__ __device__ inline uint32_t hot_sublist_cap(uint32_t cap_total) { return cap_total / (kHotLists / 4) + 64u; }
+template <bool HOT, typename Body>
+__device__ inline void run_units(const BinView &bv, Body body) {
+    if constexpr (!HOT) {
+        body(chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z)), -1);
+    } else {
+        const uint32_t l = blockIdx.x % kHotLists, capl = hot_sublist_cap(bv.hot_cap);
+        const uint32_t n = min((uint32_t)__builtin_amdgcn_readfirstlane((int)bv.hot[(bv.hot_sel * kHotLists + l) * 16]), capl);
+        if (blockIdx.x < kHotLists && threadIdx.x == 0) bv.hot[((bv.hot_sel ^ 1) * kHotLists + blockIdx.x) * 16] = 0u;
+        const uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
+        for (uint32_t it = blockIdx.x / kHotLists; it < n; it += gridDim.x / kHotLists) {
+            const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
+            if (item >= 0) body(item / kHotParts, item % kHotParts);   // (< 0: the unused tail of a sublist that filled up)
+            wave_phase();
+        }
+    }
+}
+// main launch: the `nparts` 64-pixel parts of unit `uid` go to the hot list
+__device__ inline void defer_unit(const BinView &bv, int uid, int nparts) {
+    const uint32_t capl = hot_sublist_cap(bv.hot_cap);
+    uint32_t l = ((uint32_t)uid * 0x9E3779B1u) >> 26;
+    for (int tries = 0; tries < kHotLists; ++tries, l = (l + 1) % kHotLists) {   // (wave-uniform)
+        uint32_t at = 0;
+        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[(bv.hot_sel * kHotLists + l) * 16], (uint32_t)nparts);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
+        if (at + (uint32_t)nparts <= capl) {
+            if ((int)threadIdx.x < nparts) items[at + threadIdx.x] = (uint32_t)(uid * kHotParts + (int)threadIdx.x);
+            return;
+        }
+        if (at + threadIdx.x < capl && (int)threadIdx.x < nparts) items[at + threadIdx.x] = 0xffffffffu;   // the sublist is full
+    }
+}
+
 // grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks).
 // span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
-__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &chunk) {
+__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &chunk, int u) {
     ChunkGeom g;
     const int nunit = (nchunk + span - 1) / span;
-    const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
     chunk = (u % nunit) * span;
     g.row = (u / nunit) % H;
     g.b = (u / nunit) / H;
@@ -286,9 +361,9 @@ __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &c
 // lane in `info[pixel]`; the groups' places in the stage are the prefix sums of the counts over the first lanes; the
 // segment list emit_core wants falls out of the same numbers, so the segment-head search over the staged records is
 // skipped, and the records go to the stage ONCE, digested (emit_chunk), instead of raw -> read back -> digested -> written.
-template <typename OutT>
+template <typename OutT, bool HOT>
 __device__ inline void group_single_batch(const Rec &r, bool v0, uint32_t nrec, int keybase, int npixu, int segbase,
-                                          WaveLds<OutT> &w, UnitRecs &u) {
+                                          WaveLds<OutT, HOT> &w, UnitRecs &u) {
     const int lane = threadIdx.x;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
@@ -345,14 +420,15 @@ __device__ inline void group_single_batch(const Rec &r, bool v0, uint32_t nrec, 
 //     position = records of the window with a smaller key = sum over the runs of table[k][klo]: disjoint slots,
 //     no atomics, idempotent across builders), then read back like the classic stream.
 // c0 = first sensor column of the unit (keybase = row * W + c0): what the 8-byte records are decoded against.
-template <typename OutT>
+template <typename OutT, bool HOT>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
-                                        int keybase, int npixu, WaveLds<OutT> &w, int segbase, int c0) {
+                                        int keybase, int npixu, WaveLds<OutT, HOT> &w, int segbase, int c0, int uid,
+                                        int npix_out, int part) {
     const int lane = threadIdx.x;
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = lane;
+    u.nseg = -1; u.pos = lane; u.deferred = false; u.part = -1;
     if (khi <= klo) return u;
     // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
     // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
@@ -386,33 +462,12 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const int4 *evw = bv.ev + beg;
     const int row_base = keybase - c0;
     auto s1_at = [&](uint32_t at) -> Rec { return rec8_unpack(s8[at], row_base, c0, evw); };
-    auto fetch = [&](uint32_t j) -> Rec {
-        if (nb <= kBsChainBlocks) {
-            uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
-            uint32_t prev = s;
-            for (int k = 1; k < nb; ++k) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
-                s += (j >= pk) ? sk - prev : 0u;
-                prev = sk;
-            }
-            return s1_at(s + j);
-        }
-        uint32_t lo = 0, hi = (uint32_t)nb;
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const bool go = hi - lo > 1 && runs[mid] <= j;
-            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
-        }
-        return s1_at(runs[64 + lo] + j);
-    };
     uint32_t *cnt = reinterpret_cast<uint32_t *>(w.segs);  // npixu <= segcap counters: the segment list is built later
     const int nbits = 32 - __builtin_clz((unsigned)npixu - 1u);  // npixu >= 128
     const int per4 = npixu / (4 * kWave) + ((npixu % (4 * kWave)) ? 1 : 0);  // npixu is a multiple of 128: 16-byte vectors per lane
     uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
     const int nstage = min(w.nstage, 2 * kEvStage);  // two register batches
-    if (nrec <= (uint32_t)nstage) {
+    if (!HOT && nrec <= (uint32_t)nstage) {   // (a hot wave always sorts its part out of the unit's records: below)
         // the whole unit is ordered inside LDS: up to two batches of 64 records, held in registers between the count
         // and the placement
         const bool two = nrec > (uint32_t)kWave;  // uniform
@@ -486,12 +541,62 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         u.r0 = r;
         return u;
     }
-    // a unit of more records than the stage holds: laid out in its slot of the spill stream
+    // A unit of more records than the stage holds (a HOT unit of a clustered window, r04: a moving edge parallel to the sensor
+    // rows puts a thousand records into a handful of units while the window's average is 20): laid out in its slot of the
+    // spill stream by a counting sort over the unit's pixels, then staged from there part by part (emit_rounds).  The records
+    // are fetched in register batches of kSpillBatch x 64 (8-byte records, every load of a batch in flight together -- r03
+    // took one dependent L2 round trip per 64 records, twice); a unit of up to 1024 records is fetched once.
+    if constexpr (!HOT) {   // a main launch hands the unit's parts to its hot launch
+        defer_unit(bv, uid, (npix_out + kWave - 1) / kWave);
+        u.deferred = true;
+        u.ce = nrec;
+        return u;
+    } else {
+    // the part this wave emits, in pixels of the unit: output pixel o = unit pixel o + (segbase - keybase)
+    const int plo = part * kWave + (segbase - keybase), phi = min(part * kWave + kWave, npix_out) + (segbase - keybase);
+    u.part = part;
+    constexpr int kSpillBatch = 16;
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase();
-    for (uint32_t j0 = 0; j0 < nrec; j0 += kWave)
-        if (j0 + lane < nrec) atomicAdd(&cnt[fetch(j0 + lane).x - keybase], 1u);
+    auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
+        if (nb <= kBsChainBlocks) {
+            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t prev = sx;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                sx += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return sx + j;
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && runs[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return runs[64 + lo] + j;
+    };
+    Rec8 q[kSpillBatch];
+    auto load_batch = [&](uint32_t s0) {
+#pragma unroll
+        for (int k = 0; k < kSpillBatch; ++k) {
+            const uint32_t j = s0 + (uint32_t)(k * kWave + lane);
+            q[k] = make_uint2(0u, 0u);
+            if (j < nrec) q[k] = s8[src_of(j)];
+        }
+    };
+    auto px_of = [&](const Rec8 &r) -> uint32_t { return ((r.y & 511u) - (uint32_t)c0) & 511u; };   // pixel inside the unit
+    const bool resident = nrec <= (uint32_t)(kSpillBatch * kWave);   // wave-uniform
+    for (uint32_t s0 = 0; s0 < nrec; s0 += kSpillBatch * kWave) {
+        load_batch(s0);
+#pragma unroll
+        for (int k = 0; k < kSpillBatch; ++k)
+            if (s0 + (uint32_t)(k * kWave + lane) < nrec) atomicAdd(&cnt[px_of(q[k])], 1u);
+    }
     wave_phase();
     {
         uint32_t local = 0;
@@ -512,22 +617,47 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
     }
     wave_phase();
+    // lane l owns pixel plo + l of the part: its segment [pst, pen) of the unit's pixel-sorted order, read before the
+    // placement moves the cursors
+    uint32_t pst = 0, pen = 0;
+    {
+        const int px = plo + lane;
+        if (px >= 0 && px < phi && px < npixu) { pst = cnt[px]; pen = px + 1 < npixu ? cnt[px + 1] : nrec; }
+    }
+    wave_phase();
     volatile uint32_t *vcnt = cnt;
-    for (uint32_t j0 = 0; j0 < nrec; j0 += kWave) {
-        const bool valid = j0 + lane < nrec;
-        Rec r = make_int4(0, 0, 0, 0);
-        if (valid) r = fetch(j0 + lane);
-        const uint32_t px = valid ? (uint32_t)(r.x - keybase) : 0u;
-        uint32_t rk; bool last;
-        wave_match(px, nbits, valid, lane, rk, last);
-        uint32_t pos = 0;
-        if (valid) {
-            pos = vcnt[px] + rk;
-            bv.spill[cs + pos] = r;
+    for (uint32_t s0 = 0; s0 < nrec; s0 += kSpillBatch * kWave) {
+        if (!resident) load_batch(s0);
+#pragma unroll
+        for (int k = 0; k < kSpillBatch; ++k) {
+            if (s0 + (uint32_t)(k * kWave) >= nrec) break;   // uniform
+            uint32_t px = px_of(q[k]);
+            const bool valid = s0 + (uint32_t)(k * kWave + lane) < nrec && (int)px >= plo && (int)px < phi;
+            if (!__any(valid)) continue;
+            if (!valid) px = 0u;
+            uint32_t rk; bool last;
+            wave_match(px, nbits, valid, lane, rk, last);
+            uint32_t pos = 0;
+            if (valid) {
+                pos = vcnt[px] + rk;
+                bv.spill[cs + pos] = rec8_unpack(q[k], row_base, c0, evw);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && last) vcnt[px] = pos + 1;
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && last) vcnt[px] = pos + 1;
-        __builtin_amdgcn_wave_barrier();
+    }
+    wave_phase();
+    // the segment list emit_rounds wants (it takes the counters' place): the part's non-empty pixels, relative to the builder's
+    // own origin, and their first records
+    {
+        const bool ne = pen > pst;
+        const uint64_t m = __ballot(ne);
+        const int nseg = __popcll(m);
+        if (ne) w.segs[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(part * kWave + lane), pst);
+        if (lane == 0) w.segs[nseg] = make_uint2(0u, 0u);   // (a part's last segment ends where its lane says: see emit_rounds)
+        u.nseg = nseg;
+        u.pst = pst; u.pen = pen;
     }
     // the wave reads back what its own lanes stored: same CU, same vector L1 -- workgroup-scope release / acquire
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -535,8 +665,9 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     u.cs = cs;
     u.ce = cs + nrec;
-    u.r0 = bv.spill[cs + lane];  // nrec > 64: every lane has one
+    u.nstaged = 0;   // nothing of it is in the wave's stage: emit_rounds stages it part by part
     return u;
+    }
 }
 
 // Classic passes (the stream is pixel-sorted already): records [64, min(nrec, stage)) of the unit go to the wave's LDS
@@ -544,8 +675,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 // 64 records inside the divergent segment walks -- a global load and, for the builders whose digest divides, a float64
 // division per step of the longest segment of the wave (70 % of the records of a 640x480 window of 500 000 events).
 // emit_chunk digests the staged batches one record per lane once the segment heads are listed.
-template <typename OutT>
-__device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT> &w) {
+template <typename OutT, bool HOT>
+__device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT, HOT> &w) {
     const int nrec = (int)(u.ce - u.cs), lane = threadIdx.x;
     const int n = min(nrec, w.nstage);
     // wave-uniform.  A 128-record stage (every builder on windows of > 28 records per unit) is only filled when it takes
@@ -567,14 +698,15 @@ __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT> &w) {
 }
 
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
-template <typename OutT>
+// uid = the unit's id (run_units).  A main launch (HOT false) defers a unit of more records than its stage (u.deferred).
+template <typename OutT, bool HOT>
 __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
-                                      WaveLds<OutT> &w, ChunkGeom &g) {
+                                      WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part) {
     int chunk;
-    g = unit_geom(H, W, nchunk, span, chunk);
+    g = unit_geom(H, W, nchunk, span, chunk, uid);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = g.row * nchunk + min(chunk + span, nchunk);
-        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0, g.c0);
+        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -584,7 +716,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     UnitRecs u;
     u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = (int)threadIdx.x;
+    u.nseg = -1; u.pos = (int)threadIdx.x; u.deferred = false; u.part = -1;
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
     stage_classic(u, w);
     return u;
@@ -709,9 +841,9 @@ __device__ inline void sparse_store(const OutT *vlist, const unsigned char *map,
 // `get_staged(j)` = get(j) for a unit whose records are all staged in LDS (every unit of <= 64 records): no second source,
 // so the segment walks read LDS with ds_read instead of flat loads through a two-address-space pointer.
 // `nseg_pre` >= 0: the front end has listed the segments already (UnitRecs::nseg).
-template <typename OutT, int CMAX, typename KeyAt, typename RecAt, typename RecStaged, typename PostHeads, typename Reduce>
+template <typename OutT, int CMAX, bool HOT, typename KeyAt, typename RecAt, typename RecStaged, typename PostHeads, typename Reduce>
 __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, KeyAt key_at, RecAt get, RecStaged get_staged,
-                                 PostHeads post_heads, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
+                                 PostHeads post_heads, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w,
                                  const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const int PP = w.partpx;  // pixels per part tile (wave-uniform)
@@ -866,6 +998,76 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
     }
 }
 
+// Hot launch (r04): ONE 64-pixel part of a unit of more records than a main wave's stage -- a hot unit of a clustered window
+// (a moving edge along the sensor rows leaves 25 records per pixel where the window's average is 0.2).  unit_records has
+// laid the part's records out, pixel-sorted and time-ordered inside a pixel, in the unit's slot of the spill stream
+// (`stream`); lane l owns pixel part * 64 + l, records [st, en).  Until r03 such a unit walked its segments straight from
+// global memory inside the frame's own launch -- one dependent L2 round trip (and, for the builders that divide, one float64
+// division) per step of the longest segment.  Now
+//   * a part whose records fit the hot stage (w.big_at: the part tile + the record stage) has them STAGED -- coalesced
+//     16-byte loads, eight in flight -- and digested one record per lane; the walks read LDS; only then is the tile filled,
+//     patched and streamed out;
+//   * a hotter part is walked from the stream through a four-deep register ring per lane -- the load of record j + 4 is
+//     issued when record j is consumed, so a step waits for arithmetic, not for L2 (the walks are sequential per pixel by
+//     contract: what bounds such a wave is its longest segment).
+template <typename OutT, int CMAX, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
+__device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, uint32_t st, uint32_t en, int part, Digest digest,
+                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, true> &w,
+                                 const OutT *bg, Reduce reduce) {
+    const int lane = threadIdx.x;
+    const uint32_t cap = (uint32_t)w.bigcap;
+    const int np = min(kWave, npix - part * kWave);
+    const bool mine = en > st && lane < np;
+    const uint32_t ra = (uint32_t)wave_min(mine ? (int)st : INT32_MAX), rb = (uint32_t)wave_max(mine ? (int)en : 0);
+    auto ld = [&](uint32_t j) -> Rec {
+        const uint4 v = gload16(stream + min(j, nrec - 1u));
+        return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+    };
+    OutT vals[CMAX];
+    if (__any(mine)) {
+        if (STAGE && rb - ra <= cap) {   // wave-uniform (STAGE false: a builder that reads one record per segment)
+            constexpr int kDepth = 8;   // 16-byte loads in flight per lane
+            for (uint32_t j0 = ra; j0 < rb; j0 += kDepth * kWave) {
+                Rec r[kDepth];
+#pragma unroll
+                for (int i = 0; i < kDepth; ++i) {
+                    const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
+                    r[i] = make_int4(0, 0, 0, 0);
+                    if (j < rb) r[i] = ld(j);
+                }
+#pragma unroll
+                for (int i = 0; i < kDepth; ++i) {
+                    const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
+                    if (j < rb) *w.big_at(j - ra) = digest(r[i]);
+                }
+            }
+            wave_phase();
+            if (mine) reduce(st - ra, en - ra, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
+        } else if (mine) {
+            Rec q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+            uint32_t expect = 0xffffffffu;
+            reduce(st, en, [&](uint32_t j) -> Rec {
+                if (j != expect) { q0 = ld(j); q1 = ld(j + 1); q2 = ld(j + 2); q3 = ld(j + 3); }   // a walk starts (or restarts: voxel's second pass)
+                const Rec e = q0;
+                q0 = q1; q1 = q2; q2 = q3;
+                q3 = ld(j + 4);
+                expect = j + 1;
+                return digest_fly(e);
+            }, vals);
+        }
+    }
+    wave_phase();   // the walks are done: the stage may become the tile
+    tile_fill(w.tile, np, C, bg);
+    wave_phase();
+    if (mine) {
+        OutT *t = w.tile + (size_t)lane * C;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) t[c] = vals[c];
+    }
+    wave_phase();
+    tile_store(w.tile, np * C, dst + (size_t)part * kWave * C);
+}
+
 // emit_core over a unit's pixel-sorted records.  u.r0 = record `lane`; records [64, u.nstaged) sit in the wave's LDS stage
 // (the key-sorted front end put them there), later ones are read from u.sorted[u.cs + j].
 // `digest(rec)` = the form in which the builder's reduce wants a record (identity, or with the per-event float64
@@ -878,16 +1080,20 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
 // `digest_fly(rec)` = what get(j) returns for a record that is NOT staged (read inside a walk): the same digest by
 // default; a builder whose digest is expensive and not needed by every reader of a record passes something cheaper and
 // tells the two forms apart by the index (staged: j < max(64, u.nstaged)).
-template <typename OutT, int CMAX, typename Digest, typename DigestFly, typename Reduce>
+template <typename OutT, int CMAX, bool HOT, bool STAGE = true, typename Digest, typename DigestFly, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly digest_fly, int key0, int npix, int C,
-                                  OutT *__restrict__ dst, WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
+                                  OutT *__restrict__ dst, WaveLds<OutT, HOT> &w, const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const uint32_t nrec = u.ce - u.cs, cs = u.cs, nraw = (uint32_t)u.nstaged;
     const Rec r0 = u.r0;
     const Rec *__restrict__ sorted = u.sorted;
     Rec *evbuf = w.evbuf;
-    if (lane < (int)nrec) evbuf[u.nseg >= 0 ? u.pos : lane] = digest(r0);   // grouped units: straight to the record's place
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
+    if constexpr (HOT) {   // one part of a unit beyond a main wave's stage, out of the unit's spill slot
+        emit_part<OutT, CMAX, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        return;
+    }
+    if (lane < (int)nrec) evbuf[u.nseg >= 0 ? u.pos : lane] = digest(r0);   // grouped units: straight to the record's place
     auto key_at = [&](uint32_t j) -> int { return j < (uint32_t)kWave ? r0.x : (j < nraw ? evbuf[j].x : sorted[cs + j].x); };
     auto get = [&](uint32_t j) -> Rec { return j < nst ? evbuf[j] : digest_fly(sorted[cs + j]); };
     auto get_staged = [&](uint32_t j) -> Rec { return evbuf[j]; };
@@ -897,17 +1103,20 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
             wave_phase();
         }
     };
-    emit_core<OutT, CMAX>(nrec, u.nseg, nrec <= nst, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
+    // (main launches of the classic passes: records beyond the stage are read inside the walks, as in r03)
+    emit_core<OutT, CMAX, HOT>(nrec, u.nseg, nrec <= nst, key_at, get, get_staged, post_heads, key0, npix, C, dst, w, bg, reduce);
 }
-template <typename OutT, int CMAX, typename Digest, typename Reduce>
+template <typename OutT, int CMAX, bool HOT, bool STAGE = true, typename Digest, typename Reduce>
 __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, int key0, int npix, int C, OutT *__restrict__ dst,
-                                  WaveLds<OutT> &w, const OutT *bg, Reduce reduce) {
-    emit_chunk<OutT, CMAX>(u, digest, digest, key0, npix, C, dst, w, bg, reduce);
+                                  WaveLds<OutT, HOT> &w, const OutT *bg, Reduce reduce) {
+    emit_chunk<OutT, CMAX, HOT, STAGE>(u, digest, digest, key0, npix, C, dst, w, bg, reduce);
 }
-template <typename OutT, int CMAX, typename Reduce>
-__device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT> &w,
+// no digest; STAGE false: the builder reads ONE record per segment (EventStack) -- a unit beyond the stage is walked from
+// the stream instead of being copied to LDS first
+template <typename OutT, int CMAX, bool HOT, bool STAGE = true, typename Reduce>
+__device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w,
                                   const OutT *bg, Reduce reduce) {
-    emit_chunk<OutT, CMAX>(u, [](const Rec &r) -> Rec { return r; }, key0, npix, C, dst, w, bg, reduce);
+    emit_chunk<OutT, CMAX, HOT, STAGE>(u, [](const Rec &r) -> Rec { return r; }, key0, npix, C, dst, w, bg, reduce);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -964,9 +1173,9 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 
 // grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
 // One unit of MixedDensityEventStack: the window's statistics -> per-channel set-up -> digest / reduce -> emit.
-template <typename OutT, typename D>
+template <typename OutT, typename D, bool HOT>
 __device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double scale, const UnitRecs &u, const ChunkGeom &g,
-                                      int64_t n_win, const WindowMeta &m, OutT *__restrict__ dst, WaveLds<OutT> &w) {
+                                      int64_t n_win, const WindowMeta &m, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w) {
     const int32_t tmin = m.tmin;
     // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
     const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
@@ -1096,34 +1305,36 @@ __device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double 
 #pragma unroll
         for (int c = 0; c < D::kMaxC; ++c) vals[c] = (OutT)rr[c];
     };
-    emit_chunk<OutT, D::kMaxC>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
+    emit_chunk<OutT, D::kMaxC, HOT>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
 
-template <typename OutT, typename D>
-__global__ __launch_bounds__(kWave) void k_mdes(BinView bv, const int64_t *__restrict__ off,
+template <typename OutT, typename D, bool HOT = false>
+__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const int64_t *__restrict__ off,
                                                MdesParams P, int H, int W, int nchunk, UnitCfg uc, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = D::C(P);
-    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
-    w.arm(uc.hold);
+    run_units<HOT>(bv, [&](int uid, int part) {
+        const int C = D::C(P);
+        WaveLds<OutT, HOT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+        w.arm(uc.hold);
 #ifdef EVREP_TIMING
-    w.dbg = bv.dbg + 8 * (size_t)chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+        w.dbg = bv.dbg + 8 * (size_t)uid;
 #endif
-    ChunkGeom g;
-    // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
-    // unit's records
-    int chunk0;
-    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
-    const int64_t n_win = off[b0 + 1] - off[b0];
-    const MetaRaw mraw = meta_prefetch(bv, b0);
-    w.mark(6);
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    w.mark(0);
-    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    const WindowMeta m = meta_finish(bv, off, g.b, mraw);
-
-    mdes_emit_unit<OutT, D>(P, C, W, scale, u, g, n_win, m, dst, w);
+        ChunkGeom g;
+        // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
+        // unit's records
+        int chunk0;
+        const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        const int64_t n_win = off[b0 + 1] - off[b0];
+        const MetaRaw mraw = meta_prefetch(bv, b0);
+        w.mark(6);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        w.mark(0);
+        OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+        const WindowMeta m = meta_finish(bv, off, g.b, mraw);
+        mdes_emit_unit<OutT, D, HOT>(P, C, W, scale, u, g, n_win, m, dst, w);
+    });
 }
 
 
@@ -1208,35 +1419,38 @@ __global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__restric
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
-template <int CM>  // compile-time channel capacity (8, 12 or 16)
-__global__ __launch_bounds__(kWave) void k_event_stack(BinView bv,
+template <int CM, bool HOT = false>  // compile-time channel capacity (8, 12 or 16)
+__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_event_stack(BinView bv,
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<float> w(smem, S, uc.span * kChunkPx, uc.stage, uc.partpx);
-    w.arm(uc.hold);
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
-    const int64_t n_win = off[g.b + 1] - off[g.b];
-    // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
-    int offk[CM];
-    {
-        int cur = (int)n_win, o = 0;
+    run_units<HOT>(bv, [&](int uid, int part) {
+        WaveLds<float, HOT> w(smem, S, uc.span * kChunkPx, uc.stage, uc.partpx);
+        w.arm(uc.hold);
+        ChunkGeom g;
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
+        const int64_t n_win = off[g.b + 1] - off[g.b];
+        // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
+        int offk[CM];
+        {
+            int cur = (int)n_win, o = 0;
 #pragma unroll
-        for (int k = 0; k < CM; ++k) { offk[k] = o; cur /= 2; o += cur; }
-    }
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
-        const Rec e = get(je - 1);  // ndarray.put is last-write-wins (event_stack.py:125)
-        int p = e.w;
-        if (premap == 1) p = (p + 1) >> 1;                   // (p + 1) // 2   (gen1_transforms.py:34)
-        // 2*p - 1 as int8 (event_stack.py:18); premap 2: the column already holds that int8 value (the host
-        // formed it, negated for the reversed "future" half, event_stack.py:35)
-        const float v = (float)(int8_t)(premap == 2 ? p : 2 * p - 1) * scale;
+            for (int k = 0; k < CM; ++k) { offk[k] = o; cur /= 2; o += cur; }
+        }
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
+            const Rec e = get(je - 1);  // ndarray.put is last-write-wins (event_stack.py:125)
+            int p = e.w;
+            if (premap == 1) p = (p + 1) >> 1;                   // (p + 1) // 2   (gen1_transforms.py:34)
+            // 2*p - 1 as int8 (event_stack.py:18); premap 2: the column already holds that int8 value (the host
+            // formed it, negated for the reversed "future" half, event_stack.py:35)
+            const float v = (float)(int8_t)(premap == 2 ? p : 2 * p - 1) * scale;
 #pragma unroll
-        for (int l = 0; l < CM; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
-    };
-    emit_chunk<float, CM>(u, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, reduce);
+            for (int l = 0; l < CM; ++l) vals[l] = (e.y >= offk[l]) ? v : 0.0f;
+        };
+        emit_chunk<float, CM, HOT, false>(u, g.row * W + g.c0, g.npix, S, dst, w, (const float *)nullptr, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1357,92 +1571,95 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 
 // CM = compile-time channel capacity, 2 * slices <= CM (12 or 16); FACT = the factorised exponentials are compiled in
 // (launches on sparse windows; dense windows run the leaner per-slice form)
-template <typename OutT, int CM, bool FACT>
-__global__ __launch_bounds__(kWave, 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
+template <typename OutT, int CM, bool FACT, bool HOT = false>
+__global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
                                                        int S, double tau, int premap, double scale, OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = 2 * S;
-    WaveLds<OutT> w(smem, C, uc.span * kChunkPx, uc.stage);
-    w.arm(uc.hold);
-    // the window's cuts, held in registers with compile-time indices only (no scratch); read BEFORE the unit's front end, so
-    // that their latency runs beside the run-table / record loads instead of behind them (r03)
-    int chunk0;
-    const TsCuts *cp = cuts + unit_geom(H, W, nchunk, uc.span, chunk0).b;
-    struct { int idx[(CM / 2)], tcut[(CM / 2)], live[(CM / 2)]; } cu;
+    run_units<HOT>(bv, [&](int uid, int part) {
+        const int C = 2 * S;
+        WaveLds<OutT, HOT> w(smem, C, uc.span * kChunkPx, uc.stage);
+        w.arm(uc.hold);
+        // the window's cuts, held in registers with compile-time indices only (no scratch); read BEFORE the unit's front end, so
+        // that their latency runs beside the run-table / record loads instead of behind them (r03)
+        int chunk0;
+        const TsCuts *cp = cuts + unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        struct { int idx[(CM / 2)], tcut[(CM / 2)], live[(CM / 2)]; } cu;
 #pragma unroll
-    for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
-    // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
-    const double inv_tau = 1.0 / tau;
-    // exp((m - t_s)/tau) = exp((m - tref)/tau) * fac[s]: ONE exponential per event, formed by the digest -- one record per
-    // lane, all lanes at once -- instead of two per slice and touched pixel inside the per-pixel code (12 per pixel for the
-    // reference's 6 slices).  The digest keeps {E lo, rank, E hi, p}.  This factorised form is used by the waves whose
-    // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
-    // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
-    const int tref = cp->tref;
-    const bool fact = FACT && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
-    double fac[(CM / 2)];
+        for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
+        ChunkGeom g;
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+        // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
+        // division per exponential; the surface moves by < 1e-15 relative (budget 1e-5)
+        const double inv_tau = 1.0 / tau;
+        // exp((m - t_s)/tau) = exp((m - tref)/tau) * fac[s]: ONE exponential per event, formed by the digest -- one record per
+        // lane, all lanes at once -- instead of two per slice and touched pixel inside the per-pixel code (12 per pixel for the
+        // reference's 6 slices).  The digest keeps {E lo, rank, E hi, p}.  This factorised form is used by the waves whose
+        // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
+        // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
+        const int tref = cp->tref;
+        const bool fact = FACT && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
+        double fac[(CM / 2)];
 #pragma unroll
-    for (int q = 0; q < (CM / 2); ++q) fac[q] = cp->fac[q];
-    // the background of every slice was computed once per window by k_ts_cuts
-    if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
-    wave_phase();
-    const OutT *bg = w.bg;
-    auto digest = [&](const Rec &r) -> Rec {
-        if (!fact) return r;
-        const double E = exp_neg_range(((double)r.z - (double)tref) * inv_tau);
-        return make_int4(__double2loint(E), r.y, __double2hiint(E), r.w);
-    };
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
-        // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it, per polarity -- the record
-        // index of the last event (factorised form) or its timestamp.  INT32_MIN = never written.  Slices cut strictly
-        // before an event see the memory as it stands before it.
-        int snap0[(CM / 2)], snap1[(CM / 2)];
+        for (int q = 0; q < (CM / 2); ++q) fac[q] = cp->fac[q];
+        // the background of every slice was computed once per window by k_ts_cuts
+        if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = (OutT)cp->bg[threadIdx.x];
+        wave_phase();
+        const OutT *bg = w.bg;
+        auto digest = [&](const Rec &r) -> Rec {
+            if (!fact) return r;
+            const double E = exp_neg_range(((double)r.z - (double)tref) * inv_tau);
+            return make_int4(__double2loint(E), r.y, __double2hiint(E), r.w);
+        };
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
+            // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it, per polarity -- the record
+            // index of the last event (factorised form) or its timestamp.  INT32_MIN = never written.  Slices cut strictly
+            // before an event see the memory as it stands before it.
+            int snap0[(CM / 2)], snap1[(CM / 2)];
 #pragma unroll
-        for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
-        int cur0 = INT32_MIN, cur1 = INT32_MIN;
-        uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
-        for (uint32_t j = jb; j <= je; ++j) {
-            int rank = INT32_MAX, t = 0, p = 0;
-            if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : e.z; p = e.w; }
+            for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
+            int cur0 = INT32_MIN, cur1 = INT32_MIN;
+            uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
+            for (uint32_t j = jb; j <= je; ++j) {
+                int rank = INT32_MAX, t = 0, p = 0;
+                if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : e.z; p = e.w; }
 #pragma unroll
-            for (int q = 0; q < (CM / 2); ++q) {
-                if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
-            }
-            if (j < je) {
-                if (premap) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
-                if (p & 1) cur1 = t; else cur0 = t;
-            }
-        }
-        // pass 2
-#pragma unroll
-        for (int q = 0; q < (CM / 2); ++q) {
-            OutT v0 = bg[2 * q], v1 = bg[2 * q + 1];
-            if (q < S && cu.live[q]) {
-                if (fact) {  // the snapshot records' exponentials times the slice factor
-                    if (snap0[q] != INT32_MIN) { const Rec e = get((uint32_t)snap0[q]); v0 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
-                    if (snap1[q] != INT32_MIN) { const Rec e = get((uint32_t)snap1[q]); v1 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
-                } else {     // one straight-line batch of exponentials, the same for every lane of the wave
-                    const double tc = (double)cu.tcut[q];
-                    if (__any(snap0[q] != INT32_MIN)) {
-                        const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
-                        if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
-                    }
-                    if (__any(snap1[q] != INT32_MIN)) {
-                        const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
-                        if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
-                    }
+                for (int q = 0; q < (CM / 2); ++q) {
+                    if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
+                }
+                if (j < je) {
+                    if (premap) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
+                    if (p & 1) cur1 = t; else cur0 = t;
                 }
             }
-            vals[2 * q] = v0;
-            vals[2 * q + 1] = v1;
-        }
-    };
-    emit_chunk<OutT, CM>(u, digest, [](const Rec &r) -> Rec { return r; }, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+            // pass 2
+#pragma unroll
+            for (int q = 0; q < (CM / 2); ++q) {
+                OutT v0 = bg[2 * q], v1 = bg[2 * q + 1];
+                if (q < S && cu.live[q]) {
+                    if (fact) {  // the snapshot records' exponentials times the slice factor
+                        if (snap0[q] != INT32_MIN) { const Rec e = get((uint32_t)snap0[q]); v0 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
+                        if (snap1[q] != INT32_MIN) { const Rec e = get((uint32_t)snap1[q]); v1 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
+                    } else {     // one straight-line batch of exponentials, the same for every lane of the wave
+                        const double tc = (double)cu.tcut[q];
+                        if (__any(snap0[q] != INT32_MIN)) {
+                            const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
+                            if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
+                        }
+                        if (__any(snap1[q] != INT32_MIN)) {
+                            const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
+                            if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
+                        }
+                    }
+                }
+                vals[2 * q] = v0;
+                vals[2 * q + 1] = v1;
+            }
+        };
+        emit_chunk<OutT, CM, HOT>(u, digest, [](const Rec &r) -> Rec { return r; }, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1452,107 +1669,111 @@ constexpr int kMaxToreK = 8;
 
 // grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
-template <int CM>  // compile-time channel capacity, 2 * K <= CM (12 or 16)
-__global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+template <int CM, bool HOT = false>  // compile-time channel capacity, 2 * K <= CM (12 or 16)
+__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
                                                int H, int W, int nchunk, UnitCfg uc, int K, int frame_mode, float scale,
                                                float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = 2 * K;
-    const int span = uc.span;
-    WaveLds<float> w(smem, C, (span + 1) * kChunkPx, uc.stage);
-    w.arm(uc.hold);
-    const int nunit = (nchunk + span - 1) / span;
-    const int u = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
-    const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
-    const int64_t beg = off[b];
-    const int64_t n_win = off[b + 1] - beg;
-    // an empty window has no bounding box: mode 0 has nothing to write (the dispatcher raises on it), the
-    // full-frame modes still owe the caller the empty-FIFO background in every element of the window's slice
-    const bool empty = n_win <= 0;
-    if (empty && frame_mode == 0) return;
-    const WindowMeta m = window_meta(bv, off, b);
-    int x0 = 0, y0 = 0, Hf = H, Wf = W;
-    if (!empty && (frame_mode == 0 || frame_mode == 1)) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
-    if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
-    if (orow >= Hf || oc0 >= Wf) return;
-    const int npix = min(span * kChunkPx, Wf - oc0);
-    const int row = orow + y0;  // sensor row feeding this output row
-    const int T = empty ? 0 : (sample_times ? sample_times[b] : ev[beg + n_win - 1].z);
-    // float64 timestamps (n_imagenet hands seconds as floats, imagenet.py:1002-1006,1093-1103): the time of a record
-    // is gathered by its rank from the caller's array, the sample time is a float64 too, and the FIFOs hold RANKS
-    const double *tw = tf ? tf + beg : nullptr;
-    const double Td = (tf && !empty) ? (sample_times_f ? sample_times_f[b] : tw[n_win - 1]) : 0.0;
-    // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
-    const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
-    UnitRecs ur;
-    ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
-    ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    ur.nseg = -1; ur.pos = (int)threadIdx.x;
-    if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
-        const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
-        if (bv.fused) {
-            ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
-                              row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx);
-        } else {
-            const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
-            ur.cs = co[ch_lo];
-            ur.ce = co[ch_hi + 1];
-            if ((int)threadIdx.x < (int)(ur.ce - ur.cs)) ur.r0 = ur.sorted[ur.cs + threadIdx.x];
-            stage_classic(ur, w);
-        }
-    }
-    // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
-    const double log_min = log(151.0);
-    const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
-    if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = bgv;
-    wave_phase();
-    float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
-    // The value of a FIFO slot depends on its event alone (one sample time per window): log(min(T - t, 5e8) + 1) - log(151),
-    // floored at 0 (tore.py:63-79).  So the digest forms it per EVENT -- one record per lane, all lanes at once, one logf --
-    // and the FIFOs hold finished values: 2 K logarithms per touched pixel become one per event.  Digest:
-    // {pixel id, value bits, 1 iff the event counts (ts < currentSampleTime, tore.py:17: events at T are dropped), p}.
-    auto digest = [&](const Rec &r) -> Rec {
-        bool counts;
-        float v;
-        if (tw) { const double te = tw[r.y]; counts = te < Td; v = (float)(Td - te); }
-        else { counts = r.z < T; v = (float)(double)((int64_t)T - (int64_t)r.z); }
-        v = fminf(v, 500e6f);
-        v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
-        return make_int4(r.x, __float_as_int(v), counts ? 1 : 0, r.w);
-    };
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
-        float fp[(CM / 2)], fn[(CM / 2)];  // most recent first; slots never filled keep the empty-FIFO value
-#pragma unroll
-        for (int q = 0; q < (CM / 2); ++q) { fp[q] = bgv; fn[q] = bgv; }
-        for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);
-            if (!e.z) continue;
-            const float v = __int_as_float(e.y);
-            if (e.w > 0) {
-#pragma unroll
-                for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
-                fp[0] = v;
+    run_units<HOT>(bv, [&](int uid, int part) {
+        const int C = 2 * K;
+        const int span = uc.span;
+        WaveLds<float, HOT> w(smem, C, (span + 1) * kChunkPx, uc.stage);
+        w.arm(uc.hold);
+        const int nunit = (nchunk + span - 1) / span;
+        const int u = uid;
+        const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
+        const int64_t beg = off[b];
+        const int64_t n_win = off[b + 1] - beg;
+        // an empty window has no bounding box: mode 0 has nothing to write (the dispatcher raises on it), the
+        // full-frame modes still owe the caller the empty-FIFO background in every element of the window's slice
+        const bool empty = n_win <= 0;
+        if (empty && frame_mode == 0) return;
+        const WindowMeta m = window_meta(bv, off, b);
+        int x0 = 0, y0 = 0, Hf = H, Wf = W;
+        if (!empty && (frame_mode == 0 || frame_mode == 1)) { x0 = m.xmin; y0 = m.ymin; }  // x - min(x) + 1, then [.., j - 1]
+        if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
+        if (orow >= Hf || oc0 >= Wf) return;
+        const int npix = min(span * kChunkPx, Wf - oc0);
+        const int row = orow + y0;  // sensor row feeding this output row
+        const int T = empty ? 0 : (sample_times ? sample_times[b] : ev[beg + n_win - 1].z);
+        // float64 timestamps (n_imagenet hands seconds as floats, imagenet.py:1002-1006,1093-1103): the time of a record
+        // is gathered by its rank from the caller's array, the sample time is a float64 too, and the FIFOs hold RANKS
+        const double *tw = tf ? tf + beg : nullptr;
+        const double Td = (tf && !empty) ? (sample_times_f ? sample_times_f[b] : tw[n_win - 1]) : 0.0;
+        // sensor columns [oc0 + x0, oc0 + x0 + npix) can straddle span + 1 sensor chunks
+        const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;
+        UnitRecs ur;
+        ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
+        ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
+        ur.nseg = -1; ur.pos = (int)threadIdx.x; ur.deferred = false; ur.part = -1;
+        if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
+            const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
+            if (bv.fused) {
+                ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
+                                  row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part);
             } else {
-#pragma unroll
-                for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
-                fn[0] = v;
+                const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
+                ur.cs = co[ch_lo];
+                ur.ce = co[ch_hi + 1];
+                const int nr = (int)(ur.ce - ur.cs);
+                if ((int)threadIdx.x < nr) ur.r0 = ur.sorted[ur.cs + threadIdx.x];
+                stage_classic(ur, w);
             }
         }
+        if (ur.deferred) return;
+        // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
+        const double log_min = log(151.0);
+        const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
+        if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = bgv;
+        wave_phase();
+        float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
+        // The value of a FIFO slot depends on its event alone (one sample time per window): log(min(T - t, 5e8) + 1) - log(151),
+        // floored at 0 (tore.py:63-79).  So the digest forms it per EVENT -- one record per lane, all lanes at once, one logf --
+        // and the FIFOs hold finished values: 2 K logarithms per touched pixel become one per event.  Digest:
+        // {pixel id, value bits, 1 iff the event counts (ts < currentSampleTime, tore.py:17: events at T are dropped), p}.
+        auto digest = [&](const Rec &r) -> Rec {
+            bool counts;
+            float v;
+            if (tw) { const double te = tw[r.y]; counts = te < Td; v = (float)(Td - te); }
+            else { counts = r.z < T; v = (float)(double)((int64_t)T - (int64_t)r.z); }
+            v = fminf(v, 500e6f);
+            v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+            return make_int4(r.x, __float_as_int(v), counts ? 1 : 0, r.w);
+        };
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
+            float fp[(CM / 2)], fn[(CM / 2)];  // most recent first; slots never filled keep the empty-FIFO value
 #pragma unroll
-        for (int c = 0; c < CM; ++c) vals[c] = bgv;
-        // channel layout: positives [0, K), negatives [K, 2K)
+            for (int q = 0; q < (CM / 2); ++q) { fp[q] = bgv; fn[q] = bgv; }
+            for (uint32_t j = jb; j < je; ++j) {
+                const Rec e = get(j);
+                if (!e.z) continue;
+                const float v = __int_as_float(e.y);
+                if (e.w > 0) {
 #pragma unroll
-        for (int q = 0; q < (CM / 2); ++q) {
+                    for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
+                    fp[0] = v;
+                } else {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                if (q < K && c == q) vals[c] = fp[q];
-                if (q < K && c == K + q) vals[c] = fn[q];
+                    for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
+                    fn[0] = v;
+                }
             }
-        }
-    };
-    emit_chunk<float, CM>(ur, digest, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) vals[c] = bgv;
+            // channel layout: positives [0, K), negatives [K, 2K)
+#pragma unroll
+            for (int q = 0; q < (CM / 2); ++q) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    if (q < K && c == q) vals[c] = fp[q];
+                    if (q < K && c == K + q) vals[c] = fn[q];
+                }
+            }
+        };
+        emit_chunk<float, CM, HOT>(ur, digest, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1563,82 +1784,85 @@ __global__ __launch_bounds__(kWave) void k_tore(const int4 *__restrict__ ev, Bin
 //         and the upper bin an exact zero -- a signed event count per (time bin, y, x).
 // --------------------------------------------------------------------------------------------
 // CM = compile-time channel capacity (8 or 16): the register arrays of a <= 8-bin grid are half the size
-template <int CM>
-__global__ __launch_bounds__(kWave) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+template <int CM, bool HOT = false>
+__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
                                                 const int64_t *__restrict__ t_range, double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    WaveLds<double> w(smem, bins, uc.span * kChunkPx, uc.stage);
-    w.arm(uc.hold);
-    // the window's first / last timestamp: two dependent load levels (extent, then events) issued BEFORE the unit's own two
-    // levels (run tables, then records), not behind them (r03: they were a third and fourth step of the wave's latency chain)
-    int chunk0;
-    const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0).b;
-    const int64_t beg = off[b0];
-    const int64_t n_win = off[b0 + 1] - beg;
-    int tz0 = 0, tz1 = 0;
-    if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
-    double t0 = 0.0, den = 1.0;
-    if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
-    // explicit [t0_us, t1_us] of ev-licious' events_to_voxel_grid (utils.py:60-63), mode 2 only
-    if (t_range) { t0 = (double)t_range[2 * g.b]; den = (double)(t_range[2 * g.b + 1] - t_range[2 * g.b]); }
-    // the fractional bin position of an event: one float64 division
-    auto bin_pos = [&](int t) -> double {
-        if (mode == 2) {
-            // t_norm = (num_bins - 1) * (t - t0) / deltaT: int64 product, one float64 division
-            const int64_t num = (int64_t)(bins - 1) * ((int64_t)t - (int64_t)t0);
-            return (double)num / (den == 0.0 ? 1.0 : den);
-        }
-        if (mode == 0) {
-            const double tn = ((double)t - t0) / den;
-            return (double)(bins - 1) * tn;
-        }
-        const double num = (double)bins * ((double)t - t0);
-        return num / den;
-    };
-    // emit_chunk digests the staged records -- one record per lane, all lanes at once: the bin position rides in the
-    // (rank, t) fields, which the segment walks below do not need.  Both np.add.at passes of every segment then run
-    // without a division (they were the bulk of this kernel's VALU work: the walks are divergent, one division per step
-    // and lane).
-    auto digest = [&](const Rec &r) -> Rec {
-        const double bp = bin_pos(r.z);
-        return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
-    };
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[CM]) {
+    run_units<HOT>(bv, [&](int uid, int part) {
+        WaveLds<double, HOT> w(smem, bins, uc.span * kChunkPx, uc.stage);
+        w.arm(uc.hold);
+        // the window's first / last timestamp: two dependent load levels (extent, then events) issued BEFORE the unit's own two
+        // levels (run tables, then records), not behind them (r03: they were a third and fourth step of the wave's latency chain)
+        int chunk0;
+        const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        const int64_t beg = off[b0];
+        const int64_t n_win = off[b0 + 1] - beg;
+        int tz0 = 0, tz1 = 0;
+        if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
+        ChunkGeom g;
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
+        double t0 = 0.0, den = 1.0;
+        if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
+        // explicit [t0_us, t1_us] of ev-licious' events_to_voxel_grid (utils.py:60-63), mode 2 only
+        if (t_range) { t0 = (double)t_range[2 * g.b]; den = (double)(t_range[2 * g.b + 1] - t_range[2 * g.b]); }
+        // the fractional bin position of an event: one float64 division
+        auto bin_pos = [&](int t) -> double {
+            if (mode == 2) {
+                // t_norm = (num_bins - 1) * (t - t0) / deltaT: int64 product, one float64 division
+                const int64_t num = (int64_t)(bins - 1) * ((int64_t)t - (int64_t)t0);
+                return (double)num / (den == 0.0 ? 1.0 : den);
+            }
+            if (mode == 0) {
+                const double tn = ((double)t - t0) / den;
+                return (double)(bins - 1) * tn;
+            }
+            const double num = (double)bins * ((double)t - t0);
+            return num / den;
+        };
+        // emit_chunk digests the staged records -- one record per lane, all lanes at once: the bin position rides in the
+        // (rank, t) fields, which the segment walks below do not need.  Both np.add.at passes of every segment then run
+        // without a division (they were the bulk of this kernel's VALU work: the walks are divergent, one division per step
+        // and lane).
+        auto digest = [&](const Rec &r) -> Rec {
+            const double bp = bin_pos(r.z);
+            return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
+        };
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[CM]) {
 #pragma unroll
-        for (int c = 0; c < CM; ++c) vals[c] = 0.0;
-        // two np.add.at passes: lower bin for every event, then upper bin for every event
-        for (int pass = 0; pass < (mode == 2 ? 1 : 2); ++pass) {
-            for (uint32_t j = jb; j < je; ++j) {
-                const Rec e = get(j);
-                double p = (double)e.w;
-                if (mode == 1 && e.w == 0) p = -1.0;
-                const double bpos = __hiloint2double(e.z, e.y);
-                // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
-                // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
-                if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
-                const int bi = (int)bpos;
-                const int blim = bi + pass;
-                if (blim < bins) {
-                    double wgt;
-                    if (mode == 2) wgt = 1.0;
-                    else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
-                    else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
-                    const double wp = wgt * p;
+            for (int c = 0; c < CM; ++c) vals[c] = 0.0;
+            // two np.add.at passes: lower bin for every event, then upper bin for every event
+            for (int pass = 0; pass < (mode == 2 ? 1 : 2); ++pass) {
+                for (uint32_t j = jb; j < je; ++j) {
+                    const Rec e = get(j);
+                    double p = (double)e.w;
+                    if (mode == 1 && e.w == 0) p = -1.0;
+                    const double bpos = __hiloint2double(e.z, e.y);
+                    // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
+                    // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
+                    if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
+                    const int bi = (int)bpos;
+                    const int blim = bi + pass;
+                    if (blim < bins) {
+                        double wgt;
+                        if (mode == 2) wgt = 1.0;
+                        else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
+                        else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
+                        const double wp = wgt * p;
 #pragma unroll
-                    for (int c = 0; c < CM; ++c) if (c == blim) vals[c] = vals[c] + wp;
+                        for (int c = 0; c < CM; ++c) if (c == blim) vals[c] = vals[c] + wp;
+                    }
                 }
             }
-        }
-        if (scale != 1.0) {
+            if (scale != 1.0) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) vals[c] = vals[c] * scale;
-        }
-    };
-    emit_chunk<double, CM>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
+                for (int c = 0; c < CM; ++c) vals[c] = vals[c] * scale;
+            }
+        };
+        emit_chunk<double, CM, HOT>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1653,78 +1877,81 @@ struct PolStatParams {
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
 // (6 waves per SIMD asked for: 110 -> 80 VGPRs with 52 bytes of scratch, 81 -> 64 us at 32 x 50 000 events, 640x480x6;
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
-template <int CM>
-__global__ __launch_bounds__(kWave, 6) void k_polstats(BinView bv,
+template <int CM, bool HOT = false>
+__global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, UnitCfg uc,
                                                    float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = P.C;
-    WaveLds<float> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
-    w.arm(uc.hold);
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-    const int lane = threadIdx.x;
-    const double *tw = tnorm + off[g.b];
-    // empty pixels: 0, except EXP channels = exp(-(1 - 0)/tau)  (imagenet.py:463,466)
-    bool any_bg = false;
+    run_units<HOT>(bv, [&](int uid, int part) {
+        const int C = P.C;
+        WaveLds<float, HOT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+        w.arm(uc.hold);
+        ChunkGeom g;
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+        const int lane = threadIdx.x;
+        const double *tw = tnorm + off[g.b];
+        // empty pixels: 0, except EXP channels = exp(-(1 - 0)/tau)  (imagenet.py:463,466)
+        bool any_bg = false;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
-    if (any_bg) {
-        if (lane < CM) {
-            float v = 0.0f;
-            if (lane < C && P.stat[lane] == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - 0.0) / P.tau);
-            w.bg[lane] = v;
-        }
-        wave_phase();
-    }
-    const float *bg = any_bg ? w.bg : nullptr;
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
-        int n_any = 0, n_pos = 0, n_neg = 0;
-        double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
-        for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);   // digest: {t_n lo, t_n hi, rank, p}
-            const double tn = __hiloint2double(e.y, e.x);
-            if (n_any == 0 || tn > mx_any) mx_any = tn;
-            if (n_any == 0 || tn < mn_any) mn_any = tn;
-            ++n_any;
-            if (e.w > 0) {
-                if (n_pos == 0 || tn > mx_pos) mx_pos = tn;
-                if (n_pos == 0 || tn < mn_pos) mn_pos = tn;
-                ++n_pos;
-            } else if (e.w < 0) {
-                if (n_neg == 0 || tn > mx_neg) mx_neg = tn;
-                if (n_neg == 0 || tn < mn_neg) mn_neg = tn;
-                ++n_neg;
+        for (int c = 0; c < CM; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
+        if (any_bg) {
+            if (lane < CM) {
+                float v = 0.0f;
+                if (lane < C && P.stat[lane] == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - 0.0) / P.tau);
+                w.bg[lane] = v;
             }
+            wave_phase();
         }
+        const float *bg = any_bg ? w.bg : nullptr;
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
+            int n_any = 0, n_pos = 0, n_neg = 0;
+            double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
+            for (uint32_t j = jb; j < je; ++j) {
+                const Rec e = get(j);   // digest: {t_n lo, t_n hi, rank, p}
+                const double tn = __hiloint2double(e.y, e.x);
+                if (n_any == 0 || tn > mx_any) mx_any = tn;
+                if (n_any == 0 || tn < mn_any) mn_any = tn;
+                ++n_any;
+                if (e.w > 0) {
+                    if (n_pos == 0 || tn > mx_pos) mx_pos = tn;
+                    if (n_pos == 0 || tn < mn_pos) mn_pos = tn;
+                    ++n_pos;
+                } else if (e.w < 0) {
+                    if (n_neg == 0 || tn > mx_neg) mx_neg = tn;
+                    if (n_neg == 0 || tn < mn_neg) mn_neg = tn;
+                    ++n_neg;
+                }
+            }
 #pragma unroll
-        for (int c = 0; c < CM; ++c) {
-            float v = 0.0f;
-            if (c < C) {
-                const int k = P.pol[c], st = P.stat[c];
-                const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
-                const double mx = k == EVREP_PS_POS ? mx_pos : (k == EVREP_PS_NEG ? mx_neg : mx_any);
-                const double mn = k == EVREP_PS_POS ? mn_pos : (k == EVREP_PS_NEG ? mn_neg : mn_any);
-                if (st == EVREP_PS_COUNT) v = (float)n;
-                else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
-                else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
-                else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
-                else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
-                else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+            for (int c = 0; c < CM; ++c) {
+                float v = 0.0f;
+                if (c < C) {
+                    const int k = P.pol[c], st = P.stat[c];
+                    const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
+                    const double mx = k == EVREP_PS_POS ? mx_pos : (k == EVREP_PS_NEG ? mx_neg : mx_any);
+                    const double mn = k == EVREP_PS_POS ? mn_pos : (k == EVREP_PS_NEG ? mn_neg : mn_any);
+                    if (st == EVREP_PS_COUNT) v = (float)n;
+                    else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
+                    else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
+                    else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
+                    else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
+                    else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+                }
+                vals[c] = v;
             }
-            vals[c] = v;
-        }
-    };
-    // the record's normalised time is gathered from the caller's array by the DIGEST -- one load per record, all lanes at once,
-    // staged in place of the fields the walks do not need -- instead of one dependent global load per step of the divergent
-    // segment walks (r03)
-    auto digest = [&](const Rec &r) -> Rec {
-        const double tn = tw[r.y];
-        return make_int4(__double2loint(tn), __double2hiint(tn), r.y, r.w);
-    };
-    emit_chunk<float, CM>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+        };
+        // the record's normalised time is gathered from the caller's array by the DIGEST -- one load per record, all lanes at once,
+        // staged in place of the fields the walks do not need -- instead of one dependent global load per step of the divergent
+        // segment walks (r03)
+        auto digest = [&](const Rec &r) -> Rec {
+            const double tn = tw[r.y];
+            return make_int4(__double2loint(tn), __double2hiint(tn), r.y, r.w);
+        };
+        emit_chunk<float, CM, HOT>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1751,48 +1978,52 @@ __device__ inline float est_value(float u, const double *__restrict__ seg, const
 }
 
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's float32 t / t.max().
-__global__ __launch_bounds__(kWave) void k_est(BinView bv,
+template <bool HOT = false>
+__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_est(BinView bv,
                                               const int64_t *__restrict__ off, const float *__restrict__ tnorm,
                                               const double *__restrict__ seg, const uint32_t *__restrict__ bucket,
                                               EstParams P, int H, int W, int nchunk, UnitCfg uc, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C2 = 2 * P.C;
-    WaveLds<float> w(smem, C2, uc.span * kChunkPx, uc.stage);
-    w.arm(uc.hold);
-    ChunkGeom g;
-    const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g);
-    float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
-    const float *tw = tnorm + off[g.b];
-    auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
-        float lo_half[kEstMaxBins], hi_half[kEstMaxBins];
+    run_units<HOT>(bv, [&](int uid, int part) {
+        const int C2 = 2 * P.C;
+        WaveLds<float, HOT> w(smem, C2, uc.span * kChunkPx, uc.stage);
+        w.arm(uc.hold);
+        ChunkGeom g;
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        if (u.deferred) return;
+        float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
+        const float *tw = tnorm + off[g.b];
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[EVREP_MAX_CHANNELS]) {
+            float lo_half[kEstMaxBins], hi_half[kEstMaxBins];
 #pragma unroll
-        for (int i = 0; i < kEstMaxBins; ++i) { lo_half[i] = 0.0f; hi_half[i] = 0.0f; }
-        for (uint32_t j = jb; j < je; ++j) {
-            const Rec e = get(j);   // digest: {t_n bits, rank, t, p}
-            const float tn = __int_as_float(e.x);
+            for (int i = 0; i < kEstMaxBins; ++i) { lo_half[i] = 0.0f; hi_half[i] = 0.0f; }
+            for (uint32_t j = jb; j < je; ++j) {
+                const Rec e = get(j);   // digest: {t_n bits, rank, t, p}
+                const float tn = __int_as_float(e.x);
 #pragma unroll
-            for (int i = 0; i < kEstMaxBins; ++i) {
-                if (i < P.C) {
-                    const float u = tn - P.shift[i];
-                    const float v = tn * est_value(u, seg, bucket, P);   // values = t * value_layer(t - i/(C-1))  (:167)
-                    if (e.w > 0) hi_half[i] = hi_half[i] + v; else lo_half[i] = lo_half[i] + v;
+                for (int i = 0; i < kEstMaxBins; ++i) {
+                    if (i < P.C) {
+                        const float u = tn - P.shift[i];
+                        const float v = tn * est_value(u, seg, bucket, P);   // values = t * value_layer(t - i/(C-1))  (:167)
+                        if (e.w > 0) hi_half[i] = hi_half[i] + v; else lo_half[i] = lo_half[i] + v;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
-            float v = 0.0f;
+            for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) {
+                float v = 0.0f;
 #pragma unroll
-            for (int i = 0; i < kEstMaxBins; ++i) {
-                if (c == i && i < P.C) v = lo_half[i];
-                if (c == P.C + i && i < P.C) v = hi_half[i];
+                for (int i = 0; i < kEstMaxBins; ++i) {
+                    if (c == i && i < P.C) v = lo_half[i];
+                    if (c == P.C + i && i < P.C) v = hi_half[i];
+                }
+                vals[c] = v;
             }
-            vals[c] = v;
-        }
-    };
-    // the normalised time is gathered by the digest, one load per record with all lanes busy, not inside the walks (see k_polstats)
-    auto digest = [&](const Rec &r) -> Rec { return make_int4(__float_as_int(tw[r.y]), r.y, r.z, r.w); };
-    emit_chunk<float, EVREP_MAX_CHANNELS>(u, digest, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, reduce);
+        };
+        // the normalised time is gathered by the digest, one load per record with all lanes busy, not inside the walks (see k_polstats)
+        auto digest = [&](const Rec &r) -> Rec { return make_int4(__float_as_int(tw[r.y]), r.y, r.z, r.w); };
+        emit_chunk<float, EVREP_MAX_CHANNELS, HOT>(u, digest, g.row * W + g.c0, g.npix, C2, dst, w, (const float *)nullptr, reduce);
+    });
 }
 
 // --------------------------------------------------------------------------------------------

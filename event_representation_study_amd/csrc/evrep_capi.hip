@@ -239,7 +239,8 @@ int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_
     plan->off_sorted1 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
     plan->off_sorted2 = o; o += up256((size_t)(total_events + 1) * sizeof(Rec));
     plan->off_cuts = o;    o += up256((size_t)B * sizeof(TsCuts));
-    plan->off_scratch = o; o += 256;
+    // the hot list (evrep_builders.hip, run_units): count, exit ticket, then one id per unit of more than 64 records
+    plan->off_scratch = o; o += up256(4 * ((size_t)kHotHdrWords + 2 * (size_t)kHotLists * hot_sublist_cap((uint32_t)(kHotParts * ((size_t)total_events / 65 + 1)))));
     plan->workspace_bytes = o;
     return EVREP_OK;
 }
@@ -282,6 +283,12 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
     Rec *s2 = WS(Rec, off_sorted2);
     BlockStats *stats = WS(BlockStats, off_stats);
     const unsigned xgrid = 8u * (unsigned)((B + 7) / 8) * (unsigned)nblk;  // XCD-aware 1-D grid, see decode_window_block
+    uint32_t *hot = WS(uint32_t, off_scratch);   // the builders' hot lists start empty (k_block_keysort clears them itself)
+    const_cast<evrep_plan *>(plan)->flags &= ~((int32_t)1 << 30);
+    if (plan->reserved != 2 && plan->reserved != 3) {
+        int rc2 = hip_check(hipMemsetAsync(hot, 0, (size_t)kHotHdrWords * 4, stream), "hipMemsetAsync(hot list)");
+        if (rc2) return rc2;
+    }
     if (plan->reserved == 2 || plan->reserved == 3) {
         if ((chunk != kBsChunk && chunk != 4096) || nblk > (plan->reserved == 2 ? kBsMaxBlocks : kCsMaxRuns)) return EVREP_EINVAL;
         const int NK = H * plan->nchunk;
@@ -301,7 +308,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
             // per-lane chains of the kernel (returning LDS atomics, group walks, scan) are half as long: 19.4 -> 18.6 us
             if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<1024, 4>), block_keysort_lds_bytes(NK, cap, 4096))) return rc2;
             k_block_keysort<1024, 4><<<xgrid, 1024, block_keysort_lds_bytes(NK, cap, 4096), stream>>>(
-                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off), hot);
         } else {
             // two workgroups per CU (<= 79 KB each) beat one with a one-round stage: the kernel is a chain of barrier-separated
             // latencies, a second resident workgroup fills them
@@ -309,7 +316,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
                             : (block_keysort_lds_bytes(NK, kBsChunk, kBsChunk) + 1024 <= 160 * 1024 ? kBsChunk : 4096);
             if (int rc2 = opt_in(reinterpret_cast<const void *>(&k_block_keysort<1024>), block_keysort_lds_bytes(NK, cap, kBsChunk))) return rc2;
             k_block_keysort<1024><<<xgrid, kBsThreads, block_keysort_lds_bytes(NK, cap, kBsChunk), stream>>>(
-                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off));
+                ev, offsets, B, H, W, plan->nchunk, nblk, cap, table, stats, s1, reinterpret_cast<int64_t *>(row_off), hot);
         }
         LAUNCH_CHECK("k_block_keysort");
         if (plan->reserved == 3) return column_sort_keys(plan, events, offsets, workspace, stream);
@@ -365,6 +372,9 @@ static BinView bin_view(const evrep_plan *plan, const int32_t *events, void *wor
     bv.meta = CWS(WindowMeta, off_meta);
     bv.spill = WS(Rec, off_sorted2);
     bv.nblk = plan->nblk;
+    bv.hot = WS(uint32_t, off_scratch);
+    bv.hot_cap = (uint32_t)(kHotParts * (plan->total_events / 65 + 1));
+    bv.hot_sel = (plan->flags >> 30) & 1;
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
 #ifdef EVREP_TIMING
     bv.dbg = bv.fused ? WS(unsigned long long, off_sorted2) : WS(unsigned long long, off_sorted1);   // 8 slots per builder wave in the stream that is idle
@@ -390,12 +400,17 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
     // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
     // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
-    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0) ? 128 : 64);
+    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     return uc;
 }
 #define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
+// The builder calls on a plan alternate between the two hot lists (run_units): bit 30 of plan->flags is the library's own.
+// (A plan drives ONE workspace between two binning passes; evrep_bin_events clears both lists and the bit.)
+static void hot_flip(const evrep_plan *plan) { const_cast<evrep_plan *>(plan)->flags ^= (int32_t)1 << 30; }
+// the hot launch behind every builder launch (run_units): the same unit numbering (span), a stage of kHotStage records, no pacing
+static UnitCfg hot_cfg(UnitCfg uc) { uc.stage = kHotStage; uc.hold = 0; return uc; }
 
 // Automatic store pacing (plan->pacing == -1) of a builder instance whose launch is bound by its HBM writes on sparse
 // windows.  The waves resident on a CU offer U x unit_bytes every wave lifetime; on most placements of a ~1 GB output tensor
@@ -461,6 +476,8 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T)); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
+        k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+            bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
     do {                                                    \
@@ -476,6 +493,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
     }
 #undef MDES_RUNTIME
 #undef MDES_LAUNCH
+    hot_flip(plan);
     LAUNCH_CHECK("k_mdes");
     return EVREP_OK;
 }
@@ -496,10 +514,15 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
 #define ES_LAUNCH(CM)                                                                                              \
+    do {                                                                                                           \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
-        bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out)
+        bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out);          \
+    k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+        bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, hot_cfg(uc), stack_size, premap, scale, out); \
+    } while (0)
     if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
 #undef ES_LAUNCH
+    hot_flip(plan);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
 }
@@ -525,7 +548,14 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     k_time_surface<T, CM, F><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(            \
         bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
         static_cast<T *>(out))
-#define TS_LAUNCH(T, CM, GRID, SEG) do { if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG); } while (0)
+    // the hot launch always takes its exponentials per slice: a unit beyond the stage does so under every binning pass
+#define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
+    do {                                                                                                             \
+        if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG);                  \
+        k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
+            bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, hot_cfg(uc), slices, tau, premap,  \
+            scale, static_cast<T *>(out));                                                                           \
+    } while (0)
         if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
     } else {
         const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4, 0, false, false);
@@ -534,6 +564,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
     }
 #undef TS_LAUNCH
 #undef TS_LAUNCH_F
+    hot_flip(plan);
     LAUNCH_CHECK("k_time_surface");
     return EVREP_OK;
 }
@@ -554,11 +585,17 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
     const int span = uc.span;
 #define TORE_LAUNCH(CM)                                                                                             \
+    do {                                                                                                            \
     k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
-        plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out)
+        plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
+    k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, kHotStage), stream>>>(     \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
+        plan->H, plan->W, plan->nchunk, hot_cfg(uc), k, frame_mode, scale, out);                                    \
+    } while (0)
     if (k <= 6) TORE_LAUNCH(12); else TORE_LAUNCH(16);
 #undef TORE_LAUNCH
+    hot_flip(plan);
     LAUNCH_CHECK("k_tore");
     return EVREP_OK;
 }
@@ -578,11 +615,17 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     const UnitCfg uc = unit_cfg(plan, (size_t)bins * 8);
     const int span = uc.span;
 #define VOXEL_LAUNCH(CM)                                                                                         \
+    do {                                                                                                         \
     k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
-        bins, mode, scale, t_range, out)
+        bins, mode, scale, t_range, out);                                                                        \
+    k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, kHotStage), stream>>>(         \
+        reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
+        hot_cfg(uc), bins, mode, scale, t_range, out);                                                           \
+    } while (0)
     if (bins <= 8) VOXEL_LAUNCH(8); else VOXEL_LAUNCH(16);
 #undef VOXEL_LAUNCH
+    hot_flip(plan);
     LAUNCH_CHECK("k_voxel");
     return EVREP_OK;
 }
@@ -623,12 +666,16 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)C * 4, 0, true);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
-    if (C <= 8)
-        k_polstats<8><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(
-            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
-    else
-        k_polstats<16><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(
-            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);
+#define PS_LAUNCH(CM)                                                                                                 \
+    do {                                                                                                              \
+        k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
+            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
+        k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, span * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
+            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), out);   \
+    } while (0)
+    if (C <= 8) PS_LAUNCH(8); else PS_LAUNCH(16);
+#undef PS_LAUNCH
+    hot_flip(plan);
     LAUNCH_CHECK("k_polstats");
     return EVREP_OK;
 }
@@ -648,9 +695,13 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * C * 4);
     const int span = uc.span;
-    k_est<<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, uc.stage), stream>>>(
+    k_est<false><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, uc.stage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, uc, out);
+    k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, kHotStage), stream>>>(
+        bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
+        plan->nchunk, hot_cfg(uc), out);
+    hot_flip(plan);
     LAUNCH_CHECK("k_est");
     return EVREP_OK;
 }

@@ -66,7 +66,8 @@ typedef struct evrep_plan {
                                       2 = key-sorted (k_block_keysort alone; the builder waves finish the order by pixel),
                                       3 = k_block_keysort + the column sort per (row, chunk) key (dense windows),
                                       1 = k_block_rowsort + the column sort per row, 0 = the three-kernel pass */
-    int32_t flags;                 /* EVREP_PLAN_* bits the plan was made with */
+    int32_t flags;                 /* EVREP_PLAN_* bits the plan was made with; bit 30 is the library's own (it alternates with
+                                    * every builder call on the plan: which of the workspace's two hot-unit lists is in use) */
     int32_t pacing;                /* store pacing of the wide float64 builders (evrep_plan_set_pacing): -1 = automatic,
                                       0 = off, > 0 = every builder wave starts its stores no earlier than this many
                                       10 ns ticks after it started */
