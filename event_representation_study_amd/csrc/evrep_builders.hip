@@ -260,6 +260,7 @@ struct UnitRecs {
     bool deferred;
     int part;   // hot launch: the 64-pixel part of the unit this wave emits (run_units)
     uint32_t pst, pen;   // hot launch, per lane: the segment of pixel part * 64 + lane in the unit's spill slot
+    int dpx, npixu;      // main launch, a unit in the spill slot: output pixel o = unit pixel o + dpx; w.segs holds every pixel's END
 };
 
 // inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts), no LDS crossbar
@@ -546,18 +547,22 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     // spill stream by a counting sort over the unit's pixels, then staged from there part by part (emit_rounds).  The records
     // are fetched in register batches of kSpillBatch x 64 (8-byte records, every load of a batch in flight together -- r03
     // took one dependent L2 round trip per 64 records, twice); a unit of up to 1024 records is fetched once.
-    if constexpr (!HOT) {   // a main launch hands the unit's parts to its hot launch
-        defer_unit(bv, uid, (npix_out + kWave - 1) / kWave);
-        u.deferred = true;
-        u.ce = nrec;
-        return u;
-    } else {
-    // the part this wave emits, in pixels of the unit: output pixel o = unit pixel o + (segbase - keybase)
-    const int plo = part * kWave + (segbase - keybase), phi = min(part * kWave + kWave, npix_out) + (segbase - keybase);
-    u.part = part;
-    constexpr int kSpillBatch = 16;
+    // A MAIN launch (r04b) sorts the whole unit and emits it part by part from the slot (emit_parts_main) -- such a wave is
+    // bound by latency and arithmetic and runs beside the frame's store-bound waves for free, which a separate launch cannot
+    // -- unless one of its 64-pixel parts holds more records than the hot stage (tile + record stage): then the unit's parts
+    // go to the builder's HOT launch, whose waves each sort ONE part out of the unit's records and have the registers for the
+    // prefetch ring (emit_part).  Four-record batches in a main launch: its register budget is the sparse paths'.
+    // the pixels this wave sorts, in pixels of the unit: output pixel o = unit pixel o + (segbase - keybase)
+    const int dpx = segbase - keybase;
+    const int plo = HOT ? part * kWave + dpx : 0, phi = HOT ? min(part * kWave + kWave, npix_out) + dpx : npixu;
+    u.part = HOT ? part : -2;   // -2: a main launch's unit in its spill slot, -3: in the hot stage (emit_chunk)
+    constexpr int kSpillBatch = HOT ? 16 : 4;
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
+    wave_phase();
+    // (the run table moves behind the pixel counters: a main launch places a warm unit over the record stage it lay in)
+    uint32_t *runs2 = cnt + npixu;
+    if (nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
     wave_phase();
     auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
         if (nb <= kBsChainBlocks) {
@@ -575,10 +580,10 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
             const uint32_t mid = (lo + hi) >> 1;
-            const bool go = hi - lo > 1 && runs[mid] <= j;
+            const bool go = hi - lo > 1 && runs2[mid] <= j;
             if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
         }
-        return runs[64 + lo] + j;
+        return runs2[64 + lo] + j;
     };
     Rec8 q[kSpillBatch];
     auto load_batch = [&](uint32_t s0) {
@@ -617,10 +622,26 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
     }
     wave_phase();
+    // a main launch keeps a unit that fits the hot stage (tile + record stage) in LDS altogether: no slot, no second trip
+    const bool in_lds = !HOT && nrec <= (uint32_t)w.bigcap;   // wave-uniform
+    if (!HOT && !in_lds) {
+        bool fits = true;   // wave-uniform: every 64-pixel part of the output fits the hot stage
+        for (int o0 = 0; o0 < npix_out; o0 += kWave) {
+            const int lo = o0 + dpx, hi = min(o0 + kWave, npix_out) + dpx;
+            const uint32_t b0 = lo < npixu ? cnt[lo] : nrec, b1 = hi < npixu ? cnt[hi] : nrec;
+            fits = fits && b1 - b0 <= (uint32_t)w.bigcap;
+        }
+        if (!fits) {
+            defer_unit(bv, uid, (npix_out + kWave - 1) / kWave);
+            u.deferred = true;
+            u.ce = nrec;
+            return u;
+        }
+    }
     // lane l owns pixel plo + l of the part: its segment [pst, pen) of the unit's pixel-sorted order, read before the
     // placement moves the cursors
     uint32_t pst = 0, pen = 0;
-    {
+    if constexpr (HOT) {
         const int px = plo + lane;
         if (px >= 0 && px < phi && px < npixu) { pst = cnt[px]; pen = px + 1 < npixu ? cnt[px + 1] : nrec; }
     }
@@ -640,7 +661,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             uint32_t pos = 0;
             if (valid) {
                 pos = vcnt[px] + rk;
-                bv.spill[cs + pos] = rec8_unpack(q[k], row_base, c0, evw);
+                const Rec rec = rec8_unpack(q[k], row_base, c0, evw);
+                if (in_lds) *w.big_at(pos) = rec; else bv.spill[cs + pos] = rec;
             }
             __builtin_amdgcn_wave_barrier();
             if (valid && last) vcnt[px] = pos + 1;
@@ -648,26 +670,17 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
     }
     wave_phase();
-    // the segment list emit_rounds wants (it takes the counters' place): the part's non-empty pixels, relative to the builder's
-    // own origin, and their first records
-    {
-        const bool ne = pen > pst;
-        const uint64_t m = __ballot(ne);
-        const int nseg = __popcll(m);
-        if (ne) w.segs[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)(part * kWave + lane), pst);
-        if (lane == 0) w.segs[nseg] = make_uint2(0u, 0u);   // (a part's last segment ends where its lane says: see emit_rounds)
-        u.nseg = nseg;
-        u.pst = pst; u.pen = pen;
-    }
+    u.pst = pst; u.pen = pen;   // hot launch: the lane's segment; a main launch reads the cursors (now every pixel's END) per part
+    if (in_lds) u.part = -3;
     // the wave reads back what its own lanes stored: same CU, same vector L1 -- workgroup-scope release / acquire
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     u.cs = cs;
     u.ce = cs + nrec;
-    u.nstaged = 0;   // nothing of it is in the wave's stage: emit_rounds stages it part by part
+    u.nstaged = 0;   // nothing of it is in the wave's stage: emit_part / emit_parts_main stage it part by part
+    u.dpx = dpx; u.npixu = npixu;
     return u;
-    }
 }
 
 // Classic passes (the stream is pixel-sorted already): records [64, min(nrec, stage)) of the unit go to the wave's LDS
@@ -1010,9 +1023,9 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
 //   * a hotter part is walked from the stream through a four-deep register ring per lane -- the load of record j + 4 is
 //     issued when record j is consumed, so a step waits for arithmetic, not for L2 (the walks are sequential per pixel by
 //     contract: what bounds such a wave is its longest segment).
-template <typename OutT, int CMAX, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
+template <typename OutT, int CMAX, bool HOT, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
 __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, uint32_t st, uint32_t en, int part, Digest digest,
-                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, true> &w,
+                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w,
                                  const OutT *bg, Reduce reduce) {
     const int lane = threadIdx.x;
     const uint32_t cap = (uint32_t)w.bigcap;
@@ -1026,7 +1039,7 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     OutT vals[CMAX];
     if (__any(mine)) {
         if (STAGE && rb - ra <= cap) {   // wave-uniform (STAGE false: a builder that reads one record per segment)
-            constexpr int kDepth = 8;   // 16-byte loads in flight per lane
+            constexpr int kDepth = HOT ? 8 : 4;   // 16-byte loads in flight per lane
             for (uint32_t j0 = ra; j0 < rb; j0 += kDepth * kWave) {
                 Rec r[kDepth];
 #pragma unroll
@@ -1038,11 +1051,18 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
 #pragma unroll
                 for (int i = 0; i < kDepth; ++i) {
                     const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
-                    if (j < rb) *w.big_at(j - ra) = digest(r[i]);
+                    if (j < rb) *w.big_at(j - ra) = HOT ? digest(r[i]) : r[i];
                 }
             }
             wave_phase();
+            if constexpr (!HOT) {   // digested in its own loop: the load batch and the digest's temporaries would add up in a main launch's register budget
+                for (uint32_t j = (uint32_t)lane; j < rb - ra; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
+                wave_phase();
+            }
             if (mine) reduce(st - ra, en - ra, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
+        } else if (!HOT) {
+            // STAGE false (a main launch only sorts units whose parts fit the stage): one record per segment, from the slot
+            if (mine) reduce(st, en, [&](uint32_t j) -> Rec { return digest_fly(stream[j]); }, vals);
         } else if (mine) {
             Rec q0 = make_int4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
             uint32_t expect = 0xffffffffu;
@@ -1065,7 +1085,61 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
         for (int c = 0; c < CMAX; ++c) if (c < C) t[c] = vals[c];
     }
     wave_phase();
+    if (part == 0) w.pace();
     tile_store(w.tile, np * C, dst + (size_t)part * kWave * C);
+}
+
+// Main launch, key-sorted pass, a WARM unit (r04): more records than the record stage, few enough for the hot stage (an edge
+// crossing the unit leaves it 100-400 records where the window's average is 20).  unit_records has placed ALL its records,
+// pixel-sorted and time-ordered inside a pixel, in the hot stage -- which overlays the part tile; w.segs holds every pixel's
+// END.  They are digested one record per lane, then each 64-pixel part is reduced with one lane per PIXEL and leaves the wave
+// straight from the lanes' registers: lane l stores the C values of pixel l (the background for an empty pixel), 16 bytes at a
+// time -- a wave-instruction writes 16 bytes of each of 64 consecutive pixels, the C * sizeof / 16 instructions of a part
+// complete every line.  No tile, so no second home for the records, no spill slot and no trip through it: three dependent
+// memory round trips (run tables, records, -- ) where the slot path takes eight, which is what such a wave is made of when it
+// runs beside the frame's store-bound waves.
+template <typename OutT, int CMAX, typename Digest, typename Reduce>
+__device__ inline void emit_warm(const UnitRecs &u, uint32_t nrec, Digest digest, int npix, int C, OutT *__restrict__ dst,
+                                 WaveLds<OutT, false> &w, const OutT *bg, Reduce reduce) {
+    const int lane = threadIdx.x;
+    constexpr int V = 16 / (int)sizeof(OutT);
+    for (uint32_t j = (uint32_t)lane; j < nrec; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
+    wave_phase();
+    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(w.segs);
+    const bool vec = (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;   // wave-uniform
+    w.pace();
+    for (int p = 0; p * kWave < npix; ++p) {
+        const int np = min(kWave, npix - p * kWave);
+        const int px = p * kWave + u.dpx + lane;
+        uint32_t st = 0, en = 0;
+        if (lane < np && px < u.npixu) { en = cnt[px]; st = px ? cnt[px - 1] : 0u; }
+        OutT vals[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) vals[c] = (bg && c < C) ? bg[c] : (OutT)0;
+        if (en > st) reduce(st, en, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
+        if (lane < np) {
+            OutT *o = dst + ((size_t)p * kWave + lane) * C;
+            if (vec) {
+#pragma unroll
+                for (int v = 0; v < CMAX / V; ++v) {
+                    if (v * V < C) {
+                        uint4 pk;
+                        if constexpr (sizeof(OutT) == 8) {
+                            const double a = (double)vals[2 * v], b = (double)vals[2 * v + 1];
+                            pk = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+                        } else {
+                            pk = make_uint4(__float_as_uint((float)vals[4 * v]), __float_as_uint((float)vals[4 * v + 1]),
+                                            __float_as_uint((float)vals[4 * v + 2]), __float_as_uint((float)vals[4 * v + 3]));
+                        }
+                        gstore16(o + v * V, pk);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) o[c] = vals[c];
+            }
+        }
+    }
 }
 
 // emit_core over a unit's pixel-sorted records.  u.r0 = record `lane`; records [64, u.nstaged) sit in the wave's LDS stage
@@ -1090,7 +1164,20 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     Rec *evbuf = w.evbuf;
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     if constexpr (HOT) {   // one part of a unit beyond a main wave's stage, out of the unit's spill slot
-        emit_part<OutT, CMAX, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        emit_part<OutT, CMAX, true, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        return;
+    } else if (u.part == -3) {   // wave-uniform: a main launch, a WARM unit sorted into the hot stage (over the tile)
+        emit_warm<OutT, CMAX>(u, nrec, digest, npix, C, dst, w, bg, reduce);
+        return;
+    } else if (u.part == -2) {   // wave-uniform: a main launch, a unit it has sorted into its spill slot: part by part
+        const uint32_t *cnt = reinterpret_cast<const uint32_t *>(w.segs);   // every pixel's END in the slot
+        for (int p = 0; p * kWave < npix; ++p) {
+            const int px = p * kWave + u.dpx + lane;
+            uint32_t st = 0, en = 0;
+            if (lane < min(kWave, npix - p * kWave) && px < u.npixu) { en = cnt[px]; st = px ? cnt[px - 1] : 0u; }
+            wave_phase();   // the previous part's tile store has read the tile
+            emit_part<OutT, CMAX, false, STAGE>(sorted + cs, nrec, st, en, p, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        }
         return;
     }
     if (lane < (int)nrec) evbuf[u.nseg >= 0 ? u.pos : lane] = digest(r0);   // grouped units: straight to the record's place
