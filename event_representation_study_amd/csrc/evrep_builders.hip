@@ -35,6 +35,9 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 #ifndef EVREP_PARTS
 #define EVREP_PARTS 2
 #endif
+#ifndef EVREP_DEFER_MULT
+#define EVREP_DEFER_MULT 1   // a main launch defers a unit with a 64-pixel part of more than this many hot stages of records
+#endif
 #ifndef EVREP_XCD_MAP
 #define EVREP_XCD_MAP 1
 #endif
@@ -298,8 +301,14 @@ __device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
 // list, which nothing touches while it runs and which the next call's main launch appends to.  The binning pass clears both.
 // A hot item is ONE 64-pixel part of a unit (id * 8 + part): the wave sorts the part's records out of the unit's, stages and
 // walks them with one lane per pixel -- half the latency chain of a whole 128-pixel unit, twice the waves to spread.
-constexpr int kHotStage = 256;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
-constexpr int kHotGrid = 4096;    // workgroups of a hot launch
+#ifndef EVREP_HOT_STAGE
+#define EVREP_HOT_STAGE 256
+#endif
+#ifndef EVREP_HOT_GRID
+#define EVREP_HOT_GRID 4096
+#endif
+constexpr int kHotStage = EVREP_HOT_STAGE;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
+constexpr int kHotGrid = EVREP_HOT_GRID;    // workgroups of a hot launch
 constexpr int kHotParts = 8;      // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
 // Each of the two lists is kHotLists SUBLISTS with a counter of its own, 64 bytes apart: a clustered batch defers ten thousand
 // units, and device-scope atomics on ONE address retire at ~12 ns each (120 us of a 150 us launch, measured); a unit goes to
@@ -560,47 +569,48 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase();
-    // (the run table moves behind the pixel counters: a main launch places a warm unit over the record stage it lay in)
-    uint32_t *runs2 = cnt + npixu;
-    if (nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
-    wave_phase();
-    auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
-        if (nb <= kBsChainBlocks) {
-            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
-            uint32_t prev = sx;
-            for (int k = 1; k < nb; ++k) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
-                sx += (j >= pk) ? sk - prev : 0u;
-                prev = sk;
-            }
-            return sx + j;
-        }
-        uint32_t lo = 0, hi = (uint32_t)nb;
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const bool go = hi - lo > 1 && runs2[mid] <= j;
-            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
-        }
-        return runs2[64 + lo] + j;
-    };
+    // The sweeps go RUN BY RUN: a batch is up to 64 consecutive records of ONE block run -- address = the run's first record of
+    // the unit + lane, a handful of scalar instructions per batch where finding the run of record j of the unit takes a
+    // 3-instruction step per run (a 6-step LDS search in windows of more than 16 runs) per record.  kSpillBatch batches are
+    // in flight together; runs are visited in block order and a run is time-ordered, so the sweep order is the time order.
+    const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;   // lane k: the unit's first record in run k
+    int rk_ = 0;            // the sweep cursor: run, offset inside the run (wave-uniform)
+    uint32_t ro_ = 0;
+    uint32_t addr[kSpillBatch], bcnt[kSpillBatch];
     Rec8 q[kSpillBatch];
-    auto load_batch = [&](uint32_t s0) {
+    auto sweep_begin = [&]() { rk_ = 0; ro_ = 0; };
+    auto load_batch = [&]() -> bool {   // fills addr / bcnt / q; false: the sweep is over (nothing was filled)
+        bool any = false;
 #pragma unroll
-        for (int k = 0; k < kSpillBatch; ++k) {
-            const uint32_t j = s0 + (uint32_t)(k * kWave + lane);
-            q[k] = make_uint2(0u, 0u);
-            if (j < nrec) q[k] = s8[src_of(j)];
+        for (int sl = 0; sl < kSpillBatch; ++sl) {
+            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+            bcnt[sl] = 0u; addr[sl] = 0u;
+            if (rk_ < nb) {
+                addr[sl] = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_;
+                bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                ro_ += kWave;
+                any = true;
+            }
         }
+#pragma unroll
+        for (int sl = 0; sl < kSpillBatch; ++sl) {
+            q[sl] = make_uint2(0u, 0u);
+            if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr[sl] + (uint32_t)lane];
+        }
+        return any;
     };
     auto px_of = [&](const Rec8 &r) -> uint32_t { return ((r.y & 511u) - (uint32_t)c0) & 511u; };   // pixel inside the unit
-    const bool resident = nrec <= (uint32_t)(kSpillBatch * kWave);   // wave-uniform
-    for (uint32_t s0 = 0; s0 < nrec; s0 += kSpillBatch * kWave) {
-        load_batch(s0);
+    sweep_begin();
+    bool resident = false;
+    for (int round = 0; load_batch(); ++round) {
 #pragma unroll
-        for (int k = 0; k < kSpillBatch; ++k)
-            if (s0 + (uint32_t)(k * kWave + lane) < nrec) atomicAdd(&cnt[px_of(q[k])], 1u);
+        for (int sl = 0; sl < kSpillBatch; ++sl)
+            if ((uint32_t)lane < bcnt[sl]) atomicAdd(&cnt[px_of(q[sl])], 1u);
+        // the whole unit in ONE round: the placement below finds it still in the registers
+        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+        if (rk_ >= nb) { resident = round == 0; break; }
     }
     wave_phase();
     {
@@ -629,8 +639,11 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         for (int o0 = 0; o0 < npix_out; o0 += kWave) {
             const int lo = o0 + dpx, hi = min(o0 + kWave, npix_out) + dpx;
             const uint32_t b0 = lo < npixu ? cnt[lo] : nrec, b1 = hi < npixu ? cnt[hi] : nrec;
-            fits = fits && b1 - b0 <= (uint32_t)w.bigcap;
+            fits = fits && b1 - b0 <= (uint32_t)(EVREP_DEFER_MULT * w.bigcap);
         }
+#ifdef EVREP_NO_DEFER
+        fits = true;
+#endif
         if (!fits) {
             defer_unit(bv, uid, (npix_out + kWave - 1) / kWave);
             u.deferred = true;
@@ -647,13 +660,13 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     }
     wave_phase();
     volatile uint32_t *vcnt = cnt;
-    for (uint32_t s0 = 0; s0 < nrec; s0 += kSpillBatch * kWave) {
-        if (!resident) load_batch(s0);
+    if (!resident) sweep_begin();
+    for (bool more = resident ? true : load_batch(); more; more = resident ? false : load_batch()) {
 #pragma unroll
-        for (int k = 0; k < kSpillBatch; ++k) {
-            if (s0 + (uint32_t)(k * kWave) >= nrec) break;   // uniform
-            uint32_t px = px_of(q[k]);
-            const bool valid = s0 + (uint32_t)(k * kWave + lane) < nrec && (int)px >= plo && (int)px < phi;
+        for (int sl = 0; sl < kSpillBatch; ++sl) {
+            if (bcnt[sl] == 0u) break;   // uniform
+            uint32_t px = px_of(q[sl]);
+            const bool valid = (uint32_t)lane < bcnt[sl] && (int)px >= plo && (int)px < phi;
             if (!__any(valid)) continue;
             if (!valid) px = 0u;
             uint32_t rk; bool last;
@@ -661,7 +674,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             uint32_t pos = 0;
             if (valid) {
                 pos = vcnt[px] + rk;
-                const Rec rec = rec8_unpack(q[k], row_base, c0, evw);
+                const Rec rec = rec8_unpack(q[sl], row_base, c0, evw);
                 if (in_lds) *w.big_at(pos) = rec; else bv.spill[cs + pos] = rec;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1023,10 +1036,11 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
 //   * a hotter part is walked from the stream through a four-deep register ring per lane -- the load of record j + 4 is
 //     issued when record j is consumed, so a step waits for arithmetic, not for L2 (the walks are sequential per pixel by
 //     contract: what bounds such a wave is its longest segment).
-template <typename OutT, int CMAX, bool HOT, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
+template <typename OutT, int CMAX, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
 __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, uint32_t st, uint32_t en, int part, Digest digest,
-                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w,
+                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, true> &w,
                                  const OutT *bg, Reduce reduce) {
+    constexpr bool HOT = true;
     const int lane = threadIdx.x;
     const uint32_t cap = (uint32_t)w.bigcap;
     const int np = min(kWave, npix - part * kWave);
@@ -1089,6 +1103,33 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     tile_store(w.tile, np * C, dst + (size_t)part * kWave * C);
 }
 
+// One pixel's C values straight from a lane's registers: 16 bytes at a time when the pixel is a whole number of 16-byte
+// vectors (a wave-instruction then writes 16 bytes of each of 64 consecutive pixels; the C * sizeof / 16 instructions of a
+// part complete every line), element by element otherwise.
+template <typename OutT, int CMAX>
+__device__ inline void store_pixel(OutT *__restrict__ o, const OutT (&vals)[CMAX], int C, bool vec) {
+    constexpr int V = 16 / (int)sizeof(OutT);
+    if (vec) {
+#pragma unroll
+        for (int v = 0; v < CMAX / V; ++v) {
+            if (v * V < C) {
+                uint4 pk;
+                if constexpr (sizeof(OutT) == 8) {
+                    const double a = (double)vals[2 * v], b = (double)vals[2 * v + 1];
+                    pk = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+                } else {
+                    pk = make_uint4(__float_as_uint((float)vals[4 * v]), __float_as_uint((float)vals[4 * v + 1]),
+                                    __float_as_uint((float)vals[4 * v + 2]), __float_as_uint((float)vals[4 * v + 3]));
+                }
+                gstore16(o + v * V, pk);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) o[c] = vals[c];
+    }
+}
+
 // Main launch, key-sorted pass, a WARM unit (r04): more records than the record stage, few enough for the hot stage (an edge
 // crossing the unit leaves it 100-400 records where the window's average is 20).  unit_records has placed ALL its records,
 // pixel-sorted and time-ordered inside a pixel, in the hot stage -- which overlays the part tile; w.segs holds every pixel's
@@ -1117,28 +1158,77 @@ __device__ inline void emit_warm(const UnitRecs &u, uint32_t nrec, Digest digest
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) vals[c] = (bg && c < C) ? bg[c] : (OutT)0;
         if (en > st) reduce(st, en, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
-        if (lane < np) {
-            OutT *o = dst + ((size_t)p * kWave + lane) * C;
-            if (vec) {
+        if (lane < np) store_pixel<OutT, CMAX>(dst + ((size_t)p * kWave + lane) * C, vals, C, vec);
+    }
+}
+
+// Main launch, key-sorted pass, one 64-pixel part of a unit beyond the hot stage (r04), out of the unit's spill slot
+// (`stream`; lane l owns pixel part * 64 + l, records [st, en)).  The part is worked off in PIECES: as many consecutive pixels
+// as hold no more records than the hot stage; a piece's records are staged -- coalesced 16-byte loads, four in flight --
+// digested one record per lane, reduced from LDS one lane per pixel, and the lanes store their pixels straight from their
+// registers (store_pixel), so the stage never has to make room for a tile and nothing outlives a piece.  A single PIXEL of
+// more records than the stage is walked from the slot.  (A unit with a part of more than EVREP_DEFER_MULT stages goes to the
+// hot launch instead: unit_records.)
+template <typename OutT, int CMAX, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
+__device__ inline void emit_part_main(const Rec *__restrict__ stream, uint32_t st, uint32_t en, int part, Digest digest,
+                                      DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, false> &w,
+                                      const OutT *bg, Reduce reduce) {
+    const int lane = threadIdx.x;
+    constexpr int V = 16 / (int)sizeof(OutT);
+    const uint32_t cap = (uint32_t)w.bigcap;
+    const int np = min(kWave, npix - part * kWave);
+    const bool mine = en > st && lane < np;
+    const bool vec = (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;   // wave-uniform
+    const uint64_t mm = __ballot(mine);
+    OutT *o = dst + ((size_t)part * kWave + lane) * C;
+    for (int ls = 0; ls < np;) {   // pieces (wave-uniform)
+        const uint64_t m = mm & ~((1ull << ls) - 1ull);
+        int le = np;
+        bool staged = false;
+        uint32_t ra = 0;
+        if (m) {
+            const int f = __builtin_ctzll(m);
+            ra = (uint32_t)__builtin_amdgcn_readlane((int)st, f);
+            if (STAGE) {
+                const uint64_t bad = __ballot(mine && lane >= f && en - ra > cap);
+                if (bad) le = __builtin_ctzll(bad);
+                if (le == f) le = f + 1;   // ONE pixel of more records than the stage: walked from the slot
+                else {
+                    const uint64_t in = m & ((le < 64 ? (1ull << le) : 0ull) - 1ull);
+                    const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)en, 63 - __builtin_clzll(in));
+                    wave_phase();   // the previous piece's walks have read the stage
+                    for (uint32_t j0 = ra; j0 < rb; j0 += 4 * kWave) {
+                        uint4 r[4];
 #pragma unroll
-                for (int v = 0; v < CMAX / V; ++v) {
-                    if (v * V < C) {
-                        uint4 pk;
-                        if constexpr (sizeof(OutT) == 8) {
-                            const double a = (double)vals[2 * v], b = (double)vals[2 * v + 1];
-                            pk = make_uint4((uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
-                        } else {
-                            pk = make_uint4(__float_as_uint((float)vals[4 * v]), __float_as_uint((float)vals[4 * v + 1]),
-                                            __float_as_uint((float)vals[4 * v + 2]), __float_as_uint((float)vals[4 * v + 3]));
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
+                            r[i] = make_uint4(0u, 0u, 0u, 0u);
+                            if (j < rb) r[i] = gload16(stream + j);
                         }
-                        gstore16(o + v * V, pk);
-                    }
-                }
-            } else {
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) o[c] = vals[c];
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
+                            if (j < rb) *w.big_at(j - ra) = make_int4((int)r[i].x, (int)r[i].y, (int)r[i].z, (int)r[i].w);
+                        }
+                    }
+                    wave_phase();
+                    for (uint32_t j = (uint32_t)lane; j < rb - ra; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
+                    wave_phase();
+                    staged = true;
+                }
             }
         }
+        if (lane >= ls && lane < le) {
+            OutT vals[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) vals[c] = (bg && c < C) ? bg[c] : (OutT)0;
+            if (mine) {
+                if (staged) reduce(st - ra, en - ra, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
+                else reduce(st, en, [&](uint32_t j) -> Rec { return digest_fly(stream[j]); }, vals);
+            }
+            store_pixel<OutT, CMAX>(o, vals, C, vec);
+        }
+        ls = le;
     }
 }
 
@@ -1164,7 +1254,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     Rec *evbuf = w.evbuf;
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     if constexpr (HOT) {   // one part of a unit beyond a main wave's stage, out of the unit's spill slot
-        emit_part<OutT, CMAX, true, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        emit_part<OutT, CMAX, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
         return;
     } else if (u.part == -3) {   // wave-uniform: a main launch, a WARM unit sorted into the hot stage (over the tile)
         emit_warm<OutT, CMAX>(u, nrec, digest, npix, C, dst, w, bg, reduce);
@@ -1175,8 +1265,8 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
             const int px = p * kWave + u.dpx + lane;
             uint32_t st = 0, en = 0;
             if (lane < min(kWave, npix - p * kWave) && px < u.npixu) { en = cnt[px]; st = px ? cnt[px - 1] : 0u; }
-            wave_phase();   // the previous part's tile store has read the tile
-            emit_part<OutT, CMAX, false, STAGE>(sorted + cs, nrec, st, en, p, digest, digest_fly, npix, C, dst, w, bg, reduce);
+            if (p == 0) w.pace();
+            emit_part_main<OutT, CMAX, STAGE>(sorted + cs, st, en, p, digest, digest_fly, npix, C, dst, w, bg, reduce);
         }
         return;
     }
