@@ -61,6 +61,7 @@ SYMBOLS = {
     "evrep_tore_ftime": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "evrep_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f64, _vp, _vp]),
     "evrep_voxel_range": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "evrep_voxel_tnorm": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp]),
     "evrep_voxel_subpixel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "evrep_polstats": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp]),
     "evrep_est_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _f64, _f64, _vp, _vp]),

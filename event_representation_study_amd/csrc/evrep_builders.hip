@@ -1777,7 +1777,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
         // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
         // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
         const int tref = cp->tref;
-        const bool fact = FACT && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
+        const bool fact = FACT && !(premap & 2) && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
         double fac[(CM / 2)];
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) fac[q] = cp->fac[q];
@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
                     if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
                 }
                 if (j < je) {
-                    if (premap) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
+                    if (premap & 1) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
                     if (p & 1) cur1 = t; else cur0 = t;
                 }
             }
@@ -1964,7 +1964,8 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
 template <int CM, bool HOT = false>
 __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
-                                                const int64_t *__restrict__ t_range, double *__restrict__ out) {
+                                                const int64_t *__restrict__ t_range, const double *__restrict__ tnorm,
+                                                double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         WaveLds<double, HOT> w(smem, bins, uc.span * kChunkPx, uc.stage);
@@ -2003,8 +2004,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_voxel(const int4 *__rest
         // (rank, t) fields, which the segment walks below do not need.  Both np.add.at passes of every segment then run
         // without a division (they were the bulk of this kernel's VALU work: the walks are divergent, one division per step
         // and lane).
+        // tnorm (evrep_voxel_tnorm): the caller's own normalised time, gathered by the record's rank -- one load per record
+        const double *tw = tnorm ? tnorm + beg : nullptr;
         auto digest = [&](const Rec &r) -> Rec {
-            const double bp = bin_pos(r.z);
+            const double bp = tw ? (double)(bins - 1) * tw[r.y] : bin_pos(r.z);
             return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
         };
         auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[CM]) {

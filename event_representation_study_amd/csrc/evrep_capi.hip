@@ -605,8 +605,22 @@ int evrep_voxel(const evrep_plan *plan, const int32_t *events, const int64_t *of
     return evrep_voxel_range(plan, events, offsets, workspace, bins, mode, scale, nullptr, out, stream_);
 }
 
+static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                        int32_t bins, int32_t mode, double scale, const int64_t *t_range, const double *tnorm, double *out, void *stream_);
+
 int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                       int32_t bins, int32_t mode, double scale, const int64_t *t_range, double *out, void *stream_) {
+    return voxel_launch(plan, events, offsets, workspace, bins, mode, scale, t_range, nullptr, out, stream_);
+}
+
+int evrep_voxel_tnorm(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      const double *tnorm, int32_t bins, double scale, double *out, void *stream_) {
+    if (plan && plan->total_events > 0 && !tnorm) return EVREP_EINVAL;
+    return voxel_launch(plan, events, offsets, workspace, bins, 0, scale, nullptr, tnorm, out, stream_);
+}
+
+static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                        int32_t bins, int32_t mode, double scale, const int64_t *t_range, const double *tnorm, double *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
@@ -618,10 +632,10 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
     do {                                                                                                         \
     k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
-        bins, mode, scale, t_range, out);                                                                        \
+        bins, mode, scale, t_range, tnorm, out);                                                                 \
     k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, kHotStage), stream>>>(         \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
-        hot_cfg(uc), bins, mode, scale, t_range, out);                                                           \
+        hot_cfg(uc), bins, mode, scale, t_range, tnorm, out);                                                    \
     } while (0)
     if (bins <= 8) VOXEL_LAUNCH(8); else VOXEL_LAUNCH(16);
 #undef VOXEL_LAUNCH

@@ -203,12 +203,14 @@ class EventBatch:
 
     def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None, indices=None):
         """ToTimesurface for every window -> (B, H, W, 2*slices), channel c = 2*s + p.  indices=None: the
-        dispatcher's cuts searchsorted(t_norm, 1..slices); else explicit event indices per window."""
+        dispatcher's cuts searchsorted(t_norm, 1..slices); else explicit event indices per window.
+        premap: True / 1 = p -> int8((p+1)/2) first; + 2 = timestamps not ascending (array-order scan, per-slice exponentials;
+        needs explicit indices)."""
         self.bin()
         out = self._out(out, 2 * slices, dtype)
         keep, iptr = self._i32_dev(indices, slices)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_time_surface(*self._args(), int(slices), iptr, float(tau), int(bool(premap)),
+            check(self.lib.evrep_time_surface(*self._args(), int(slices), iptr, float(tau), int(premap),
                                               float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
                   "evrep_time_surface")
         return out
@@ -263,6 +265,18 @@ class EventBatch:
         with torch.cuda.device(self.device):
             check(self.lib.evrep_voxel_range(*self._args(), int(bins), int(mode), float(scale), rptr, _ptr(out),
                                              _stream_ptr()), "evrep_voxel_range")
+        return out
+
+    def voxel_tnorm(self, tnorm, bins=5, scale=1.0, out=None):
+        """compute_repr with the caller's own normalised time (gromov_wasserstein.py:72-82) -> (B, H, W, bins) float64.
+        tnorm: float64 device tensor, one value per event (indexed like the events)."""
+        self.bin()
+        if tnorm.dtype != torch.float64 or tnorm.device != self.device or tnorm.numel() != self.total or not tnorm.is_contiguous():
+            raise ValueError("tnorm must be a contiguous float64 tensor with one entry per event on %s" % self.device)
+        out = self._out(out, bins, torch.float64)
+        with torch.cuda.device(self.device):
+            check(self.lib.evrep_voxel_tnorm(*self._args(), _ptr(tnorm), int(bins), float(scale), _ptr(out), _stream_ptr()),
+                  "evrep_voxel_tnorm")
         return out
 
     def voxel_subpixel(self, xy, bins=5, t_range=None, out=None):

@@ -108,6 +108,10 @@ def _context(height, width, n):
     return ctx
 
 
+class UnsortedWindow(NotImplementedError):
+    """A window whose timestamps are not ascending reached a wrapper that needs them so (or needs to take its slow path)."""
+
+
 class SampleBatch:
     """One pooled window: ``.batch`` is the resident EventBatch (its builders take ``out=``), ``.out(C, dtype)`` the pooled
     output tensor, ``finish()`` the one synchronisation."""
@@ -134,7 +138,7 @@ class SampleBatch:
     def event_stack(self, stack_size=12, premap=True, scale=1.0):
         return self.batch.event_stack(stack_size, premap, scale, out=self.out(stack_size, torch.float32))
 
-    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, indices=None):
+    def time_surface(self, slices=6, tau=50000.0, premap=1, scale=1.0, dtype=torch.float64, indices=None):
         return self.batch.time_surface(slices, tau, premap, scale, dtype, out=self.out(2 * slices, dtype), indices=indices)
 
     def voxel(self, bins=5, mode=0, scale=1.0, t_range=None):
@@ -219,7 +223,7 @@ def _raise_for_status_word(st, batch, allow_oob, what, allow_unsorted=False):
         # MixedDensityEventStack works in ARRAY order (windows by index, scatter in index order, t.min() / t.max()): the
         # kernels do the same whatever the timestamps' order, so its wrappers pass allow_unsorted; the other builders'
         # semantics on unsorted input differ from what the FIFO / last-event kernels compute
-        raise NotImplementedError("%s: timestamps must be ascending (the reference's adapters deliver them so)" % what)
+        raise UnsortedWindow("%s: timestamps must be ascending (the reference's adapters deliver them so)" % what)
 
 
 def events_from_fields(x, y, t, p, truncate=False):
@@ -240,7 +244,7 @@ def single_batch(event_sequence, height, width, truncate=False, rebase_t=False):
     return EventBatch.from_numpy(ev, height, width)
 
 
-def raise_for_status(batch, allow_oob=False, what="builder", any_window_oob=False):
+def raise_for_status(batch, allow_oob=False, what="builder", any_window_oob=False, allow_unsorted=False):
     """Turn the per-window status word into the exception the reference raises (window 0 is the sample;
     ``any_window_oob``: the out-of-frame check covers every window of the batch)."""
     sts = batch.status()
@@ -250,6 +254,6 @@ def raise_for_status(batch, allow_oob=False, what="builder", any_window_oob=Fals
     oob = any(int(s) & _lib.ST_OOB for s in sts) if any_window_oob else (st & _lib.ST_OOB)
     if oob and not allow_oob:
         raise IndexError("%s: event coordinates outside the %dx%d frame" % (what, batch.W, batch.H))
-    if st & _lib.ST_UNSORTED:
-        raise NotImplementedError("%s: timestamps must be ascending (the reference's adapters deliver them so)" % what)
+    if (st & _lib.ST_UNSORTED) and not allow_unsorted:
+        raise UnsortedWindow("%s: timestamps must be ascending (the reference's adapters deliver them so)" % what)
     return st

@@ -8,7 +8,7 @@ one fused launch sequence on the GPU (binning pass + builder, the x255 folded in
 """
 import numpy as np
 
-from ._common import finish, sample_batch
+from ._common import UnsortedWindow, finish, sample_batch
 
 STACK_LEVELS = 12      # gen1_transforms.py:35
 VOXEL_BINS = 12        # :22
@@ -39,9 +39,15 @@ def _optimized(events, transform, height, width, num_events, device_out=False):
 
 
 def _event_stack(events, transform, height, width, num_events, device_out=False):
-    sb = sample_batch(events, height, width, device_out=device_out)
+    # EventStack.pre_stack splits at last_timestamp = t[-1] (:36-38, event_stack.py:23,27) and the dispatcher keeps the past
+    # half (:40); the stack itself only looks at the ORDER of the events (put is last-write-wins in array order,
+    # event_stack.py:125).  On ascending timestamps the past half is the whole window; otherwise it is the events with
+    # t <= t[-1], in array order (r04: unsorted windows are built in array order, as the reference does)
+    t = np.asarray(events["t"])
+    past = t <= t[-1] if len(t) else None
+    sb = sample_batch(events if past is None or past.all() else events[past], height, width, device_out=device_out)
     events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34)
-    return finish(sb, sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE)), what="EventStack")
+    return finish(sb, sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE)), what="EventStack", allow_unsorted=True)
 
 
 def _histogram(events, transform, height, width, num_events, device_out=False):
@@ -57,6 +63,9 @@ def _histogram(events, transform, height, width, num_events, device_out=False):
 
 
 def _tore(events, transform, height, width, num_events, device_out=False):
+    # (timestamps that are not ascending are refused: the reference keeps a pixel's k most recent intervals with np.partition
+    # on a k-vector (tore.py:22-25), which is a FIFO only while every new interval is the smallest; otherwise the order of
+    # the kept values is whatever numpy's introselect leaves behind -- no semantics to mirror)
     sb = sample_batch(events, height, width, device_out=device_out)
     # bounding-box frame, origin-shifted, sample time t[-1] (:61-66): frame_mode 0; the box travels with the result
     return finish(sb, sb.tore_full(k=TORE_K, frame_mode=0, scale=float(SCALE)), what="TORE", tore_k=TORE_K)
@@ -64,9 +73,20 @@ def _tore(events, transform, height, width, num_events, device_out=False):
 
 def _time_surface(events, transform, height, width, num_events, device_out=False):
     sb = sample_batch(events, height, width, device_out=device_out)
+    t = np.asarray(events["t"])       # (read before the side effect below; the events themselves are on their way already)
     events["p"] = ((events["p"] + 1) / 2).astype(np.int8)     # (:70-72)
     # the six cuts searchsorted(t_norm, 1..6) are taken on the device from the same float64 formula
-    return finish(sb, sb.time_surface(TS_SLICES, float(TS_TAU), premap=True, scale=float(SCALE)), what="ToTimesurface")
+    try:
+        return finish(sb, sb.time_surface(TS_SLICES, float(TS_TAU), premap=1, scale=float(SCALE)), what="ToTimesurface")
+    except UnsortedWindow:
+        # timestamps not ascending (r04): the reference's scan runs in array order whatever they are (time_surface.py:66-74),
+        # and so do the kernels; the cuts are what the DISPATCHER's own numpy call yields on such an array (:79-81) -- taken
+        # here, handed over as explicit indices -- and the exponentials are not factorised (premap bit 1)
+        t_norm = (t - t[0]) / (t[-1] - t[0]) * TS_SLICES
+        idx = np.searchsorted(t_norm, np.arange(TS_SLICES) + 1)
+        sb.batch._binned = True       # the same events, already binned
+        return finish(sb, sb.time_surface(TS_SLICES, float(TS_TAU), premap=3, scale=float(SCALE), indices=idx),
+                      what="ToTimesurface", allow_unsorted=True)
 
 
 # order matters: "MixedDensityEventStack" contains "EventStack" (:27 is tested before :33)

@@ -28,7 +28,9 @@ class ToTimesurface:
             return out
         ev = events_from_fields(events["x"], events["y"], events["t"], events["p"])
         batch = EventBatch.from_numpy(ev, H, W)
-        raise_for_status(batch, what="ToTimesurface")
+        # the scan of time_surface.py:66-74 runs in array order: timestamps that are not ascending only forbid the factorised
+        # exponentials (premap bit 1)
+        unsorted = bool(raise_for_status(batch, what="ToTimesurface", allow_unsorted=True) & 4)
         # the reference's scan tests `index == indices[pos]` once per event: only a strictly increasing
         # prefix of in-range indices is ever reached, every later surface stays all-zero
         live, prev = 0, -1
@@ -38,7 +40,7 @@ class ToTimesurface:
             live, prev = live + 1, i
         for s0 in range(0, live, 8):                                  # up to 8 surfaces per launch
             chunk = indices[s0:min(s0 + 8, live)]
-            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=False, indices=chunk)
+            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=2 if unsorted else 0, indices=chunk)
             rep = rep[0].cpu().numpy().reshape(H, W, len(chunk), 2)    # channel c = 2*s + p
             out[s0:s0 + len(chunk)] = rep.transpose(2, 3, 0, 1)
         return out

@@ -144,7 +144,10 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
 /* ToTimesurface.__call__ (time_surface.py:25-74): S <= 8 surfaces sampled at event indices.
  * indices == NULL: the cuts gen1_transforms.py:79-81 computes, searchsorted(t_norm, 1..S);
  * otherwise DEVICE int32 [B,S], the `indices` argument of ToTimesurface.__call__.
- * premap != 0 applies p -> int8((p+1)/2) first (gen1_transforms.py:70-72).
+ * premap bit 0 applies p -> int8((p+1)/2) first (gen1_transforms.py:70-72); bit 1 (premap 2 / 3): the timestamps are NOT
+ * ascending -- the scan of time_surface.py:66-74 runs in ARRAY order whatever the timestamps, and so do the kernels; the bit
+ * only keeps them from factorising the exponentials around a reference time (a memory timestamp may then lie far BEHIND a
+ * cut's).  The caller must hand `indices` itself for such a window: searchsorted on an unsorted array is the caller's numpy's.
  * out DEVICE (B,H,W,2S) float64/float32, channel c = 2s+p. */
 int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                        int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
@@ -187,6 +190,13 @@ int evrep_voxel_range(const evrep_plan *plan, const int32_t *events, const int64
  * order.  `events` carries the TRUNCATED coordinates (x.astype("int32"), :92-93), xy DEVICE double [total,2] the
  * original (x, y) of every event (indexed like `events`); t_range as evrep_voxel_range.
  * out DEVICE float32 (B,H,W,bins), before the optional normalisation. */
+/* compute_repr(x, y, t, p, width, height, bins) itself (representation_search/gromov_wasserstein.py:72-82): the caller hands
+ * its own normalised time per event -- tnorm DEVICE double [total_events], indexed like `events`, used exactly as the
+ * reference uses `t`: b = (bins - 1) * t, blim in {int(b), int(b) + 1}, grid[y, x, blim] += (1 - |blim - b|) * p, lower
+ * bin for every event, then the upper bin.  The events' own t column only orders them.  out DEVICE double (B,H,W,bins). */
+int evrep_voxel_tnorm(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                      const double *tnorm, int32_t bins, double scale, double *out, void *stream);
+
 int evrep_voxel_subpixel(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                          const double *xy, int32_t bins, const int64_t *t_range, float *out, void *stream);
 

@@ -5,6 +5,8 @@ import torch
 
 from conftest import STANDARD_CASES, assert_bit_equal, load_golden
 
+from event_representation_study_amd.synthetic import to_structured  # noqa: E402
+
 from event_representation_study_amd.synthetic import make_events
 
 pytestmark = pytest.mark.gpu
@@ -162,8 +164,48 @@ def test_status_bits_and_exceptions(eng):
     from conftest import assert_bit_equal as abe
     import oracle as orc
     abe(get_optimized_representation(to_structured(unsorted), 500, H, W), orc.ergo12(unsorted, H, W))
+    # TORE's order on such a window is whatever numpy's introselect leaves behind (tore.py:22-25: np.partition of a 6-vector
+    # whose new element is not the smallest): refused, loudly
     with pytest.raises(NotImplementedError):
-        gen1_transforms.get_item_transform(to_structured(unsorted), "ToTimesurface", None, H, W, 500, 50000)
+        gen1_transforms.get_item_transform(to_structured(unsorted), "<function events2ToreFeature at 0x0>", None, H, W, 500, 50000)
+
+
+@pytest.mark.parametrize("enc", ["pm1", "01"])
+def test_unsorted_windows_through_the_dispatcher(enc):
+    """Timestamps that are NOT ascending (r04): EventStack (the past half t <= t[-1] in array order) and ToTimesurface
+    (array-order scan, cuts from numpy's searchsorted on the unsorted t_norm) against goldens from the reference's own
+    dispatcher (tests/golden/make_golden_r04.py), host result and device result."""
+    from event_representation_study_amd.representations import gen1_transforms
+    g = load_golden("unsorted_80x60_n4000_" + enc)
+    H, W, N = int(g["H"]), int(g["W"]), g["events"].shape[0]
+    for label, name in (("event_stack", "EventStack"), ("time_surface", "ToTimesurface")):
+        rec = to_structured(g["events"])
+        rep = gen1_transforms.get_item_transform(rec, name, None, H, W, N, 50000)
+        want = g["rep_" + label]
+        assert rep.shape == want.shape and rep.dtype == want.dtype, label
+        if label == "event_stack":
+            assert_bit_equal(rep, want, label)
+        else:
+            np.testing.assert_allclose(rep, want, rtol=1e-12, atol=0)      # budget 1e-5
+        assert np.array_equal(rec["p"], g["p_after_" + label])
+        dev = gen1_transforms.get_item_transform_cuda(to_structured(g["events"]), name, None, H, W, N, 50000)
+        assert np.array_equal(dev.cpu().numpy(), rep), label
+
+
+def test_compute_repr_with_the_callers_own_float_time():
+    """compute_repr(x, y, t, p, width, height, bins) -- the reference's name and signature -- with caller-normalised float64 t
+    in no particular order: bit-exact against the reference's own function (np.add.at order: lower bins, then upper bins)."""
+    from event_representation_study_amd.representations.representation_search.gromov_wasserstein import compute_repr
+    g = load_golden("compute_repr_float_t_64x48")
+    for bins in (5, 9):
+        got = compute_repr(g["x"], g["y"], g["t"], g["p"], int(g["W"]), int(g["H"]), bins=bins)
+        assert_bit_equal(got, g["voxel%d" % bins], "compute_repr bins=%d" % bins)
+    # and the demo's own normalisation of integer timestamps (gromov_wasserstein.py:96) equals the integer-time entry point
+    c1 = load_golden("c1_304x240_n10000_01")
+    ev = c1["events"]
+    t = ev[:, 2].astype(np.float64)
+    t = (t - t[0]) / (t[-1] - t[0])
+    assert_bit_equal(compute_repr(ev[:, 0], ev[:, 1], t, ev[:, 3], int(c1["W"]), int(c1["H"])), c1["voxel5"], "compute_repr c1")
 
 
 def test_mdes_unsorted_timestamps(eng, monkeypatch):

@@ -143,6 +143,25 @@ def test_gwd_fullsize_properties(eng, oracle):
     assert abs(sub - ref) <= 1e-5 * ref
 
 
+def test_gwd_fullsize_golden(eng):
+    """The 12 500 x 4 vs 14 400 x 14 cost bench.py's GWD leg prints, against the float64 oracle value committed as a golden
+    (tests/golden/make_golden_gwd_fullsize.py; budget 1e-5 relative), single solve and batched solve."""
+    import json
+    import os
+    from conftest import GOLDEN
+    sys_path = os.path.join(GOLDEN, "gwd_fullsize.json")
+    g = json.load(open(sys_path))
+    rng = np.random.default_rng(g["seed"])
+    Xs = rng.random((g["n"], 4))
+    Xt = rng.random((g["m"], 14)) * np.array([255.0] * 12 + [1.0, 1.0])
+    c = float(eng.gwd_padded_l1(Xs, Xt).item())
+    assert abs(c - g["cost_f64"]) <= 1e-5 * g["cost_f64"], (c, g["cost_f64"])
+    xs, xt = torch.from_numpy(Xs).cuda(), torch.from_numpy(Xt).cuda()
+    one = torch.ones(3, dtype=torch.int64, device="cuda")
+    cb = eng.gwd_padded_l1_batch(xs, one * g["n"], xt, one * g["m"], g["n"], g["m"], xs_row=one * 0, xt_row=one * 0)
+    assert all(abs(float(v) - g["cost_f64"]) <= 1e-5 * g["cost_f64"] for v in cb.cpu())
+
+
 def test_bin_build_pipeline_matches_serial(eng):
     """bin(k+1) overlapped with build(k) on a second stream gives the same tensors as the serial path."""
     H, W, N, B = 120, 160, 6000, 4

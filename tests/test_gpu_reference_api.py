@@ -656,3 +656,78 @@ def test_nimagenet_acc_sort(tag):
                                  use_image=False, quantize_sort=None, strict=False, denoise_image=False, denoise_sort=True)
     with pytest.raises(KeyError):
         ni.reshape_then_acc_sort(torch.from_numpy(ev.copy()), height=H, width=W)
+
+
+def test_results_are_the_callers_own():
+    """"outputs are fresh arrays".  A caller keeps 40 results of the same shape (a list comprehension over
+    samples, a collate over a batch): none of them may change when later calls reuse the pinned pool."""
+    from event_representation_study_amd.representations.optimized_representation import get_optimized_representation
+    from event_representation_study_amd.representations import gen1_transforms, _common
+    from event_representation_study_amd import engine as eng
+    H, W, N = 60, 80, 3000
+    wins = [make_events(N, W, H, seed=900 + i) for i in range(40)]
+    kept = [get_optimized_representation(to_structured(w), N, H, W) for w in wins]
+    want = eng.EventBatch.from_numpy(wins, H, W).optimized().cpu().numpy()
+    for i in range(40):
+        assert_bit_equal(kept[i], want[i], "kept result %d" % i)
+    # views of a result keep its buffer out of the pool as well
+    views = [get_item(w) for w in wins[:12] for get_item in (lambda w: gen1_transforms.get_item_transform(
+        to_structured(w), "EventStack", None, H, W, N, 50000)[..., 3],)]
+    es = eng.EventBatch.from_numpy(wins[:12], H, W).event_stack(scale=255.0).cpu().numpy()
+    for i in range(12):
+        assert np.array_equal(views[i], es[i][..., 3])
+    # dropped results give their buffers back: the pool does not grow past its depth
+    del kept, views
+    for w in wins:
+        get_optimized_representation(to_structured(w), N, H, W)
+    pools = [len(p) for ctx in _common._CONTEXTS.values() for p in ctx.pools.values()]
+    assert max(pools) <= _common.RESULT_POOL_DEPTH
+
+
+def test_wrappers_from_two_host_threads():
+    """Two host threads call the per-sample wrappers at the same (H, W, size): each has its own pooled context."""
+    import threading
+    from event_representation_study_amd.representations.optimized_representation import get_optimized_representation
+    from event_representation_study_amd import engine as eng
+    H, W, N = 48, 64, 2500
+    wins = [make_events(N, W, H, seed=1200 + i) for i in range(24)]
+    want = eng.EventBatch.from_numpy(wins, H, W).optimized().cpu().numpy()
+    got, errs = [None] * 24, []
+
+    def work(lo):
+        try:
+            for rep in range(3):
+                for i in range(lo, lo + 12):
+                    got[i] = get_optimized_representation(to_structured(wins[i]), N, H, W)
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(lo,)) for lo in (0, 12)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(24):
+        assert_bit_equal(got[i], want[i], "thread result %d" % i)
+
+
+def test_get_item_transform_cuda_equals_host_path():
+    """device_out: the same dispatch, side effects and x255, result left on the GPU (no read-back)."""
+    import torch
+    from event_representation_study_amd.representations import gen1_transforms, gen4_transforms
+    from event_representation_study_amd.representations.tonic_compat import ToImage, ToVoxelGrid
+    H, W, N = 60, 80, 4000
+    for name, tr in (("MixedDensityEventStack", None), ("EventStack", None), (TORE_NAME, None), ("ToTimesurface", None),
+                     (str(ToVoxelGrid), ToVoxelGrid), (str(ToImage), ToImage)):
+        a, b = to_structured(make_events(N, W, H, seed=77)), to_structured(make_events(N, W, H, seed=77))
+        host = gen1_transforms.get_item_transform(a, name, tr, H, W, N, 50000)
+        dev = gen1_transforms.get_item_transform_cuda(b, name, tr, H, W, N, 50000)
+        assert isinstance(dev, torch.Tensor) and dev.is_cuda and tuple(dev.shape) == host.shape, name
+        assert np.array_equal(dev.cpu().numpy(), host), name
+        assert np.array_equal(a["p"], b["p"]), name       # the same in-place rewrite of ["p"]
+        dev4 = gen4_transforms.get_item_transform_cuda(to_structured(make_events(N, W, H, seed=77)), name, tr, H, W, N)
+        assert torch.equal(dev4, dev), name
+    # a kept device result is the caller's own too
+    kept = [gen1_transforms.get_item_transform_cuda(to_structured(make_events(N, W, H, seed=s)), "EventStack", None, H, W, N, 0)
+            for s in range(10)]
+    again = [gen1_transforms.get_item_transform_cuda(to_structured(make_events(N, W, H, seed=s)), "EventStack", None, H, W, N, 0)
+             for s in range(10)]
+    assert all(torch.equal(x, y) for x, y in zip(kept, again))

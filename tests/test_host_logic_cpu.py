@@ -159,3 +159,23 @@ def test_precompute_parts_of_one_batch_never_share_pinned_storage(monkeypatch):
     depth = 4 + pc.nwriters + 2
     assert len(set(seen_flat[:depth])) == depth                  # consecutive batches get different buffers
     assert seen_flat[depth:2 * depth] == seen_flat[2 * depth:3 * depth]   # ... recycled round-robin afterwards
+
+
+def test_result_slot_is_free_only_when_nothing_outside_refers_to_it():
+    """The pinned result pool of the per-sample wrappers (representations/_common.py): a buffer is handed out again only when
+    no array handed out earlier -- or any view of one -- is still alive."""
+    import torch
+    from event_representation_study_amd.representations._common import _ResultSlot
+    slot = _ResultSlot((4, 5, 3), torch.float64, pin=False)
+    assert slot.free()
+    a = slot.master.view()
+    assert not slot.free()
+    b = a[..., 1]                      # a view of a view still has the master as its base
+    c = a.reshape(-1)[:6].reshape(2, 3)
+    del a
+    assert not slot.free()
+    t = torch.from_numpy(b)            # torch.tensor()-style consumers keep it alive as well
+    del b, c
+    assert not slot.free()
+    del t
+    assert slot.free()
