@@ -74,6 +74,8 @@ def parse():
                     help="after the timed region, also time 200 steps into the FIRST candidate allocation (what a run without the "
                          "placement probe gets) -> value_per_gpu_first_allocation; off by default so that a profiled run's kernel "
                          "statistics hold the measured steps only (all_us[0] of the probe already predicts it)")
+    ap.add_argument("--resident-batches", type=int, default=12,
+                    help="distinct resident batches the timed loop rotates over (12 x 25.6 MB of events > the 256 MB Infinity Cache)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -313,16 +315,33 @@ def gw_extension_leg(device):
 
 def sweep_leg(device):
     """Every builder at the reference's real Gen1 shape (304x240, 50 000 events, gen1_2yolo.py:41-42,81-82) and at BASELINE
-    configs 2 and 3: binning and build launch timed separately with HIP events (tools/bench_sweep.py), the build launch
-    against the same algorithmic-byte definition as the headline (16 B per event + the output tensor once)."""
+    configs 2 and 3: binning and build launch(es) timed separately with HIP events (tools/bench_sweep.py), the build against
+    the same algorithmic-byte definition as the headline (16 B per event + the output tensor once).  Beside the uniform
+    streams of SURVEY 8(d): the reference's moving-circle stream and an edge-cluster stream (synthetic.GENERATORS) for the
+    three 12-channel builders, and the dense stress points N = 500 000 (640x480) / N = 1 000 000 (1280x720)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_sweep
     rows = bench_sweep.sweep(("gen1", "c2", "c3"), iters=10, device=str(device))
-    keep = ("config", "builder", "binning_pass", "bin_ms", "build_ms", "build_GBps", "build_frac_of_8TBps",
+    three = ("optimized_f64", "event_stack_f32", "time_surface_f64")
+    rows += bench_sweep.sweep(("gen1@circle", "gen1@edges", "c2@circle", "c2@edges"), iters=10, builders=three, device=str(device))
+    rows += bench_sweep.sweep(("c2-dense", "c3-1M"), iters=10, builders=three + ("tore_full_frame_f32", "voxel5_f64"), device=str(device))
+    keep = ("config", "distribution", "builder", "binning_pass", "bin_ms", "build_ms", "build_GBps", "build_frac_of_8TBps",
             "events_per_s_bin_plus_build")
+    # clustered rows: bin + build time over the uniform row of the same shape and builder
+    base = {(r["config"], r["builder"]): r["bin_ms"] + r["build_ms"] for r in rows if r["distribution"] == "uniform"}
+    out = []
+    for r in rows:
+        d = {k: r[k] for k in keep}
+        if r["distribution"] != "uniform" and (r["config"], r["builder"]) in base:
+            d["bin_plus_build_over_uniform"] = round((r["bin_ms"] + r["build_ms"]) / base[(r["config"], r["builder"])], 3)
+        out.append(d)
+    shapes = ("gen1", "c2", "c3", "c2-dense", "c3-1M")
     return {"roofline_bound": "hbm", "peak_GBps": HBM_PEAK_GBPS,
-            "shapes": {k: dict(zip(("W", "H", "events_per_window", "batch"), bench_sweep.CONFIGS[k])) for k in ("gen1", "c2", "c3")},
-            "rows": [{k: r[k] for k in keep} for r in rows]}
+            "distributions": {"uniform": "x, y ~ U (SURVEY 8(d))",
+                              "circle": "ev-licious generate_fake_events restated (fake_events.py:5-29), scaled to the frame",
+                              "edges": "80 % of the events on 12 straight edges covering 5 % of the pixels"},
+            "shapes": {k: dict(zip(("W", "H", "events_per_window", "batch"), bench_sweep.CONFIGS[k])) for k in shapes},
+            "rows": out}
 
 
 def precompute_leg(device, samples=512, batch=8, events=200000):
@@ -366,6 +385,28 @@ def precompute_leg(device, samples=512, batch=8, events=200000):
             "gpu_only_us_per_sample": gpu_s * 1e6, "gpu_only_samples_per_s": 1.0 / gpu_s,
             "pinned_d2h_GBps": d2h, "pcie_gen5_x16_GBps": 63.0, "d2h_bound_samples_per_s": d2h * 1e9 / per,
             "bytes_per_sample_over_pcie": per}
+
+
+def achievable_rates(device, nbytes=1 << 30, iters=10):
+    """What this box's HBM delivers to the simplest kernels, measured in this process: a 1 GiB fill (write-only, the
+    builder's own traffic pattern) and a 1 GiB device-to-device copy (read + write counted).  The 8 TB/s of `peak` is the
+    HBM3E specification; `frac_of_achievable` prices the builder against the better of these two."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    out = {}
+    for name, fn, moved in (("fill", lambda: a.fill_(1.0), nbytes), ("copy", lambda: b.copy_(a), 2 * nbytes)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out["measured_%s_GBps" % name] = moved * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out["achievable_GBps"] = max(out["measured_fill_GBps"], out["measured_copy_GBps"])
+    del a, b
+    return out
 
 
 def self_launch(args):
@@ -419,6 +460,9 @@ def main():
     # --pipeline: two resident batches (different windows) alternate, as a stream of batches would, and the
     # binning pass of step k+1 overlaps the builder of step k on a second HIP stream (measured: ~5 % more
     # throughput, but the builder's own launch time is inflated by the sharing, so it is not the default)
+    # (r04) the timed loop rotates over `nbatch` DISTINCT resident batches: 12 x 25.6 MB of events (+ 12 workspaces) is more
+    # than the 256 MB Infinity Cache holds, so the read side of a step comes from HBM, as it does for a stream of batches
+    nbatch = 2 if args.pipeline else max(1, args.resident_batches)
     nbuf = 2 if args.pipeline else 1
     pipe = None
     if dry:
@@ -428,13 +472,15 @@ def main():
         from event_representation_study_amd.engine import BinBuildPipeline, EventBatch
         from event_representation_study_amd.synthetic import make_events
         batches, outs = [], []
-        for j in range(nbuf):
+        for j in range(nbatch):
             wins = [make_events(N, W, H, seed=rank * 100000 + j * B + i) for i in range(B)]  # seed = window index
             batches.append(EventBatch.from_numpy(wins, H, W, device=device))
             if args.pacing is not None:
                 import ctypes
                 from event_representation_study_amd._lib import check
                 check(batches[-1].lib.evrep_plan_set_pacing(ctypes.byref(batches[-1].plan), args.pacing), "evrep_plan_set_pacing")
+            if j >= nbuf:
+                continue            # one output tensor: it is written, never read, by the step
             if args.probe_placement > 1:
                 from event_representation_study_amd.engine import probe_output_placement
                 # timed with the library's store probe (the builder's write footprint, no builder launch: the k_mdes
@@ -465,8 +511,10 @@ def main():
             return fn
 
         def step(k, ev_pair=None):
-            batch = batches[k % nbuf]
+            batch = batches[k % nbatch]
             if pipe is None:
+                if ev_pair is not None:
+                    ev_pair[2].record()
                 batch.rebin()
                 build(k, ev_pair)(batch)
             else:
@@ -480,7 +528,7 @@ def main():
     # HIP events bracket the builder launch on every `ev_stride`-th timed step (each record is a marker packet in the
     # stream: bracketing every launch costs ~4 % of the step; every 4th still gives K/4 live samples inside the timed region)
     ev_stride = 4 if args.steps >= 8 else 1
-    pairs = None if dry else {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    pairs = None if dry else {k: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
                               for k in range(0, args.steps, ev_stride)}
     sync()
     if world > 1:
@@ -553,12 +601,21 @@ def main():
         result["dry_run"] = True      # launcher / rendezvous / collectives only: NOT a measurement
         result["value"] = 0.0
     else:
-        builder_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs.values()]))  # the k_mdes launch, HIP events on its stream
+        builder_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in pairs.values()]))  # the builder (main + hot launch), HIP events on its stream
+        bin_ms = float(np.mean([c.elapsed_time(a) for a, _, c in pairs.values()])) if pipe is None else None
         achieved = alg_bytes / (builder_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": "k_mdes<%s>" % ("double" if elem == 8 else "float"),
                               "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": builder_ms,
                               "algorithmic_bytes_per_launch": alg_bytes}
+        # per-kernel microseconds of the step, HIP events inside the timed region (every 4th step)
+        result["step_us"] = {"bin (k_block_keysort)": None if bin_ms is None else bin_ms * 1e3,
+                             "build (k_mdes main launch + hot launch)": builder_ms * 1e3,
+                             "resident_batches_rotated": nbatch,
+                             "resident_event_MB": nbatch * B * N * 16 / 1e6}
+        ach = achievable_rates(device)
+        result["roofline"].update(ach)
+        result["roofline"]["frac_of_achievable"] = achieved / ach["achievable_GBps"]
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
