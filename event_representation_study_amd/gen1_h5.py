@@ -6,6 +6,8 @@ to the window's first event).  Read with h5lite -- chunk-wise, Blosc included --
 recording.  ``windows(indices)`` hands (n, 4) int32 arrays to ``EventBatch.from_numpy`` / the precompute pipeline."""
 import numpy as np
 
+from .synthetic import int64_to_int32
+
 from . import h5lite
 
 
@@ -42,10 +44,12 @@ class Gen1H5Events:
         idx0 = max(0, idx1 - self.num_events)
         ev = self.h5["%s/events" % name]
         x, y, t, p = (np.asarray(ev[k][idx0:idx1]) for k in ("x", "y", "t", "p"))
+        if idx1 - idx0 <= 0:
+            raise IndexError("sample %d: no events before its label (the reference fails on xyt[0, -1], gen1_2yolo.py:196)" % idx)
         out = np.empty((idx1 - idx0, 4), dtype=np.int32)
-        out[:, 0], out[:, 1], out[:, 3] = x, y, p
-        if len(t):
-            out[:, 2] = (t.astype(np.int64) - int(t[0])).astype(np.int32)                       # xyt[:, -1] -= xyt[0, -1], :196
+        # range-checked narrowing: a corrupt container (or a window of more than 2^31 us) fails loudly instead of wrapping
+        out[:, 0], out[:, 1], out[:, 3] = (int64_to_int32(np.asarray(v).astype(np.int64), n) for v, n in ((x, "x"), (y, "y"), (p, "p")))
+        out[:, 2] = int64_to_int32(t.astype(np.int64) - int(t[0]), "t")                         # xyt[:, -1] -= xyt[0, -1], :196
         return out
 
     def windows(self, indices):

@@ -161,7 +161,7 @@ class Dataset:
                 # ev-licious' default (h5_writer.py:8-26).  The chunk is one Blosc 1 frame: decoded by blosc_lite (pinned against
                 # frames of the real libblosc; zstd / lz4 through the system's shared libraries)
                 from . import blosc_lite
-                raw = blosc_lite.decompress(raw)
+                raw = blosc_lite.decompress(raw, expected_nbytes=nbytes if k == 0 else None)   # (the first filter's output is the chunk)
             else:
                 raise NotImplementedError("HDF5 filter %d is not supported" % fid)
         return raw

@@ -34,9 +34,10 @@ followed by the reference's own image-space statements (count clipping, 5x5 pool
 rank of the discounted timestamps) as torch ops on the GPU.
 
 reshape_then_acc_sort (:513-838) is mirrored for strict=False (the "sorted timestamp image": latest time INDEX per
-pixel, from the same builder with the dense time rank as the per-event value); strict=True depends on
-torch_scatter's arg-max tie-breaking (absent package) and raises NotImplementedError, the denoise options raise
-the NameError they raise in the reference (density_filter_event_image is never defined there).
+pixel, from the same builder with the dense time rank as the per-event value) and for strict=True (followed by the dense
+rank of the per-pixel maxima; bit-exact on goldens that the generator checks not to depend on which of several tied events
+torch_scatter's arg-max names); the denoise options raise the NameError they raise in the reference
+(density_filter_event_image is never defined there).
 The EST quantisation layer is in est.py.
 The product path needs the HIP library and an MI355X; there is no CPU fallback.
 """

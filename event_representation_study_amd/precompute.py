@@ -49,7 +49,7 @@ class RepPrecomputer:
         self.nwriters = int(writers)
         self.container = container
         self.augment = bool(augment)
-        self._ring, self._ring_pos = {}, {}
+        self._ring, self._ring_lock = {}, threading.Lock()
         self.nloaders = int(loaders)
         self._in_ring, self._in_lock = [], threading.Lock()
 
@@ -90,34 +90,46 @@ class RepPrecomputer:
 
     # ------------------------------------------------------------------------------------------ host side
     def _pinned_parts(self, shapes):
-        """Pinned staging for ONE batch: a flat float32 buffer from a ring (page-locking a fresh 150 MB buffer per batch
+        """Pinned staging for ONE batch: a flat float32 buffer from a pool (page-locking a fresh 150 MB buffer per batch
         costs more than the copy), cut into one view per part -- so the parts of a batch never share storage, however
-        many there are (TORE hands one part per sample when the bounding-box frames differ).  The ring is deeper than
-        the writer queue + the writers, so a buffer is not handed out again while a writer may still read it."""
+        many there are (TORE hands one part per sample when the bounding-box frames differ).  A buffer is handed out again
+        only after the writer that drained it has RELEASED it (r04: the ring used to rely on writers finishing in FIFO
+        order -- a writer stalled on a slow file could have had its buffer overwritten); when every buffer is still in
+        use a new one is page-locked (the writer queue bounds how many can be: 4 queued + one per writer + one filling).
+        Returns (views, token); release with ``self._release(token)``."""
         sizes = [int(np.prod(sh)) for sh in shapes]
         total = max(sum(sizes), 1)
-        depth = 4 + self.nwriters + 2
-        ring = self._ring.setdefault("flat", [])
-        if len(ring) < depth:
-            ring.append(torch.empty(total, dtype=torch.float32, pin_memory=True))
-            flat = ring[-1]
-        else:
-            pos = self._ring_pos["flat"] = (self._ring_pos.get("flat", -1) + 1) % depth
-            if ring[pos].numel() < total:
-                ring[pos] = torch.empty(total, dtype=torch.float32, pin_memory=True)
-            flat = ring[pos]
+        with self._ring_lock:
+            pool = self._ring.setdefault("flat", [])
+            slot = next((sl for sl in pool if not sl["busy"] and sl["buf"].numel() >= total), None)
+            if slot is None:
+                slot = next((sl for sl in pool if not sl["busy"]), None)
+                if slot is not None:
+                    slot["buf"] = torch.empty(total, dtype=torch.float32, pin_memory=True)   # a larger batch than before
+            if slot is None:
+                slot = {"buf": torch.empty(total, dtype=torch.float32, pin_memory=True), "busy": False}
+                pool.append(slot)
+            slot["busy"] = True
+        flat = slot["buf"]
         views, o = [], 0
         for sh, n in zip(shapes, sizes):
             views.append(flat[o:o + n].view(sh))
             o += n
-        return views
+        return views, slot
+
+    def _release(self, slot):
+        with self._ring_lock:
+            slot["busy"] = False
 
     def reserve(self, shapes):
-        """Fill the pinned ring up front for batches of these part shapes (page-locking ~150 MB per buffer costs tens of
+        """Fill the pinned pool up front for batches of these part shapes (page-locking ~150 MB per buffer costs tens of
         milliseconds each: a short run would otherwise spend most of its time in it)."""
         depth = 4 + self.nwriters + 2
+        held = []
         while len(self._ring.get("flat", [])) < depth:
-            self._pinned_parts(shapes)
+            held.append(self._pinned_parts(shapes)[1])
+        for slot in held:
+            self._release(slot)
 
     def _write(self, path_base, arr):
         if self.container == "h5":
@@ -139,7 +151,7 @@ class RepPrecomputer:
                 item = q.get()
                 if item is None:
                     return
-                idx0, host, ev = item
+                idx0, host, ev, token = item
                 try:
                     ev.synchronize()                               # the D2H copy of this buffer has landed
                     for k in range(len(host)):
@@ -150,6 +162,8 @@ class RepPrecomputer:
                             os.remove(path)
                 except Exception as e:                             # surfaced by run(): a lost sample is not silent
                     errors.append(e)
+                finally:
+                    self._release(token)                           # only now may the pinned buffer be handed out again
 
         threads = [threading.Thread(target=writer, args=(i,), daemon=True) for i in range(self.nwriters)]
         for t in threads:
@@ -185,7 +199,7 @@ class RepPrecomputer:
                     batch = EventBatch(ev_dev, torch.from_numpy(offs), self.H, self.W, max_events_per_window=nmax)
                     small = self.represent_batch(batch)
                     parts = small if isinstance(small, list) else [small]
-                    hosts = self._pinned_parts([tuple(part.shape) for part in parts])
+                    hosts, token = self._pinned_parts([tuple(part.shape) for part in parts])
                     done = torch.cuda.Event()
                     self.copy_stream.wait_stream(main)
                     with torch.cuda.stream(self.copy_stream):
@@ -194,7 +208,7 @@ class RepPrecomputer:
                             part.record_stream(self.copy_stream)
                         done.record(self.copy_stream)
                     host_list = hosts[0] if not isinstance(small, list) else hosts
-                    q.put((count, host_list, done))
+                    q.put((count, host_list, done, token))
                     count += nwin
         finally:
             # whatever happened above (a loader raising, a GPU error, out of memory): the writers get their sentinels and

@@ -147,18 +147,26 @@ def test_precompute_parts_of_one_batch_never_share_pinned_storage(monkeypatch):
     real_empty = torch.empty
     monkeypatch.setattr(precompute.torch, "empty", lambda *a, pin_memory=False, **k: real_empty(*a, **k))
     pc = precompute.RepPrecomputer.__new__(precompute.RepPrecomputer)
-    pc.nwriters, pc._ring, pc._ring_pos = 4, {}, {}
-    shapes = [(37, 640, 12)] * 25 + [(640, 11, 12)] * 3          # more same-shape parts than the ring is deep
-    seen_flat = []
-    for _ in range(3 * (4 + pc.nwriters + 2)):                    # wraps the ring twice
-        views = pc._pinned_parts(shapes)
+    import threading
+    pc.nwriters, pc._ring, pc._ring_lock = 4, {}, threading.Lock()
+    shapes = [(37, 640, 12)] * 25 + [(640, 11, 12)] * 3          # more same-shape parts than a ring would be deep
+    held = []
+    for _ in range(12):
+        views, token = pc._pinned_parts(shapes)
         assert [tuple(v.shape) for v in views] == shapes
         spans = sorted((v.data_ptr(), v.data_ptr() + v.numel() * 4) for v in views)
         assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "parts of one batch overlap"
-        seen_flat.append(views[0].untyped_storage().data_ptr())
-    depth = 4 + pc.nwriters + 2
-    assert len(set(seen_flat[:depth])) == depth                  # consecutive batches get different buffers
-    assert seen_flat[depth:2 * depth] == seen_flat[2 * depth:3 * depth]   # ... recycled round-robin afterwards
+        held.append((views[0].untyped_storage().data_ptr(), token))
+    # a buffer is never handed out while its writer still holds it -- whatever order the writers finish in
+    assert len({p for p, _ in held}) == 12
+    pc._release(held[7][1])                                       # the EIGHTH writer finishes first
+    views, token = pc._pinned_parts(shapes)
+    assert views[0].untyped_storage().data_ptr() == held[7][0]    # its buffer, and only its buffer, is recycled
+    views2, token2 = pc._pinned_parts(shapes)
+    assert views2[0].untyped_storage().data_ptr() not in {p for p, _ in held}   # everything else is busy: a new one
+    for _, t in held:
+        pc._release(t)
+    assert len(pc._ring["flat"]) == 13
 
 
 def test_result_slot_is_free_only_when_nothing_outside_refers_to_it():

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from event_representation_study_amd import engine as eng
-from event_representation_study_amd.synthetic import make_events
+from event_representation_study_amd.synthetic import GENERATORS, make_events
 import oracle
 def builders(eb):
     out = {"ergo12": eb.optimized(), "ergo12_f32": eb.optimized(dtype=torch.float32), "es": eb.event_stack(),
@@ -29,7 +29,12 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
     wins = []
     for b in range(B):
         nn = max(2, int(dens * W * H * rng.uniform(0.3, 1.7)))
-        ev = make_events(nn, W, H, seed=seed * 7 + b, polarity="pm1" if rng.random() < 0.5 else "01", span_us=int(rng.choice([5, 2000, 50000])))
+        # r04: a third of the windows come from the clustered generators (hot / warm builder units: the moving circle of the
+        # reference's fake_events, the edge-cluster model), with hot densities
+        dist = str(rng.choice(["uniform", "uniform", "circle", "edges"]))
+        ev = GENERATORS[dist](nn, W, H, seed=seed * 7 + b, polarity="pm1" if rng.random() < 0.5 else "01", span_us=int(rng.choice([5, 2000, 50000])))
+        if rng.random() < 0.2:   # a hot UNIT: a fifth of the window in a 100-pixel stretch of one row
+            k = rng.integers(0, nn, size=nn // 5); ev[k, 0] = rng.integers(0, min(W, 100), size=len(k)) + int(rng.integers(0, max(1, W - 100))); ev[k, 1] = int(rng.integers(0, H))
         if rng.random() < 0.3:   # a hot pixel
             k = rng.integers(0, nn, size=nn // 3); ev[k, 0] = int(rng.integers(0, W)); ev[k, 1] = int(rng.integers(0, H))
         wins.append(ev)
