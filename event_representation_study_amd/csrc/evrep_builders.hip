@@ -987,6 +987,7 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
             if (part == 0) w.pace();
             tile_store(w.tile, np * C, dst + (size_t)part * PP * C);
         }
+        w.mark(5);
     } else {
         // dense chunk: one pass per part tile, each segment reduced in the pass of its own part.  The segment list is
         // pixel-ordered, so a part owns the contiguous range [sb, se) of it -- at most PP entries, one per lane,
@@ -1101,6 +1102,7 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     wave_phase();
     if (part == 0) w.pace();
     tile_store(w.tile, np * C, dst + (size_t)part * kWave * C);
+    w.mark(5);
 }
 
 // One pixel's C values straight from a lane's registers: 16 bytes at a time when the pixel is a whole number of 16-byte
@@ -1160,6 +1162,7 @@ __device__ inline void emit_warm(const UnitRecs &u, uint32_t nrec, Digest digest
         if (en > st) reduce(st, en, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
         if (lane < np) store_pixel<OutT, CMAX>(dst + ((size_t)p * kWave + lane) * C, vals, C, vec);
     }
+    w.mark(5);
 }
 
 // Main launch, key-sorted pass, one 64-pixel part of a unit beyond the hot stage (r04), out of the unit's spill slot
@@ -1268,6 +1271,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
             if (p == 0) w.pace();
             emit_part_main<OutT, CMAX, STAGE>(sorted + cs, st, en, p, digest, digest_fly, npix, C, dst, w, bg, reduce);
         }
+        w.mark(5);
         return;
     }
     if (lane < (int)nrec) evbuf[u.nseg >= 0 ? u.pos : lane] = digest(r0);   // grouped units: straight to the record's place

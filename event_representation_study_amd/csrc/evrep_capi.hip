@@ -377,7 +377,10 @@ static BinView bin_view(const evrep_plan *plan, const int32_t *events, void *wor
     bv.hot_sel = (plan->flags >> 30) & 1;
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
 #ifdef EVREP_TIMING
-    bv.dbg = bv.fused ? WS(unsigned long long, off_sorted2) : WS(unsigned long long, off_sorted1);   // 8 slots per builder wave in the stream that is idle
+    // 8 slots per builder wave: behind the 8-byte records of the key-sorted pass (the upper half of sorted1 is idle; sorted2 is
+    // the spill stream of the warm / hot units), in sorted1 under the classic passes
+    bv.dbg = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + plan->off_sorted1 +
+                                                    (bv.fused ? up256((size_t)plan->total_events * 8) : 0));
 #endif
     return bv;
 }

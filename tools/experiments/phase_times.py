@@ -13,18 +13,19 @@ import torch
 
 from event_representation_study_amd._lib import check
 from event_representation_study_amd.engine import EventBatch
-from event_representation_study_amd.synthetic import make_events
+from event_representation_study_amd.synthetic import GENERATORS
 
 H, W, N, B = 480, 640, 50000, 32
 if os.environ.get("SHAPE"):   # SHAPE=W,H,N,B: another workload (dense windows: 640,480,500000,8; marks 3/4 = first part tile)
     W, H, N, B = (int(v) for v in os.environ["SHAPE"].split(","))
-eb = EventBatch.from_numpy([make_events(N, W, H, seed=i) for i in range(B)], H, W)
+DIST = os.environ.get("DIST", "uniform")   # uniform | circle | edges (synthetic.GENERATORS)
+eb = EventBatch.from_numpy([GENERATORS[DIST](N, W, H, seed=i) for i in range(B)], H, W)
 eb.bin()
 outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
 holds = [int(v) for v in sys.argv[1:]] or [0, 600, 670]
 nunit = B * H * ((W + 127) // 128)
-assert nunit * 64 <= (eb.total + 1) * 16, "the idle record stream is too small for the marks"
-idle = eb.plan.off_sorted2 if eb.plan.reserved == 2 else eb.plan.off_sorted1   # the stream the builders do not read
+assert nunit * 64 <= (eb.total + 1) * 8, "the idle half of the record stream is too small for the marks"
+idle = eb.plan.off_sorted1 + (((eb.total * 8 + 255) // 256) * 256 if eb.plan.reserved == 2 else 0)   # see bin_view (EVREP_TIMING)
 dbg = eb.workspace[idle: idle + nunit * 64].view(torch.int64).view(nunit, 8)
 for o in outs:
     for h in holds:
@@ -42,4 +43,7 @@ for o in outs:
         d = dbg.cpu().numpy().astype(float) / 100.0
         import numpy as np
         ph = ["%d: %.2f/%.2f" % (i, d[:, i].mean(), np.percentile(d[:, i], 95)) for i in range(8)]
-        print("%x hold %4d  %.1f us/launch  phases mean/p95 (us) %s" % (o.data_ptr(), h, a.elapsed_time(b) * 100, "  ".join(ph)), flush=True)
+        life = d[:, 5][d[:, 5] > 0]      # mark 5 = the wave's last store is issued: its lifetime (hot items: of the item's wave)
+        print("%x %s hold %4d  %.1f us/launch  wave lifetime mean %.2f p95 %.2f p99 %.2f max %.2f us  phases mean/p95 (us) %s"
+              % (o.data_ptr(), DIST, h, a.elapsed_time(b) * 100, life.mean(), np.percentile(life, 95), np.percentile(life, 99), life.max(),
+                 "  ".join(ph)), flush=True)

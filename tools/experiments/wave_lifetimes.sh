@@ -1,3 +1,6 @@
+#!/bin/bash
+# Per-wave lifetimes of the ERGO-12 float64 builder (mean / p95 / p99 / max, microseconds) on uniform, moving-circle and
+# edge-cluster windows, from the EVREP_TIMING build (tools/variants/libevrep_timing.so: hipcc ... -DEVREP_TIMING).
 L=tools/variants/libevrep_timing.so
 for cfg in "640,480,50000,32 uniform" "640,480,50000,32 circle" "640,480,50000,32 edges" "304,240,50000,32 uniform" "304,240,50000,32 circle" "304,240,50000,32 edges"; do
   set -- $cfg
