@@ -1112,14 +1112,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     const uint32_t nhot = nhot_s;   // block-uniform (written before the barrier above)
     // arrival order -> time order inside every key group
     const uint32_t mine0 = (uint32_t)(w0 + lane);
-    uint32_t hs[PL];   // hot-group slot + 1 of the record's key, 0 = ordinary group (or not placed)
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
-        hs[i] = 0u;
         if (ko[i] != 0xffffffffu) {
-            const uint32_t bw = base[ko[i] & 0xffffu];
-            hs[i] = bw >> 16;
-            if (!hs[i]) rankbuf[(bw & 0xffffu) + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
+            const uint32_t bw = base[ko[i] & 0xffffu];   // upper half: hot-group slot + 1, 0 = an ordinary group
+            if (!(bw >> 16)) rankbuf[(bw & 0xffffu) + (ko[i] >> 16)] = (uint16_t)(mine0 + i * kWave);
         }
     }
     // Hot groups (r04).  The repair below reads g ranks per member of a g-record group -- fine for the 2-4 records a key holds
@@ -1136,7 +1133,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         wave_phase_lds();
 #pragma unroll
         for (int i = 0; i < PL; ++i)
-            if (hs[i]) atomicAdd(&hcnt[wave * kHs + hs[i] - 1u], 1u);
+            if (ko[i] != 0xffffffffu) {
+                const uint32_t hsl = base[ko[i] & 0xffffu] >> 16;
+                if (hsl) atomicAdd(&hcnt[wave * kHs + hsl - 1u], 1u);
+            }
         __syncthreads();
         if (threadIdx.x < nhot) {
             uint32_t acc = 0;
@@ -1147,15 +1147,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         volatile uint32_t *vh = hcnt + wave * kHs;
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
-            const bool hot = hs[i] != 0u;
+            const uint32_t bw = ko[i] != 0xffffffffu ? base[ko[i] & 0xffffu] : 0u;
+            const bool hot = (bw >> 16) != 0u;
             if (!__any(hot)) continue;
-            const uint32_t slot = hot ? hs[i] - 1u : 0u;
+            const uint32_t slot = hot ? (bw >> 16) - 1u : 0u;
             uint32_t rk; bool last;
             wave_match(slot, hbits, hot, lane, rk, last);
             uint32_t pos = 0;
             if (hot) {
                 pos = vh[slot] + rk;
-                ko[i] = (base[ko[i] & 0xffffu] & 0xffffu) + pos;
+                ko[i] = ((bw & 0xffffu) + pos) | 0x80000000u;   // final place; bit 31 marks it for the repair below (cleared there)
             }
             __builtin_amdgcn_wave_barrier();
             if (hot && last) vh[slot] = pos + 1;
@@ -1171,10 +1172,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             gb[i] = 0; g[i] = 0; sm[i] = 0;
-            if (ko[i] != 0xffffffffu && !hs[i]) {
+            if (ko[i] != 0xffffffffu && !(ko[i] >> 31)) {
                 const uint32_t key = ko[i] & 0xffffu;
-                gb[i] = base[key] & 0xffffu;
-                g[i] = (base[key + 1] & 0xffffu) - gb[i];
+                const uint32_t bw = base[key];
+                gb[i] = bw & 0xffffu;
+                g[i] = (bw >> 16) ? 0u : (base[key + 1] & 0xffffu) - gb[i];   // (a hot group without hot placement cannot occur: nhot counts them all)
                 if (KS_DEBUG & 1) { sm[i] = ko[i] >> 16; g[i] = 0; }
                 if (g[i] == 1) g[i] = 0;  // alone in its group
                 gmax = max(gmax, g[i]);
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         }
 #pragma unroll
         for (int i = 0; i < PL; ++i)
-            if (ko[i] != 0xffffffffu && !hs[i]) ko[i] = gb[i] + sm[i];
+            if (ko[i] != 0xffffffffu) ko[i] = (ko[i] >> 31) ? (ko[i] & 0x7fffffffu) : gb[i] + sm[i];
     }
     if (nhot) __syncthreads();   // the hot-group counters live in the stage: every wave has read its own before the write-out
     Rec8 *dst = reinterpret_cast<Rec8 *>(sorted1) + beg + lo;   // the block's own slot, 8 bytes per record

@@ -573,30 +573,76 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     // the unit + lane, a handful of scalar instructions per batch where finding the run of record j of the unit takes a
     // 3-instruction step per run (a 6-step LDS search in windows of more than 16 runs) per record.  kSpillBatch batches are
     // in flight together; runs are visited in block order and a run is time-ordered, so the sweep order is the time order.
+    // ... when the runs are long enough to fill batches (a hot unit of a sparse window: a dozen runs of 30-250 records).  A
+    // unit whose runs hold a handful of records each (a window of 250 000 events: 31 runs of 4) would load a mostly empty
+    // batch per run: there a batch is 64 consecutive records of the UNIT and every lane finds its record's run itself (the
+    // readlane chain / LDS search of r03).
+    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
     const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;   // lane k: the unit's first record in run k
-    int rk_ = 0;            // the sweep cursor: run, offset inside the run (wave-uniform)
+    uint32_t *runs2 = cnt + npixu;   // (behind the pixel counters: a main launch places a warm unit over the record stage)
+    if (!by_run && nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
+    wave_phase();
+    auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
+        if (nb <= kBsChainBlocks) {
+            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t prev = sx;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                sx += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return sx + j;
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && runs2[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return runs2[64 + lo] + j;
+    };
+    int rk_ = 0;            // the sweep cursor: run, offset inside the run (by run) / record of the unit (wave-uniform)
     uint32_t ro_ = 0;
     uint32_t addr[kSpillBatch], bcnt[kSpillBatch];
     Rec8 q[kSpillBatch];
     auto sweep_begin = [&]() { rk_ = 0; ro_ = 0; };
-    auto load_batch = [&]() -> bool {   // fills addr / bcnt / q; false: the sweep is over (nothing was filled)
+    auto skip_empty = [&]() {   // by run: the cursor moves to the next record there is
+        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+        return lk;
+    };
+    auto sweep_done = [&]() -> bool { if (by_run) { skip_empty(); return rk_ >= nb; } return ro_ >= nrec; };
+    auto load_batch = [&]() -> bool {   // fills bcnt / q; false: the sweep is over (nothing was filled)
         bool any = false;
+        if (by_run) {
 #pragma unroll
-        for (int sl = 0; sl < kSpillBatch; ++sl) {
-            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-            bcnt[sl] = 0u; addr[sl] = 0u;
-            if (rk_ < nb) {
-                addr[sl] = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_;
-                bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
-                ro_ += kWave;
-                any = true;
+            for (int sl = 0; sl < kSpillBatch; ++sl) {
+                const uint32_t lk = skip_empty();
+                bcnt[sl] = 0u; addr[sl] = 0u;
+                if (rk_ < nb) {
+                    addr[sl] = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_;
+                    bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                    ro_ += kWave;
+                    any = true;
+                }
             }
-        }
 #pragma unroll
-        for (int sl = 0; sl < kSpillBatch; ++sl) {
-            q[sl] = make_uint2(0u, 0u);
-            if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr[sl] + (uint32_t)lane];
+            for (int sl = 0; sl < kSpillBatch; ++sl) {
+                q[sl] = make_uint2(0u, 0u);
+                if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr[sl] + (uint32_t)lane];
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < kSpillBatch; ++sl) {
+                const uint32_t j0 = ro_ + (uint32_t)(sl * kWave);
+                bcnt[sl] = j0 < nrec ? min(nrec - j0, (uint32_t)kWave) : 0u;
+                q[sl] = make_uint2(0u, 0u);
+                if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[src_of(j0 + (uint32_t)lane)];
+            }
+            any = ro_ < nrec;
+            ro_ += (uint32_t)(kSpillBatch * kWave);
         }
         return any;
     };
@@ -608,9 +654,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         for (int sl = 0; sl < kSpillBatch; ++sl)
             if ((uint32_t)lane < bcnt[sl]) atomicAdd(&cnt[px_of(q[sl])], 1u);
         // the whole unit in ONE round: the placement below finds it still in the registers
-        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-        if (rk_ >= nb) { resident = round == 0; break; }
+        if (sweep_done()) { resident = round == 0; break; }
     }
     wave_phase();
     {
@@ -2313,7 +2357,7 @@ __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restr
 // --------------------------------------------------------------------------------------------
 // Placement probe: the write footprint of the float64 12-channel builder (one wave per 12 KiB tile, XCD-contiguous
 // eighths, non-temporal 16-byte stores, 19 waves per CU) with nothing else.  On MI355X the time of this kernel into a
-// 0.9 GB tensor takes one of three levels depending on where the tensor lies physically (DESIGN.md 8,
+// 0.9 GB tensor takes one of three levels depending on where the tensor lies physically (NOTES.md 8,
 // tools/microbench/placement_patterns.hip); engine.probe_output_placement times it into candidate allocations.
 // grid (tiles), 64 threads, dynamic LDS 8320 B.  Writes zeros.
 // --------------------------------------------------------------------------------------------

@@ -418,7 +418,7 @@ static UnitCfg hot_cfg(UnitCfg uc) { uc.stage = kHotStage; uc.hold = 0; return u
 // Automatic store pacing (plan->pacing == -1) of a builder instance whose launch is bound by its HBM writes on sparse
 // windows.  The waves resident on a CU offer U x unit_bytes every wave lifetime; on most placements of a ~1 GB output tensor
 // MI355X serves ~5.7 TB/s when that offer exceeds ~7 TB/s (19 waves x 12 KiB ready after ~7 us: 8.5 TB/s), and
-// 6.4-6.9 TB/s when it stays just below (tools/experiments/pacing.py: the float64 12-channel builder takes
+// 6.4-6.9 TB/s when it stays just below (NOTES.md 3.2, tools/experiments/pacing.py: the float64 12-channel builder takes
 // 168 us unpaced, 148 us held at 7.0 us, 155 us held at 7.5 us -- a cliff on the short side, a slope on the long side, so
 // the hold sits 2 % beyond the knee).  The hold scales with the bytes the CU's resident waves own.
 static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_bytes, int span, size_t pixel_bytes) {

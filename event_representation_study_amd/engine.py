@@ -399,7 +399,7 @@ class BinBuildPipeline:
 
 def probe_output_placement(shape, dtype, launch=None, candidates=8, launches=10, device="cuda:0", keep_first=False,
                            good_GBps=None, max_candidates=None):
-    """Where a large output tensor lies in HBM decides up to 25 % of a builder launch on MI355X (the same
+    """Where a large output tensor lies in HBM decides up to 25 % of a builder launch on MI355X (NOTES.md 8: the same
     launch takes 134, 148 or 172 us into different 900 MiB allocations of one process; a linear fill does not care).
     A producer that allocates its output ring once can pick its allocations: this helper allocates `candidates` tensors,
     times a writer into each and returns (best tensor, its us per launch, all timings); the other tensors are released.

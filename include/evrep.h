@@ -82,7 +82,7 @@ typedef struct evrep_plan {
 #define EVREP_PLAN_FORCE_KEY_SORTED 4u  /* pass 2 also for windows denser than it is chosen for */
 #define EVREP_PLAN_BIG_BLOCKS 8u        /* key-sorted pass: 8192-event blocks also for short windows */
 #define EVREP_PLAN_NO_FUSED_SCATTER 16u /* three-kernel pass: separate scan and scatter kernels */
-#define EVREP_PLAN_X_SPAN2 64u          /* experiment: float64 MDES units of two 128-pixel chunks */
+#define EVREP_PLAN_X_SPAN2 64u          /* experiment: float64 MDES units of two 128-pixel chunks (NOTES.md 8) */
 
 int evrep_abi_version(void);
 const char *evrep_last_hip_error(void);
@@ -95,7 +95,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
  * the Python binding translates EVREP_BIN_CLASSIC / EVREP_BIN_THREE_KERNEL / EVREP_BIN_KEY_SORTED / ... into flags. */
 int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
                        int64_t max_events_per_window, uint32_t flags);
-/* Store pacing of the builders whose launch is bound by HBM writes: ticks = -1 automatic (what
+/* Store pacing of the builders whose launch is bound by HBM writes (NOTES.md 3.2 "Store pacing"): ticks = -1 automatic (what
  * evrep_plan_init sets), 0 off, > 0 explicit hold in 10 ns ticks.  Results never depend on it. */
 int evrep_plan_set_pacing(evrep_plan *plan, int32_t ticks);
 size_t evrep_workspace_bytes(const evrep_plan *plan);
@@ -249,7 +249,7 @@ int evrep_read_bbox(const evrep_plan *plan, const void *workspace, int32_t *bbox
 
 /* Placement probe (no reference counterpart): writes zeros over `bytes` of `out` with the write footprint of the float64
  * 12-channel builder and nothing else.  On MI355X the physical placement of a ~1 GB output tensor decides up to 25 % of a
- * builder launch; a producer that allocates its output ring once can time this call into a few
+ * builder launch (NOTES.md section 8); a producer that allocates its output ring once can time this call into a few
  * candidate allocations and keep the fastest (engine.probe_output_placement does).  out DEVICE, 16-byte aligned. */
 int evrep_probe_store(void *out, size_t bytes, void *stream);
 

@@ -228,7 +228,7 @@ def test_rebinning_is_idempotent_and_deterministic(monkeypatch):
 
 
 def test_placement_probe_writes_zeros_and_returns_a_candidate():
-    """evrep_probe_store (the builder's write footprint, DESIGN.md 8) zero-fills whole 12 KiB tiles of the tensor;
+    """evrep_probe_store (the builder's write footprint, NOTES.md 8) zero-fills whole 12 KiB tiles of the tensor;
     probe_output_placement returns one of its candidates with one timing per candidate."""
     from event_representation_study_amd import engine as eng
     best, us, all_us = eng.probe_output_placement((4, 48, 64, 12), torch.float64, candidates=3, launches=2)

@@ -2,7 +2,7 @@
 // most 65 536 events (the reference's default window is 50 000, gen1_2yolo.py:41).  Bit-exact on the whole
 // GPU suite when wired in behind evrep_bin_events, but not faster than the three-kernel pass in r01
 // (57.8 vs 59.3 us at 32 x 50 000 events with 1024 threads; phases: stream 17 + statistics 10 + two radix passes 15
-// + write-out 16 us, all latency-bound at one 138 KB-LDS block per CU), so it is parked here; see DESIGN.md 8.
+// + write-out 16 us, all latency-bound at one 138 KB-LDS block per CU), so it is parked here; see NOTES.md 8.
 //
 // The three-kernel pass (evrep_bin.hip) cuts a window's EVENTS into blocks and therefore needs a
 // histogram kernel, a scan and a scatter before any block knows where its events go.  Here a
@@ -14,7 +14,7 @@
 // the start of its run is the number of in-frame events in lower rows, which it counts while
 // streaming.  Window statistics (WindowMeta) come from band 0, which sees every event anyway.
 // One launch, no inter-block dependency; ~half the time of the three-kernel pass at the headline
-// configuration.
+// configuration (see NOTES.md 3.1).
 //
 // Overflow (a clustered window putting more events into one band or one wave's slice than the LDS
 // lists hold): the block redoes the pass with the same code on global scratch (its own slots of
