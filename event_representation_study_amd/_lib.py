@@ -57,6 +57,7 @@ SYMBOLS = {
     "evrep_optimized": (ctypes.c_int, [_PP, _vp, _vp, _vp, _f64, _i32, _vp, _vp]),
     "evrep_event_stack": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp]),
     "evrep_time_surface": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _vp, _f64, _i32, _f64, _i32, _vp, _vp]),
+    "evrep_time_surface_ftime": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _vp, _vp, _f64, _i32, _f64, _i32, _vp, _vp]),
     "evrep_tore": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _vp, _vp]),
     "evrep_tore_ftime": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     "evrep_voxel": (ctypes.c_int, [_PP, _vp, _vp, _vp, _i32, _i32, _f64, _vp, _vp]),

@@ -1717,14 +1717,15 @@ struct TsCuts {
     int32_t pad[6];
     double bg[2 * kMaxSlices];  // value of an untouched (pixel, polarity) entry of slice s, already scaled
     double fac[kMaxSlices];    // exp((tref - tcut[s]) / tau) * scale
-    double pad2[8];
+    double tcutf[kMaxSlices];  // the cut's timestamp as float64: t[idx[s]], or tf[idx[s]] (float timestamps, evrep_time_surface_ftime)
 };
 static_assert(sizeof(TsCuts) == 384, "TsCuts");
 
 // grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
 // int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
 __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
-                          const int32_t *__restrict__ indices, double tau, double scale, TsCuts *__restrict__ cuts) {
+                          const int32_t *__restrict__ indices, double tau, double scale, TsCuts *__restrict__ cuts,
+                          const double *__restrict__ tf) {
     const int b = blockIdx.x, s = threadIdx.x;
     __shared__ int sidx[kMaxSlices];
     const int64_t beg = off[b];
@@ -1753,6 +1754,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
         sidx[s] = idx;
         cuts[b].idx[s] = idx;
         cuts[b].tcut[s] = tc;
+        cuts[b].tcutf[s] = (tf && n > 0 && idx >= 0 && idx < n) ? tf[beg + idx] : (double)tc;
     }
     __syncthreads();
     if (s == 0) {
@@ -1771,7 +1773,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
             // untouched pixels are not zero: exp((-(3 tau + 1) - t_i) / tau)  (time_surface.py:26-29,68-72);
             // slices the scan never reaches stay exactly 0
             double v = 0.0;
-            if (k < S && alive) v = exp_neg_range((-(tau * 3.0 + 1.0) - (double)cuts[b].tcut[k]) * (1.0 / tau)) * scale;
+            if (k < S && alive) v = exp_neg_range((-(tau * 3.0 + 1.0) - cuts[b].tcutf[k]) * (1.0 / tau)) * scale;
             cuts[b].bg[2 * k] = v;
             cuts[b].bg[2 * k + 1] = v;
         }
@@ -1790,7 +1792,7 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
             cuts[b].fac[k] = f;
         }
         cuts[b].tref = tref;
-        cuts[b].direct = direct;
+        cuts[b].direct = tf ? 1 : direct;   // float timestamps: exponentials per slice
     }
 }
 
@@ -1799,7 +1801,8 @@ __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict
 template <typename OutT, int CM, bool FACT, bool HOT = false>
 __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
-                                                       int S, double tau, int premap, double scale, OutT *__restrict__ out) {
+                                                       int S, double tau, int premap, double scale, const double *__restrict__ tf,
+                                                       OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         const int C = 2 * S;
@@ -1825,7 +1828,8 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
         // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
         // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
         const int tref = cp->tref;
-        const bool fact = FACT && !(premap & 2) && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
+        const double *tw = tf ? tf + off[unit_geom(H, W, nchunk, uc.span, chunk0, uid).b] : nullptr;   // float timestamps, by rank
+        const bool fact = FACT && !tf && !(premap & 2) && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
         double fac[(CM / 2)];
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) fac[q] = cp->fac[q];
@@ -1849,7 +1853,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
             uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
             for (uint32_t j = jb; j <= je; ++j) {
                 int rank = INT32_MAX, t = 0, p = 0;
-                if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : e.z; p = e.w; }
+                if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : (tw ? e.y : e.z); p = e.w; }   // float timestamps: the memory holds the event's RANK
 #pragma unroll
                 for (int q = 0; q < (CM / 2); ++q) {
                     if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
@@ -1868,13 +1872,17 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
                         if (snap0[q] != INT32_MIN) { const Rec e = get((uint32_t)snap0[q]); v0 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
                         if (snap1[q] != INT32_MIN) { const Rec e = get((uint32_t)snap1[q]); v1 = (OutT)(__hiloint2double(e.z, e.x) * fac[q]); }
                     } else {     // one straight-line batch of exponentials, the same for every lane of the wave
-                        const double tc = (double)cu.tcut[q];
+                        const double tc = tw ? gload_f64(&cp->tcutf[q]) : (double)cu.tcut[q];
                         if (__any(snap0[q] != INT32_MIN)) {
-                            const double e0 = exp_neg_range(((double)snap0[q] - tc) * inv_tau) * scale;
+                            double m0 = (double)snap0[q];
+                            if (tw) m0 = snap0[q] != INT32_MIN ? gload_f64(tw + snap0[q]) : 0.0;   // the caller's float64 time of that event
+                            const double e0 = exp_neg_range((m0 - tc) * inv_tau) * scale;
                             if (snap0[q] != INT32_MIN) v0 = (OutT)e0;
                         }
                         if (__any(snap1[q] != INT32_MIN)) {
-                            const double e1 = exp_neg_range(((double)snap1[q] - tc) * inv_tau) * scale;
+                            double m1 = (double)snap1[q];
+                            if (tw) m1 = snap1[q] != INT32_MIN ? gload_f64(tw + snap1[q]) : 0.0;
+                            const double e1 = exp_neg_range((m1 - tc) * inv_tau) * scale;
                             if (snap1[q] != INT32_MIN) v1 = (OutT)e1;
                         }
                     }

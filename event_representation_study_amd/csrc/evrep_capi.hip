@@ -533,13 +533,20 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
 int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                        int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
                        int32_t out_dtype, void *out, void *stream_) {
+    return evrep_time_surface_ftime(plan, events, offsets, workspace, slices, indices, nullptr, tau, premap, scale, out_dtype, out, stream_);
+}
+
+int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                             int32_t slices, const int32_t *indices, const double *tf, double tau, int32_t premap, double scale,
+                             int32_t out_dtype, void *out, void *stream_) {
     int rc = check_common(plan, events, offsets, workspace);
     if (rc) return rc;
+    if (tf && !indices) return EVREP_EINVAL;   // the dispatcher's cut search is defined on its integer timestamps
     if (slices <= 0 || slices > kMaxSlices || !out || !(tau > 0.0)) return EVREP_EINVAL;
     if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TsCuts *cuts = WS(TsCuts, off_cuts);
-    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts);
+    k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts, tf);
     LAUNCH_CHECK("k_ts_cuts");
     // windows whose units are practically all fully staged (<= 128 records: everything the key-sorted pass is chosen for, r03;
     // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
@@ -549,7 +556,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20, 0, false, false);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
     k_time_surface<T, CM, F><<<GRID, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, uc.stage), stream>>>(            \
-        bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale,       \
+        bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale, tf,   \
         static_cast<T *>(out))
     // the hot launch always takes its exponentials per slice: a unit beyond the stage does so under every binning pass
 #define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
@@ -557,7 +564,7 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
         if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG);                  \
         k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
             bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, hot_cfg(uc), slices, tau, premap,  \
-            scale, static_cast<T *>(out));                                                                           \
+            scale, tf, static_cast<T *>(out));                                                                           \
     } while (0)
         if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
     } else {

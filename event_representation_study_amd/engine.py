@@ -201,7 +201,7 @@ class EventBatch:
         t = t.to(self.device)
         return t, _ptr(t)
 
-    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None, indices=None):
+    def time_surface(self, slices=6, tau=50000.0, premap=True, scale=1.0, dtype=torch.float64, out=None, indices=None, times_f64=None):
         """ToTimesurface for every window -> (B, H, W, 2*slices), channel c = 2*s + p.  indices=None: the
         dispatcher's cuts searchsorted(t_norm, 1..slices); else explicit event indices per window.
         premap: True / 1 = p -> int8((p+1)/2) first; + 2 = timestamps not ascending (array-order scan, per-slice exponentials;
@@ -209,8 +209,16 @@ class EventBatch:
         self.bin()
         out = self._out(out, 2 * slices, dtype)
         keep, iptr = self._i32_dev(indices, slices)
+        fptr = ctypes.c_void_p(None)
+        if times_f64 is not None:      # float64 timestamps, one per event (the events' own t column then only orders them)
+            if times_f64.dtype != torch.float64 or times_f64.device != self.device or times_f64.numel() != self.total \
+                    or not times_f64.is_contiguous():
+                raise ValueError("times_f64 must be a contiguous float64 tensor with one entry per event on %s" % self.device)
+            if indices is None:
+                raise ValueError("times_f64 needs explicit indices")
+            fptr = _ptr(times_f64)
         with torch.cuda.device(self.device):
-            check(self.lib.evrep_time_surface(*self._args(), int(slices), iptr, float(tau), int(premap),
+            check(self.lib.evrep_time_surface_ftime(*self._args(), int(slices), iptr, fptr, float(tau), int(premap),
                                               float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
                   "evrep_time_surface")
         return out

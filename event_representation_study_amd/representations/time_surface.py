@@ -3,6 +3,7 @@ from dataclasses import dataclass
 from typing import Tuple, Union
 
 import numpy as np
+import torch
 
 from ._common import events_from_fields, raise_for_status
 from ..engine import EventBatch
@@ -26,8 +27,19 @@ class ToTimesurface:
         out = np.zeros((len(indices), self.sensor_size[2], H, W))
         if len(indices) == 0:
             return out
-        ev = events_from_fields(events["x"], events["y"], events["t"], events["p"])
+        # timestamps of any dtype (time_surface.py:66-74 only stores and subtracts them): integral ones ride in the int32 event
+        # rows, others as a float64 array of their own (r04) -- the rows' t column then only carries the order
+        t = np.asarray(events["t"])
+        tf = None
+        if t.dtype.kind == "f" and len(t) and not np.all(t == np.rint(t)):
+            if not np.all(np.isfinite(t)):
+                raise OverflowError("non-finite timestamps")
+            tf = np.ascontiguousarray(t, dtype=np.float64)
+            asc = bool(np.all(tf[1:] >= tf[:-1]))
+            t = np.arange(len(tf)) if asc else -np.arange(len(tf))     # order marker: the status word reports "not ascending"
+        ev = events_from_fields(events["x"], events["y"], t, events["p"])
         batch = EventBatch.from_numpy(ev, H, W)
+        tf_dev = None if tf is None else torch.from_numpy(tf).to(batch.device)
         # the scan of time_surface.py:66-74 runs in array order: timestamps that are not ascending only forbid the factorised
         # exponentials (premap bit 1)
         unsorted = bool(raise_for_status(batch, what="ToTimesurface", allow_unsorted=True) & 4)
@@ -40,7 +52,7 @@ class ToTimesurface:
             live, prev = live + 1, i
         for s0 in range(0, live, 8):                                  # up to 8 surfaces per launch
             chunk = indices[s0:min(s0 + 8, live)]
-            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=2 if unsorted else 0, indices=chunk)
+            rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=2 if unsorted else 0, indices=chunk, times_f64=tf_dev)
             rep = rep[0].cpu().numpy().reshape(H, W, len(chunk), 2)    # channel c = 2*s + p
             out[s0:s0 + len(chunk)] = rep.transpose(2, 3, 0, 1)
         return out

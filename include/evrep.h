@@ -153,6 +153,13 @@ int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int6
                        int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
                        int32_t out_dtype, void *out, void *stream);
 
+/* The same with float64 timestamps (time_surface.py:66-74 is dtype-agnostic): tf DEVICE double [total_events], one time per
+ * event, indexed like `events` (whose own t column then only orders them); `indices` must be given.  tf == NULL:
+ * evrep_time_surface. */
+int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                             int32_t slices, const int32_t *indices, const double *tf, double tau, int32_t premap,
+                             double scale, int32_t out_dtype, void *out, void *stream);
+
 /* events2ToreFeature (tore.py:6-83) for one sample time per window, k <= 8.
  * sample_times == NULL: T = t[-1] (gen1_transforms.py:63); otherwise DEVICE int32 [B].
  * frame_mode 0: the events' bounding box, origin-shifted (gen1_transforms.py:61-64); the window's

@@ -4,7 +4,9 @@
     (gen1_transforms.get_item_transform) -- EventStack (the past half t <= t[-1], array order: event_stack.py:23,125) and
     ToTimesurface (array-order scan, time_surface.py:66-74, cuts from numpy's searchsorted on the unsorted t_norm);
   * compute_repr_float_t_64x48: compute_repr(x, y, t, p, W, H, bins) with the CALLER's own float64 t in [0, 1]
-    (gromov_wasserstein.py:72-82), unsorted, bins 5 and 9.
+    (gromov_wasserstein.py:72-82), unsorted, bins 5 and 9;
+  * time_surface_float_t_40x30: ToTimesurface.__call__(events, indices) with non-integral float64 timestamps (seconds),
+    ascending and not (time_surface.py:25-74).
 Run from anywhere:  python tests/golden/make_golden_r04.py"""
 import os
 import sys
@@ -52,5 +54,32 @@ def main():
     print("compute_repr", out["voxel5"].shape, float(out["voxel5"].sum()))
 
 
+def float_time_surface():
+    """ToTimesurface.__call__(events, indices) with NON-INTEGRAL float64 timestamps (seconds), ascending and not: the
+    reference's own class (numba stubbed to the identity, as in make_golden.py)."""
+    cwd = os.getcwd()
+    ref = make_golden._import_reference()
+    os.chdir(cwd)
+    W, H, N = 40, 30, 2500
+    ev = make_events(N, W, H, seed=411, polarity="01")
+    rng = np.random.default_rng(411)
+    out = {"W": W, "H": H, "x": ev[:, 0], "y": ev[:, 1], "p": ev[:, 3]}
+    for tag in ("asc", "unsorted"):
+        t = np.sort(rng.random(N) * 0.05)                 # seconds, non-integral
+        if tag == "unsorted":
+            k = rng.random(N) < 0.3
+            t[k] = rng.random(int(k.sum())) * 0.05
+        rec = np.zeros(N, dtype=[("x", "<i8"), ("y", "<i8"), ("t", "<f8"), ("p", "<i8")])
+        rec["x"], rec["y"], rec["t"], rec["p"] = ev[:, 0], ev[:, 1], t, ev[:, 3]
+        idx = np.array([300, 1100, 1101, 2499])
+        tr = ref["ToTimesurface"](sensor_size=(W, H, 2), surface_dimensions=None, tau=0.01, decay="exp")
+        out["t_" + tag] = t
+        out["idx"] = idx
+        out["surf_" + tag] = tr(rec, idx)
+    np.savez_compressed(os.path.join(HERE, "time_surface_float_t_40x30.npz"), **out)
+    print("float time surface", out["surf_asc"].shape)
+
+
 if __name__ == "__main__":
     main()
+    float_time_surface()

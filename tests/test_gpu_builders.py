@@ -248,3 +248,19 @@ def test_mdes_arbitrary_polarity_values(eng, oracle):
             ["sum", "variance", "sum", "mean", "mean"])
     got = eng.EventBatch.from_numpy(ev, H, W).mdes(*trip)[0].cpu().numpy()
     assert_bit_equal(got, oracle.mdes(ev, H, W, *trip))
+
+
+def test_to_timesurface_with_float_timestamps():
+    """ToTimesurface.__call__ with NON-INTEGRAL float64 timestamps (seconds; time_surface.py:66-74 is dtype-agnostic), ascending
+    and not, against the reference's own class (tests/golden/make_golden_r04.py)."""
+    from event_representation_study_amd.representations.time_surface import ToTimesurface
+    g = load_golden("time_surface_float_t_40x30")
+    W, H = int(g["W"]), int(g["H"])
+    for tag in ("asc", "unsorted"):
+        rec = np.zeros(len(g["x"]), dtype=[("x", "<i8"), ("y", "<i8"), ("t", "<f8"), ("p", "<i8")])
+        rec["x"], rec["y"], rec["t"], rec["p"] = g["x"], g["y"], g["t_" + tag], g["p"]
+        got = ToTimesurface(sensor_size=(W, H, 2), surface_dimensions=None, tau=0.01, decay="exp")(rec, g["idx"])
+        want = g["surf_" + tag]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=0)      # budget 1e-5 (x * (1/tau) instead of x / tau: ~1e-14 here)
+        assert np.array_equal(got == 0, want == 0)
