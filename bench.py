@@ -65,7 +65,7 @@ def parse():
                     help="skip the entropic Gromov-Wasserstein leg (extension, SURVEY 8 F5; ~1 s)")
     ap.add_argument("--probe-placement", type=int, default=0, metavar="N",
                     help="0 (default, r03): the output tensor is the FIRST allocation, as any caller gets it -- the builder paces its "
-                         "stores (NOTES.md 3.2 "Store pacing"), so its launch no longer depends on where the tensor lies.  N > 1 (r02's default was "
+                         "stores (NOTES.md 3.2, Store pacing), so its launch no longer depends on where the tensor lies.  N > 1 (r02's default was "
                          "16): before the warm-up, allocate N candidate output tensors and keep the one the store probe runs fastest "
                          "into; the candidates' timings are printed in config.output_placement_probe.")
     ap.add_argument("--pacing", type=int, default=None, metavar="TICKS",

@@ -95,7 +95,7 @@ int evrep_plan_init(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t t
  * the Python binding translates EVREP_BIN_CLASSIC / EVREP_BIN_THREE_KERNEL / EVREP_BIN_KEY_SORTED / ... into flags. */
 int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_t total_events,
                        int64_t max_events_per_window, uint32_t flags);
-/* Store pacing of the builders whose launch is bound by HBM writes (NOTES.md 3.2 "Store pacing"): ticks = -1 automatic (what
+/* Store pacing of the builders whose launch is bound by HBM writes (NOTES.md 3.2, Store pacing): ticks = -1 automatic (what
  * evrep_plan_init sets), 0 off, > 0 explicit hold in 10 ns ticks.  Results never depend on it. */
 int evrep_plan_set_pacing(evrep_plan *plan, int32_t ticks);
 size_t evrep_workspace_bytes(const evrep_plan *plan);

@@ -1,4 +1,4 @@
-"""Store pacing of the builders (NOTES.md 3.2 "Store pacing"): the same launch into several ~1 GB output tensors alive at once, for a list of
+"""Store pacing of the builders (NOTES.md 3.2, Store pacing): the same launch into several ~1 GB output tensors alive at once, for a list of
 hold values (10 ns ticks; 0 = unpaced).  Which of the allocations are "slow" placements shows in the first column.
 
     python tools/experiments/pacing.py [builder] [nbuf] [hold ...]
