@@ -60,7 +60,14 @@ struct UnitCfg {
     int partpx;  // pixels of one part tile: 64 (kPartPx), or 128 for narrow pixels, whose 64-pixel tiles are too small to
                  // pay for their own fill / store / phase sequence (n_imagenet accumulators 67 -> 62 us, EventStack 87 -> 81)
     int hold;    // store pacing: the wave starts its stores no earlier than `hold` x 10 ns after it started (0 = off)
+    int merge;   // 1: the row's last unit also takes the short tail chunk of a sensor whose width is not a multiple of 128 (r04:
+                 // Gen1's 304-pixel rows are 128 + 128 + 48 -- a third of the units were 48-pixel tails with a full unit's
+                 // fixed cost; now a row is two units, 128 and 176 pixels)
 };
+// units per sensor row / the chunks of unit `ur` of a row
+__host__ __device__ inline int units_per_row(int nchunk, int span, int merge) {
+    return merge ? ((nchunk - 1 + span - 1) / span > 0 ? (nchunk - 1 + span - 1) / span : 1) : (nchunk + span - 1) / span;
+}
 // float32 builders on sparse windows take two consecutive 128-pixel chunks per wave (the same 12 KB per
 // wave as a float64 builder: 108 -> 90 us for EventStack at 640x480x32); chosen on the host from the
 // average record count per chunk, see unit_cfg() in evrep_capi.hip.
@@ -351,16 +358,22 @@ __device__ inline void defer_unit(const BinView &bv, int uid, int nparts) {
 
 // grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks).
 // span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
-__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, int span, int &chunk, int u) {
+__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, const UnitCfg &uc, int &chunk, int &nch, int u) {
     ChunkGeom g;
-    const int nunit = (nchunk + span - 1) / span;
-    chunk = (u % nunit) * span;
+    const int nunit = units_per_row(nchunk, uc.span, uc.merge);
+    const int ur = u % nunit;
+    chunk = ur * uc.span;
+    nch = (uc.merge && ur == nunit - 1) ? nchunk - chunk : min(uc.span, nchunk - chunk);
     g.row = (u / nunit) % H;
     g.b = (u / nunit) / H;
     g.c0 = chunk * kChunkPx;
-    g.npix = min(span * kChunkPx, W - g.c0);
+    g.npix = min(nch * kChunkPx, W - g.c0);
     g.cs = 0; g.ce = 0;
     return g;
+}
+__device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, const UnitCfg &uc, int &chunk, int u) {
+    int nch;
+    return unit_geom(H, W, nchunk, uc, chunk, nch, u);
 }
 
 // One batch (<= 64 records, record `lane` in r): the records only have to be GROUPED by pixel, in time order inside a
@@ -770,19 +783,19 @@ __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT, HOT> &w) {
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
 // uid = the unit's id (run_units).  A main launch (HOT false) defers a unit of more records than its stage (u.deferred).
 template <typename OutT, bool HOT>
-__device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, int span,
+__device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, const UnitCfg &uc,
                                       WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part) {
-    int chunk;
-    g = unit_geom(H, W, nchunk, span, chunk, uid);
+    int chunk, nch;
+    g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
     if (bv.fused) {
-        const int klo = g.row * nchunk + chunk, khi = g.row * nchunk + min(chunk + span, nchunk);
-        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, span * kChunkPx, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
+        const int klo = g.row * nchunk + chunk, khi = klo + nch;
+        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
     const uint32_t *co = bv.chunk_off + ((size_t)g.b * H + g.row) * (nchunk + 1);
     g.cs = co[chunk];
-    g.ce = co[min(chunk + span, nchunk)];
+    g.ce = co[chunk + nch];
     UnitRecs u;
     u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
@@ -1540,7 +1553,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         const int C = D::C(P);
-        WaveLds<OutT, HOT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+        WaveLds<OutT, HOT> w(smem, C, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
 #ifdef EVREP_TIMING
         w.dbg = bv.dbg + 8 * (size_t)uid;
@@ -1549,11 +1562,11 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
         // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
         // unit's records
         int chunk0;
-        const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        const int b0 = unit_geom(H, W, nchunk, uc, chunk0, uid).b;
         const int64_t n_win = off[b0 + 1] - off[b0];
         const MetaRaw mraw = meta_prefetch(bv, b0);
         w.mark(6);
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         w.mark(0);
         OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
@@ -1650,10 +1663,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_event_stack(BinView bv,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
-        WaveLds<float, HOT> w(smem, S, uc.span * kChunkPx, uc.stage, uc.partpx);
+        WaveLds<float, HOT> w(smem, S, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
         const int64_t n_win = off[g.b + 1] - off[g.b];
@@ -1806,17 +1819,17 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         const int C = 2 * S;
-        WaveLds<OutT, HOT> w(smem, C, uc.span * kChunkPx, uc.stage);
+        WaveLds<OutT, HOT> w(smem, C, (uc.span + uc.merge) * kChunkPx, uc.stage);
         w.arm(uc.hold);
         // the window's cuts, held in registers with compile-time indices only (no scratch); read BEFORE the unit's front end, so
         // that their latency runs beside the run-table / record loads instead of behind them (r03)
         int chunk0;
-        const TsCuts *cp = cuts + unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        const TsCuts *cp = cuts + unit_geom(H, W, nchunk, uc, chunk0, uid).b;
         struct { int idx[(CM / 2)], tcut[(CM / 2)], live[(CM / 2)]; } cu;
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
         // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
@@ -1828,7 +1841,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
         // whole unit is staged (every unit of a sparse window) in windows of up to 600 tau (beyond, the factors would
         // overflow); the other waves keep the timestamps and take their exponentials per slice, as round 1 did.
         const int tref = cp->tref;
-        const double *tw = tf ? tf + off[unit_geom(H, W, nchunk, uc.span, chunk0, uid).b] : nullptr;   // float timestamps, by rank
+        const double *tw = tf ? tf + off[unit_geom(H, W, nchunk, uc, chunk0, uid).b] : nullptr;   // float timestamps, by rank
         const bool fact = FACT && !tf && !(premap & 2) && cp->direct == 0 && (u.ce - u.cs) <= max((uint32_t)kWave, (uint32_t)u.nstaged);  // wave-uniform
         double fac[(CM / 2)];
 #pragma unroll
@@ -2024,18 +2037,18 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_voxel(const int4 *__rest
                                                 double *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
-        WaveLds<double, HOT> w(smem, bins, uc.span * kChunkPx, uc.stage);
+        WaveLds<double, HOT> w(smem, bins, (uc.span + uc.merge) * kChunkPx, uc.stage);
         w.arm(uc.hold);
         // the window's first / last timestamp: two dependent load levels (extent, then events) issued BEFORE the unit's own two
         // levels (run tables, then records), not behind them (r03: they were a third and fourth step of the wave's latency chain)
         int chunk0;
-        const int b0 = unit_geom(H, W, nchunk, uc.span, chunk0, uid).b;
+        const int b0 = unit_geom(H, W, nchunk, uc, chunk0, uid).b;
         const int64_t beg = off[b0];
         const int64_t n_win = off[b0 + 1] - beg;
         int tz0 = 0, tz1 = 0;
         if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
         double t0 = 0.0, den = 1.0;
@@ -2121,10 +2134,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         const int C = P.C;
-        WaveLds<float, HOT> w(smem, C, uc.span * kChunkPx, uc.stage, uc.partpx);
+        WaveLds<float, HOT> w(smem, C, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
         const int lane = threadIdx.x;
@@ -2222,10 +2235,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_est(BinView bv,
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
         const int C2 = 2 * P.C;
-        WaveLds<float, HOT> w(smem, C2, uc.span * kChunkPx, uc.stage);
+        WaveLds<float, HOT> w(smem, C2, (uc.span + uc.merge) * kChunkPx, uc.stage);
         w.arm(uc.hold);
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc.span, w, g, uid, part);
+        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C2;
         const float *tw = tnorm + off[g.b];

@@ -406,9 +406,15 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
+    // a short tail chunk (<= 64 of 128 pixels: Gen1's 304-pixel rows end in 48) rides with the row's last unit (UnitCfg::merge);
+    // TORE's units live in the OUTPUT frame and keep their own geometry (extra_chunks)
+    const int tail = plan->W % kChunkPx;
+    // (an experiment switch, off by default: measured at the Gen1 shape the 176-pixel unit loses the sparse emit -- ~95 records
+    //  in ~80 pixels -- and its three-part tile sequence costs more than the 48-pixel tail unit it saves: ERGO-12 68 -> 82 us)
+    uc.merge = (extra_chunks == 0 && tail != 0 && tail <= kChunkPx / 2 && plan->nchunk >= 2 && (plan->flags & EVREP_PLAN_X_TAIL_MERGE)) ? 1 : 0;
     return uc;
 }
-#define SPAN_GRID(span) dim3((plan->nchunk + (span) - 1) / (span), plan->H, plan->B)
+#define SPAN_GRID(span) dim3(units_per_row(plan->nchunk, (span), uc.merge), plan->H, plan->B)
 // The builder calls on a plan alternate between the two hot lists (run_units): bit 30 of plan->flags is the library's own.
 // (A plan drives ONE workspace between two binning passes; evrep_bin_events clears both lists and the bit.)
 static void hot_flip(const evrep_plan *plan) { const_cast<evrep_plan *>(plan)->flags ^= (int32_t)1 << 30; }
@@ -421,7 +427,7 @@ static UnitCfg hot_cfg(UnitCfg uc) { uc.stage = kHotStage; uc.hold = 0; return u
 // 6.4-6.9 TB/s when it stays just below (NOTES.md 3.2, tools/experiments/pacing.py: the float64 12-channel builder takes
 // 168 us unpaced, 148 us held at 7.0 us, 155 us held at 7.5 us -- a cliff on the short side, a slope on the long side, so
 // the hold sits 2 % beyond the knee).  The hold scales with the bytes the CU's resident waves own.
-static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_bytes, int span, size_t pixel_bytes) {
+static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_bytes, int span, size_t pixel_bytes, int merge) {
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
     if (per_chunk > 30.0) return 0;   // dense windows are bound by their segment walks, not by their stores
     int waves = 0;
@@ -429,7 +435,7 @@ static int auto_hold(const evrep_plan *plan, const void *kernel, size_t lds_byte
         (void)hipGetLastError();
         return 0;
     }
-    const int nunit = (plan->nchunk + span - 1) / span;
+    const int nunit = units_per_row(plan->nchunk, span, merge);
     const double unit_bytes = (double)plan->W * (double)pixel_bytes / (double)nunit;   // a row's bytes over its units
     const double ticks = 690.0 * ((double)waves * unit_bytes) / (19.0 * 12288.0);
     return ticks < 50.0 ? 0 : (int)(ticks + 0.5);
@@ -475,11 +481,11 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
     const bool pace_auto = plan->pacing < 0 && out_dtype == EVREP_F64 && C * 8 >= 64;   // the store-bound instances
 #define MDES_LAUNCH(T, DESC)                                                                                          \
     do {                                                                                                              \
-        const size_t lds_ = chunk_lds_bytes(C, sizeof(T), span * kChunkPx, uc.stage, uc.partpx);                       \
-        if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T)); \
+        const size_t lds_ = chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, uc.stage, uc.partpx);                       \
+        if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
-        k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), span * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+        k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
             bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
@@ -518,9 +524,9 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     const int span = uc.span;
 #define ES_LAUNCH(CM)                                                                                              \
     do {                                                                                                           \
-    k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
+    k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out);          \
-    k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, span * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+    k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, hot_cfg(uc), stack_size, premap, scale, out); \
     } while (0)
     if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
@@ -566,11 +572,11 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
             bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, hot_cfg(uc), slices, tau, premap,  \
             scale, tf, static_cast<T *>(out));                                                                           \
     } while (0)
-        if (slices <= 6) TS_LAUNCH(double, 12, BUILDER_GRID, kChunkPx); else TS_LAUNCH(double, 16, BUILDER_GRID, kChunkPx);
+        if (slices <= 6) TS_LAUNCH(double, 12, SPAN_GRID(1), (1 + uc.merge) * kChunkPx); else TS_LAUNCH(double, 16, SPAN_GRID(1), (1 + uc.merge) * kChunkPx);
     } else {
         const UnitCfg uc = unit_cfg(plan, (size_t)2 * slices * 4, 0, false, false);
         const int span = uc.span;
-        if (slices <= 6) TS_LAUNCH(float, 12, SPAN_GRID(span), span * kChunkPx); else TS_LAUNCH(float, 16, SPAN_GRID(span), span * kChunkPx);
+        if (slices <= 6) TS_LAUNCH(float, 12, SPAN_GRID(span), (span + uc.merge) * kChunkPx); else TS_LAUNCH(float, 16, SPAN_GRID(span), (span + uc.merge) * kChunkPx);
     }
 #undef TS_LAUNCH
 #undef TS_LAUNCH_F
@@ -640,10 +646,10 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
     const int span = uc.span;
 #define VOXEL_LAUNCH(CM)                                                                                         \
     do {                                                                                                         \
-    k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, uc.stage), stream>>>(              \
+    k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
         bins, mode, scale, t_range, tnorm, out);                                                                 \
-    k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, span * kChunkPx, kHotStage), stream>>>(         \
+    k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(         \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
         hot_cfg(uc), bins, mode, scale, t_range, tnorm, out);                                                    \
     } while (0)
@@ -692,9 +698,9 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     const int span = uc.span;
 #define PS_LAUNCH(CM)                                                                                                 \
     do {                                                                                                              \
-        k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, span * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
+        k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
-        k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, span * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
+        k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), out);   \
     } while (0)
     if (C <= 8) PS_LAUNCH(8); else PS_LAUNCH(16);
@@ -719,10 +725,10 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * C * 4);
     const int span = uc.span;
-    k_est<false><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, uc.stage), stream>>>(
+    k_est<false><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, uc, out);
-    k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, span * kChunkPx, kHotStage), stream>>>(
+    k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, hot_cfg(uc), out);
     hot_flip(plan);

@@ -83,6 +83,7 @@ typedef struct evrep_plan {
 #define EVREP_PLAN_BIG_BLOCKS 8u        /* key-sorted pass: 8192-event blocks also for short windows */
 #define EVREP_PLAN_NO_FUSED_SCATTER 16u /* three-kernel pass: separate scan and scatter kernels */
 #define EVREP_PLAN_X_SPAN2 64u          /* experiment: float64 MDES units of two 128-pixel chunks (NOTES.md 8) */
+#define EVREP_PLAN_X_TAIL_MERGE 256u    /* experiment: a row's last unit also takes a short tail chunk (NOTES.md r04: slower) */
 
 int evrep_abi_version(void);
 const char *evrep_last_hip_error(void);
