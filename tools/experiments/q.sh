@@ -1,3 +1,2 @@
-timeout 400 python -m pytest tests/test_gpu_clustered.py tests/test_gpu_key_sorted.py tests/test_gpu_fuzz.py tests/test_gpu_builders.py tests/test_gpu_reference_api.py -x -q 2>&1 | tail -3
-echo "== merged tails"; timeout 300 python tools/sweep_table.py gen1 gen1@circle gen1@edges
-echo "== no merge"; EVREP_NO_TAIL_MERGE=1 timeout 300 python tools/sweep_table.py gen1
+echo "== stage64 (warm path for every unit > 64)"; EVREP_X_STAGE64=1 timeout 300 python tools/sweep_table.py gen1 c2-150k
+echo "== default"; timeout 300 python tools/sweep_table.py gen1 c2-150k b=optimized_f64 b=event_stack_f32 b=time_surface_f64

@@ -38,9 +38,18 @@ def main():
                 out = gen1_transforms.get_item_transform(w, str(tr), tr, H, W, N, 50000)
                 ts.append(time.perf_counter() - t0)
             el = float(np.median(ts))
+            # the same call with the result left on the GPU (get_item_transform_cuda, r04): no read-back
+            td = []
+            for i in range(24):
+                w = wins[i % len(wins)].copy()
+                t0 = time.perf_counter()
+                dev = gen1_transforms.get_item_transform_cuda(w, str(tr), tr, H, W, N, 50000)
+                td.append(time.perf_counter() - t0)
+            eld = float(np.median(td))
             if rnd:
                 print(json.dumps({"representation": name, "median_ms_per_sample": round(el * 1e3, 3),
-                                  "events_per_s": round(N / el), "out_shape": list(out.shape),
+                                  "median_ms_per_sample_device_out": round(eld * 1e3, 3),
+                                  "events_per_s": round(N / el), "events_per_s_device_out": round(N / eld), "out_shape": list(out.shape),
                                   "out_dtype": str(out.dtype), "out_MB": round(out.nbytes / 1e6, 1)}))
 
 
