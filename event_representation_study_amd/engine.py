@@ -541,7 +541,9 @@ def gwd_padded_l1_batch(Xs, n, Xt, m, n_cap, m_cap, xs_row=None, xt_row=None, h=
 
 def otmi_event_clouds(events, offsets, height, width, cap=None, workspace=None):
     """Device half of otmi(): events (total, 4) int32 cuda tensor of B windows (offsets: (B+1,) int64, host or device) ->
-    (Xs (B, 3, cap, 4) float64, n (B, 3) int64, quad (B, 3) int32), all on the device, nothing read back."""
+    (Xs (B, 3, cap, 4) float64, n (B, 3) int64, quad (B, 3) int32), all on the device, nothing read back.
+    The returned tensors are VIEWS of `workspace` (default: the device's shared GwdWorkspace): the next call with the same
+    workspace overwrites them -- clone what must outlive it, or pass a GwdWorkspace of your own (one per host thread / stream)."""
     _require_gpu()
     lib = _lib.load()
     dev = events.device
@@ -564,7 +566,7 @@ def otmi_event_clouds(events, offsets, height, width, cap=None, workspace=None):
 def otmi_rep_clouds(reps, quad, B, workspace=None, slot="otmi_xt"):
     """Device half of otmi(): reps (items, S, S, C) float64/float32 cuda tensor of letterboxed representations (item i
     belongs to window i % B), quad (B, 3) int32 from otmi_event_clouds -> (Xt (items, 3, m_cap, C + 2) float64,
-    m (items, 3) int64)."""
+    m (items, 3) int64).  Views of `workspace`, like otmi_event_clouds' results."""
     _require_gpu()
     lib = _lib.load()
     dev = reps.device
