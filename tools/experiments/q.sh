@@ -1,2 +1,6 @@
-echo "== stage64 (warm path for every unit > 64)"; EVREP_X_STAGE64=1 timeout 300 python tools/sweep_table.py gen1 c2-150k
-echo "== default"; timeout 300 python tools/sweep_table.py gen1 c2-150k b=optimized_f64 b=event_stack_f32 b=time_surface_f64
+O=gpurun_out/final; mkdir -p $O
+bash tools/experiments/wave_lifetimes.sh > $O/wave_lifetimes.txt 2>&1
+EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=640,480,500000,8 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_dense.txt 2>&1
+EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=304,240,50000,32 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_gen1.txt 2>&1
+EVREP_LIB_PATH=tools/variants/libevrep_timing.so NBUF=2 timeout 300 python tools/experiments/phase_times.py 0 690 > $O/phase_times.txt 2>&1
+cat $O/wave_lifetimes.txt | cut -c1-150
