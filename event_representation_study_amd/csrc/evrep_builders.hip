@@ -270,6 +270,7 @@ struct UnitRecs {
     bool deferred;
     int part;   // hot launch: the 64-pixel part of the unit this wave emits (run_units)
     uint32_t pst, pen;   // hot launch, per lane: the segment of pixel part * 64 + lane in the unit's spill slot
+    bool hot_lds;        // hot launch: the part's records lie RAW in the hot stage already (not in the slot)
     int dpx, npixu;      // main launch, a unit in the spill slot: output pixel o = unit pixel o + dpx; w.segs holds every pixel's END
 };
 
@@ -451,7 +452,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = lane; u.deferred = false; u.part = -1;
+    u.nseg = -1; u.pos = lane; u.deferred = false; u.part = -1; u.hot_lds = false;
     if (khi <= klo) return u;
     // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
     // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
@@ -669,6 +670,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         // the whole unit in ONE round: the placement below finds it still in the registers
         if (sweep_done()) { resident = round == 0; break; }
     }
+    if constexpr (HOT) w.mark(2);   // timing builds: the count sweep is done
     wave_phase();
     {
         uint32_t local = 0;
@@ -715,6 +717,16 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         const int px = plo + lane;
         if (px >= 0 && px < phi && px < npixu) { pst = cnt[px]; pen = px + 1 < npixu ? cnt[px + 1] : nrec; }
     }
+    // a hot wave whose part fits its stage (tile + record stage) places the part straight there: no scattered 16-byte stores
+    // into the slot, no trip through it (timing build, Gen1 circle: the placement into the slot was 30 of a 71 us item)
+    uint32_t hra = 0;
+    bool hot_lds = false;
+    if constexpr (HOT) {
+        const bool hm = pen > pst;
+        hra = (uint32_t)wave_min(hm ? (int)pst : INT32_MAX);
+        const uint32_t hrb = (uint32_t)wave_max(hm ? (int)pen : 0);
+        hot_lds = hrb > hra && hrb - hra <= (uint32_t)w.bigcap;   // wave-uniform
+    }
     wave_phase();
     volatile uint32_t *vcnt = cnt;
     if (!resident) sweep_begin();
@@ -732,7 +744,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             if (valid) {
                 pos = vcnt[px] + rk;
                 const Rec rec = rec8_unpack(q[sl], row_base, c0, evw);
-                if (in_lds) *w.big_at(pos) = rec; else bv.spill[cs + pos] = rec;
+                if (in_lds) *w.big_at(pos) = rec; else if (hot_lds) *w.big_at(pos - hra) = rec; else bv.spill[cs + pos] = rec;
             }
             __builtin_amdgcn_wave_barrier();
             if (valid && last) vcnt[px] = pos + 1;
@@ -740,8 +752,10 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
     }
     wave_phase();
+    if constexpr (HOT) w.mark(3);   // timing builds: the part's records lie in the slot
     u.pst = pst; u.pen = pen;   // hot launch: the lane's segment; a main launch reads the cursors (now every pixel's END) per part
     if (in_lds) u.part = -3;
+    u.hot_lds = hot_lds;
     // the wave reads back what its own lanes stored: same CU, same vector L1 -- workgroup-scope release / acquire
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -799,7 +813,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     UnitRecs u;
     u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = (int)threadIdx.x; u.deferred = false; u.part = -1;
+    u.nseg = -1; u.pos = (int)threadIdx.x; u.deferred = false; u.part = -1; u.hot_lds = false;
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
     stage_classic(u, w);
     return u;
@@ -1095,9 +1109,9 @@ __device__ inline void emit_core(uint32_t nrec, int nseg_pre, bool all_staged, K
 //     issued when record j is consumed, so a step waits for arithmetic, not for L2 (the walks are sequential per pixel by
 //     contract: what bounds such a wave is its longest segment).
 template <typename OutT, int CMAX, bool STAGE, typename Digest, typename DigestFly, typename Reduce>
-__device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, uint32_t st, uint32_t en, int part, Digest digest,
-                                 DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst, WaveLds<OutT, true> &w,
-                                 const OutT *bg, Reduce reduce) {
+__device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, uint32_t st, uint32_t en, int part, bool staged_raw,
+                                 Digest digest, DigestFly digest_fly, int npix, int C, OutT *__restrict__ dst,
+                                 WaveLds<OutT, true> &w, const OutT *bg, Reduce reduce) {
     constexpr bool HOT = true;
     const int lane = threadIdx.x;
     const uint32_t cap = (uint32_t)w.bigcap;
@@ -1110,7 +1124,12 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     };
     OutT vals[CMAX];
     if (__any(mine)) {
-        if (STAGE && rb - ra <= cap) {   // wave-uniform (STAGE false: a builder that reads one record per segment)
+        if (staged_raw) {   // wave-uniform: unit_records has placed the part in the stage: digested in place, walked from LDS
+            for (uint32_t j = (uint32_t)lane; j < rb - ra; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
+            wave_phase();
+            w.mark(4);
+            if (mine) reduce(st - ra, en - ra, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
+        } else if (STAGE && rb - ra <= cap) {   // wave-uniform (STAGE false: a builder that reads one record per segment)
             constexpr int kDepth = HOT ? 8 : 4;   // 16-byte loads in flight per lane
             for (uint32_t j0 = ra; j0 < rb; j0 += kDepth * kWave) {
                 Rec r[kDepth];
@@ -1131,6 +1150,7 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
                 for (uint32_t j = (uint32_t)lane; j < rb - ra; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
                 wave_phase();
             }
+            w.mark(4);   // timing builds: staged
             if (mine) reduce(st - ra, en - ra, [&](uint32_t j) -> Rec { return *w.big_at(j); }, vals);
         } else if (!HOT) {
             // STAGE false (a main launch only sorts units whose parts fit the stage): one record per segment, from the slot
@@ -1314,7 +1334,7 @@ __device__ inline void emit_chunk(const UnitRecs &u, Digest digest, DigestFly di
     Rec *evbuf = w.evbuf;
     const uint32_t nst = max((uint32_t)kWave, nraw);  // records [0, nst) are staged
     if constexpr (HOT) {   // one part of a unit beyond a main wave's stage, out of the unit's spill slot
-        emit_part<OutT, CMAX, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, digest, digest_fly, npix, C, dst, w, bg, reduce);
+        emit_part<OutT, CMAX, STAGE>(sorted + cs, nrec, u.pst, u.pen, u.part, u.hot_lds, digest, digest_fly, npix, C, dst, w, bg, reduce);
         return;
     } else if (u.part == -3) {   // wave-uniform: a main launch, a WARM unit sorted into the hot stage (over the tile)
         emit_warm<OutT, CMAX>(u, nrec, digest, npix, C, dst, w, bg, reduce);
@@ -1953,7 +1973,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         UnitRecs ur;
         ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
         ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
-        ur.nseg = -1; ur.pos = (int)threadIdx.x; ur.deferred = false; ur.part = -1;
+        ur.nseg = -1; ur.pos = (int)threadIdx.x; ur.deferred = false; ur.part = -1; ur.hot_lds = false;
         if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
             const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
             if (bv.fused) {

@@ -47,3 +47,6 @@ for o in outs:
         print("%x %s hold %4d  %.1f us/launch  wave lifetime mean %.2f p95 %.2f p99 %.2f max %.2f us  phases mean/p95 (us) %s"
               % (o.data_ptr(), DIST, h, a.elapsed_time(b) * 100, life.mean(), np.percentile(life, 95), np.percentile(life, 99), life.max(),
                  "  ".join(ph)), flush=True)
+        if os.environ.get("TOP"):   # the longest-lived waves, mark by mark (hot items: 6 loads issued, 2 count sweep done,
+            for i in np.argsort(-d[:, 5])[:int(os.environ["TOP"])]:   # 3 part in the slot, 0 front end done, 1 statistics, 4 staged, 5 stored)
+                print("   unit %6d  " % i + "  ".join("%d: %.1f" % (k, d[i, k]) for k in (6, 2, 3, 0, 1, 4, 5)), flush=True)

@@ -1,6 +1,5 @@
-O=gpurun_out/final; mkdir -p $O
-bash tools/experiments/wave_lifetimes.sh > $O/wave_lifetimes.txt 2>&1
-EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=640,480,500000,8 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_dense.txt 2>&1
-EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=304,240,50000,32 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_gen1.txt 2>&1
-EVREP_LIB_PATH=tools/variants/libevrep_timing.so NBUF=2 timeout 300 python tools/experiments/phase_times.py 0 690 > $O/phase_times.txt 2>&1
-cat $O/wave_lifetimes.txt | cut -c1-150
+timeout 400 python -m pytest tests/test_gpu_clustered.py tests/test_gpu_key_sorted.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -3
+T="gen1@circle gen1@edges c2@circle c3@circle b=optimized_f64 b=event_stack_f32 b=time_surface_f64"
+echo "== default (hot stage 256)"; timeout 300 python tools/sweep_table.py $T
+for v in s512 s768; do echo "== $v"; EVREP_LIB_PATH=tools/variants/$v.so timeout 300 python tools/sweep_table.py $T; done
+EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=304,240,50000,32 DIST=circle NBUF=1 TOP=4 timeout 200 python tools/experiments/phase_times.py -1 2>&1 | grep -v amdgpu | cut -c1-200
