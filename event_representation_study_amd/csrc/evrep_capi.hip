@@ -403,7 +403,7 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
     // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
     // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
-    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : (((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) && !(plan->flags & 512)) ? 128 : 64);
+    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     // a short tail chunk (<= 64 of 128 pixels: Gen1's 304-pixel rows end in 48) rides with the row's last unit (UnitCfg::merge);
