@@ -419,6 +419,7 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
 // (A plan drives ONE workspace between two binning passes; evrep_bin_events clears both lists and the bit.)
 static void hot_flip(const evrep_plan *plan) { const_cast<evrep_plan *>(plan)->flags ^= (int32_t)1 << 30; }
 // the hot launch behind every builder launch (run_units): the same unit numbering (span), a stage of kHotStage records, no pacing
+// (only launched after the key-sorted pass: the main launches of the classic passes defer nothing)
 static UnitCfg hot_cfg(UnitCfg uc) { uc.stage = kHotStage; uc.hold = 0; return uc; }
 
 // Automatic store pacing (plan->pacing == -1) of a builder instance whose launch is bound by its HBM writes on sparse
@@ -485,7 +486,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
-        k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+        if (plan->reserved == 2) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
             bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
@@ -526,7 +527,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     do {                                                                                                           \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out);          \
-    k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+    if (plan->reserved == 2) k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, hot_cfg(uc), stack_size, premap, scale, out); \
     } while (0)
     if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
@@ -568,7 +569,7 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
 #define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
     do {                                                                                                             \
         if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG);                  \
-        k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
+        if (plan->reserved == 2) k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
             bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, hot_cfg(uc), slices, tau, premap,  \
             scale, tf, static_cast<T *>(out));                                                                           \
     } while (0)
@@ -605,7 +606,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
-    k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, kHotStage), stream>>>(     \
+    if (plan->reserved == 2) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, kHotStage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, hot_cfg(uc), k, frame_mode, scale, out);                                    \
     } while (0)
@@ -649,7 +650,7 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
     k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
         bins, mode, scale, t_range, tnorm, out);                                                                 \
-    k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(         \
+    if (plan->reserved == 2) k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(         \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
         hot_cfg(uc), bins, mode, scale, t_range, tnorm, out);                                                    \
     } while (0)
@@ -700,7 +701,7 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     do {                                                                                                              \
         k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
-        k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
+        if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), out);   \
     } while (0)
     if (C <= 8) PS_LAUNCH(8); else PS_LAUNCH(16);
@@ -728,7 +729,7 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     k_est<false><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, uc, out);
-    k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(
+    if (plan->reserved == 2) k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, hot_cfg(uc), out);
     hot_flip(plan);
