@@ -30,7 +30,8 @@ static int hip_check(hipError_t e, const char *what) {
     } while (0)
 
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
-constexpr double kKeySortedMaxPerUnit = 110.0;   // average records per builder unit up to which the key-sorted pass is chosen
+constexpr double kKeySortedMaxPerUnit = 220.0;   // average records per builder unit up to which the key-sorted pass is chosen (r04: 110 -> 220, the warm path of the builders beats the per-key column sort for a single builder per binning pass up to 500 000 events on 640x480: bin + build 159 vs 163 us for ERGO-12, 91 vs 115 us for EventStack)
+constexpr double kDeepStageMinPerUnit = 110.0;   // classic passes: windows denser than this stage 256 records per unit (stage_classic)
 
 template <int NSS, int NST>
 static int gwd_launch_tiles(const GwdTileArgs &P, hipStream_t stream) {
@@ -403,7 +404,7 @@ static UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_ch
     // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
     // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
     // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
-    uc.stage = (deep_stage && per_chunk > kKeySortedMaxPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
+    uc.stage = (deep_stage && plan->reserved != 2 && per_chunk > kDeepStageMinPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     // a short tail chunk (<= 64 of 128 pixels: Gen1's 304-pixel rows end in 48) rides with the row's last unit (UnitCfg::merge);
@@ -558,7 +559,7 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
     // windows whose units are practically all fully staged (<= 128 records: everything the key-sorted pass is chosen for, r03;
     // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
     // when ITS unit is fully staged, whatever the binning pass (Gen1 shape 88 -> 80 us)
-    const bool ts_fact = (double)plan->max_events_per_window <= kKeySortedMaxPerUnit * (double)plan->H * plan->nchunk;
+    const bool ts_fact = (double)plan->max_events_per_window <= kDeepStageMinPerUnit * (double)plan->H * plan->nchunk;
     if (out_dtype == EVREP_F64) {
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20, 0, false, false);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \

@@ -111,8 +111,15 @@ def test_the_pass_is_chosen_for_the_headline_windows_and_matches_the_oracle(orac
     ebm = eng.EventBatch.from_numpy([mid], H, W)
     assert ebm.plan.reserved == 2
     assert_bit_equal(ebm.optimized().cpu().numpy()[0], oracle.ergo12(mid, H, W), "ergo12, 83 records per unit")
-    # ... a dense window of the same sensor: k_block_keysort + the per-key column sort, then the classic builders
-    assert eng.EventBatch.from_numpy([make_events(500000, W, H, seed=1)], H, W).plan.reserved == 3
+    # ... r04: up to ~220 per unit (500 000 events here) the builders' warm path -- a unit sorted in LDS over its tile --
+    # still beats the per-key column sort for one builder per binning pass
+    d5 = make_events(500000, W, H, seed=1)
+    ebd = eng.EventBatch.from_numpy([d5], H, W)
+    assert ebd.plan.reserved == 2
+    assert_bit_equal(ebd.optimized().cpu().numpy()[0], oracle.ergo12(d5, H, W), "ergo12, 208 records per unit")
+    assert_bit_equal(ebd.event_stack().cpu().numpy()[0], oracle.event_stack(d5, H, W), "event stack, 208 records per unit")
+    # ... a denser window of the same sensor: k_block_keysort + the per-key column sort, then the classic builders
+    assert eng.EventBatch.from_numpy([make_events(600000, W, H, seed=1)], H, W).plan.reserved == 3
     # the reference's own Gen1 shape (304x240, 50 000 events: ~69 records per unit) is on the key-sorted pass
     g1 = make_events(50000, 304, 240, seed=2)
     eg = eng.EventBatch.from_numpy([g1], 240, 304)
