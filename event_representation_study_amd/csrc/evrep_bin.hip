@@ -79,12 +79,23 @@ constexpr int kRegBatch = 8;  // records a lane keeps in registers at a time
 // scattered 16-byte record writes then meet in ONE XCD's L2 and leave it as full lines, and the
 // events the histogram pass pulled through that L2 are re-read there by the scatter pass.
 // Grid size = 8 * ceil(B/8) * nblk; placement only affects speed, never results.
+// A last, partial group of windows (B % 8 of them: 4 windows of 10^6 events, one window of a per-sample call) is laid out
+// window-major instead -- consecutive ids = consecutive blocks of one window, round-robin over ALL eight XCDs (r04: with
+// the mapping above half the chip idled on 4 windows: k_block_keysort 71 us where 8 windows of the same total took 39).
 __device__ inline bool decode_window_block(int B, int nblk, int &b, int &blk) {
     const int id = blockIdx.x;
-    const int xcd = id & 7, s = id >> 3;
-    b = (s / nblk) * 8 + xcd;
-    blk = s % nblk;
-    return b < B;
+    const int per_group = 8 * nblk;
+    const int grp = id / per_group, r = id - grp * per_group;
+    const int nw = min(8, B - 8 * grp);
+    if (nw == 8) {
+        b = grp * 8 + (r & 7);
+        blk = r >> 3;
+        return true;
+    }
+    if (r >= nw * nblk) return false;
+    b = grp * 8 + r / nblk;
+    blk = r - (r / nblk) * nblk;
+    return true;
 }
 
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = H * 4 bytes.

@@ -38,6 +38,10 @@ CONFIGS = {
     "c2-dense": (640, 480, 500000, 8),
     "c3": (1280, 720, 200000, 8), "c3-1M": (1280, 720, 1000000, 4),
 }
+# experiments: SWEEP_SHAPES="w76:76,960,50000,32;w128:128,570,50000,32" adds geometries
+for _item in filter(None, os.environ.get("SWEEP_SHAPES", "").split(";")):
+    _name, _, _dims = _item.partition(":")
+    CONFIGS[_name] = tuple(int(v) for v in _dims.split(","))
 HBM_PEAK_GBPS = 8000.0
 
 
