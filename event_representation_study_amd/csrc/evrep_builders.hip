@@ -444,7 +444,11 @@ __device__ inline void group_single_batch(const Rec &r, bool v0, uint32_t nrec, 
 //     position = records of the window with a smaller key = sum over the runs of table[k][klo]: disjoint slots,
 //     no atomics, idempotent across builders), then read back like the classic stream.
 // c0 = first sensor column of the unit (keybase = row * W + c0): what the 8-byte records are decoded against.
-template <typename OutT, bool HOT>
+// LAST (r04): the builder only reads the LAST record of a pixel (EventStack: ndarray.put is last-write-wins) -- a unit beyond
+// the record stage then needs no order at all: one sweep with an LDS atomicMax per record on (rank, polarity) words, one per
+// pixel, and the survivors -- at most one record per pixel -- laid out like a warm unit (emit_warm).  No count sweep, no
+// placement, no slot, no deferral, whatever the unit holds.
+template <typename OutT, bool HOT, bool LAST = false>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
                                         int keybase, int npixu, WaveLds<OutT, HOT> &w, int segbase, int c0, int uid,
                                         int npix_out, int part) {
@@ -661,6 +665,39 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         return any;
     };
     auto px_of = [&](const Rec8 &r) -> uint32_t { return ((r.y & 511u) - (uint32_t)c0) & 511u; };   // pixel inside the unit
+    if constexpr (LAST && !HOT) {
+        if (npixu <= w.bigcap) {   // wave-uniform: the survivors fit the hot stage (always, for stacks of >= 8 levels)
+            sweep_begin();
+            while (load_batch()) {
+#pragma unroll
+                for (int sl = 0; sl < kSpillBatch; ++sl)
+                    if ((uint32_t)lane < bcnt[sl]) atomicMax(&cnt[px_of(q[sl])], (((q[sl].y >> 11) + 1u) << 2) | ((q[sl].y >> 9) & 3u));
+                if (sweep_done()) break;
+            }
+            wave_phase();
+            uint32_t nlast = 0;
+            for (int p0 = 0; p0 < npixu; p0 += kWave) {   // npixu is a multiple of 128
+                const int px = p0 + lane;
+                const uint32_t v = cnt[px];
+                const uint64_t m = __ballot(v != 0u);
+                const uint32_t pos = nlast + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (v != 0u) {
+                    const int rank = (int)(v >> 2) - 1;
+                    const uint32_t p2 = v & 3u;
+                    *w.big_at(pos) = make_int4(keybase + px, rank, 0, p2 == 3u ? evw[rank].w : (int)p2 - 1);
+                }
+                cnt[px] = pos + (v != 0u ? 1u : 0u);   // the pixel's END, as emit_warm reads it
+                nlast += (uint32_t)__popcll(m);
+            }
+            wave_phase();
+            u.part = -3;
+            u.cs = cs; u.ce = cs + nlast;
+            u.nstaged = 0;
+            u.dpx = dpx; u.npixu = npixu;
+            u.pst = 0; u.pen = 0;
+            return u;
+        }
+    }
     sweep_begin();
     bool resident = false;
     for (int round = 0; load_batch(); ++round) {
@@ -796,14 +833,14 @@ __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT, HOT> &w) {
 
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
 // uid = the unit's id (run_units).  A main launch (HOT false) defers a unit of more records than its stage (u.deferred).
-template <typename OutT, bool HOT>
+template <typename OutT, bool HOT, bool LAST = false>
 __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, const UnitCfg &uc,
                                       WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part) {
     int chunk, nch;
     g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = klo + nch;
-        const UnitRecs u = unit_records(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
+        const UnitRecs u = unit_records<OutT, HOT, LAST>(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -1686,7 +1723,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_event_stack(BinView bv,
         WaveLds<float, HOT> w(smem, S, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
+        const UnitRecs u = unit_front<float, HOT, true>(bv, off, H, W, nchunk, uc, w, g, uid, part);
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * S;
         const int64_t n_win = off[g.b + 1] - off[g.b];

@@ -524,16 +524,22 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
+    // EventStack reads the last record of a pixel only: a unit beyond the record stage keeps one (rank, polarity) word per pixel
+    // (unit_records, LAST) whenever its pixels fit the hot stage -- then the main launch defers nothing and there is no hot
+    // launch (and no flip of the hot lists: the current one stays empty)
+    const bool last_fits = (size_t)(span + uc.merge) * kChunkPx * sizeof(Rec) <=
+                           align16((size_t)uc.partpx * stack_size * 4) + (size_t)uc.stage * sizeof(Rec);
+    const bool hot_launch = plan->reserved == 2 && !last_fits;
 #define ES_LAUNCH(CM)                                                                                              \
     do {                                                                                                           \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, stack_size, premap, scale, out);          \
-    if (plan->reserved == 2) k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+    if (hot_launch) k_event_stack<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
         bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, hot_cfg(uc), stack_size, premap, scale, out); \
     } while (0)
     if (stack_size <= 8) ES_LAUNCH(8); else if (stack_size <= 12) ES_LAUNCH(12); else ES_LAUNCH(16);
 #undef ES_LAUNCH
-    hot_flip(plan);
+    if (hot_launch) hot_flip(plan);
     LAUNCH_CHECK("k_event_stack");
     return EVREP_OK;
 }
