@@ -448,10 +448,21 @@ __device__ inline void group_single_batch(const Rec &r, bool v0, uint32_t nrec, 
 // the record stage then needs no order at all: one sweep with an LDS atomicMax per record on (rank, polarity) words, one per
 // pixel, and the survivors -- at most one record per pixel -- laid out like a warm unit (emit_warm).  No count sweep, no
 // placement, no slot, no deferral, whatever the unit holds.
-template <typename OutT, bool HOT, bool LAST = false>
+// Visit (r04): the builder's per-pixel result is an order-free function of the unit's records (TimeSurface: per slice and
+// polarity the LAST event at or before the cut) -- a unit beyond the record stage is then not ordered at all: ONE sweep hands
+// every record to visit.f(pixel, record, id), which keeps its own words in the part tile (visit.words_per_px per pixel of the
+// unit, zeroed here) and whatever it wants of record `id` (its sweep slot, unique, < 64 * batches) in the record stage; the
+// kernel emits the unit from them (u.part == -4).  No count sweep, no placement, no slot, no hot launch.
+struct NoVisit { static constexpr bool enabled = false; int words_per_px; };
+template <typename F>
+struct UnitVisit { static constexpr bool enabled = true; F f; int words_per_px; };
+template <typename F>
+__device__ inline UnitVisit<F> unit_visit(F f, int words_per_px) { return UnitVisit<F>{f, words_per_px}; }
+
+template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
                                         int keybase, int npixu, WaveLds<OutT, HOT> &w, int segbase, int c0, int uid,
-                                        int npix_out, int part) {
+                                        int npix_out, int part, Visit visit = Visit()) {
     const int lane = threadIdx.x;
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
@@ -665,6 +676,28 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         return any;
     };
     auto px_of = [&](const Rec8 &r) -> uint32_t { return ((r.y & 511u) - (uint32_t)c0) & 511u; };   // pixel inside the unit
+    if constexpr (Visit::enabled && !HOT) {
+        const uint32_t words = (uint32_t)npixu * (uint32_t)visit.words_per_px;
+        if (words <= (uint32_t)w.bigsplit * 4u) {   // wave-uniform: the words fit the part tile
+            uint4 *t4 = reinterpret_cast<uint4 *>(w.tile);
+            for (uint32_t v = (uint32_t)lane; v * 4u < words; v += kWave) t4[v] = make_uint4(0u, 0u, 0u, 0u);
+            wave_phase();
+            sweep_begin();
+            for (uint32_t id0 = 0; load_batch(); id0 += (uint32_t)(kSpillBatch * kWave)) {
+#pragma unroll
+                for (int sl = 0; sl < kSpillBatch; ++sl)
+                    if ((uint32_t)lane < bcnt[sl]) visit.f(px_of(q[sl]), q[sl], id0 + (uint32_t)(sl * kWave + lane));
+                if (sweep_done()) break;
+            }
+            wave_phase();
+            u.part = -4;
+            u.cs = cs; u.ce = cs + nrec;
+            u.nstaged = 0;
+            u.dpx = dpx; u.npixu = npixu;
+            u.pst = 0; u.pen = 0;
+            return u;
+        }
+    }
     if constexpr (LAST && !HOT) {
         if (npixu <= w.bigcap) {   // wave-uniform: the survivors fit the hot stage (always, for stacks of >= 8 levels)
             sweep_begin();
@@ -833,14 +866,14 @@ __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT, HOT> &w) {
 
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
 // uid = the unit's id (run_units).  A main launch (HOT false) defers a unit of more records than its stage (u.deferred).
-template <typename OutT, bool HOT, bool LAST = false>
+template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit>
 __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, const UnitCfg &uc,
-                                      WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part) {
+                                      WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part, Visit visit = Visit()) {
     int chunk, nch;
     g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = klo + nch;
-        const UnitRecs u = unit_records<OutT, HOT, LAST>(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part);
+        const UnitRecs u = unit_records<OutT, HOT, LAST, Visit>(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part, visit);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -1886,7 +1919,26 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
 #pragma unroll
         for (int q = 0; q < (CM / 2); ++q) { cu.idx[q] = cp->idx[q]; cu.tcut[q] = cp->tcut[q]; cu.live[q] = cp->live[q]; }
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
+        // a unit beyond the record stage (r04): per (pixel, polarity class, slice) the rank + 1 of the last event at or before the
+        // slice's cut -- all a slice reads of its pixel -- kept by LDS atomicMax in one sweep over the unit's records
+        const int4 *evw = bv.ev + off[unit_geom(H, W, nchunk, uc, chunk0, uid).b];
+        // word = (rank + 1) << 9 | id: the record's timestamp waits in the record stage under its sweep id (ids beyond the
+        // stage -- a hot unit of a clustered window -- are marked 511: the timestamp is then fetched from the caller's events)
+        uint32_t *vw = reinterpret_cast<uint32_t *>(w.tile);
+        int32_t *vt = reinterpret_cast<int32_t *>(w.evbuf);
+        const uint32_t vcap = min((uint32_t)uc.stage * 4u, 511u);
+        auto visit = unit_visit([&](uint32_t px, const Rec8 &r, uint32_t id) {
+            const uint32_t rank = r.y >> 11, p2 = (r.y >> 9) & 3u;
+            int p = p2 == 3u ? evw[rank].w : (int)p2 - 1;
+            if (premap & 1) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);
+            uint32_t *at = vw + (px * 2u + (uint32_t)(p & 1)) * (uint32_t)S;
+            const uint32_t word = ((rank + 1u) << 9) | min(id, 511u);
+            if (id < vcap) vt[id] = (int32_t)r.x;
+#pragma unroll
+            for (int q = 0; q < (CM / 2); ++q)
+                if (q < S && (int)rank <= cu.idx[q]) atomicMax(at + q, id < vcap ? word : (word | 511u));
+        }, 2 * S);
+        const UnitRecs u = unit_front<OutT, HOT, false>(bv, off, H, W, nchunk, uc, w, g, uid, part, visit);
         if (u.deferred) return;
         OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
         // (m - t_i) / tau is evaluated as (m - t_i) * (1/tau): one rounding of 1/tau instead of a float64
@@ -1912,28 +1964,8 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
             const double E = exp_neg_range(((double)r.z - (double)tref) * inv_tau);
             return make_int4(__double2loint(E), r.y, __double2hiint(E), r.w);
         };
-        auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
-            // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it, per polarity -- the record
-            // index of the last event (factorised form) or its timestamp.  INT32_MIN = never written.  Slices cut strictly
-            // before an event see the memory as it stands before it.
-            int snap0[(CM / 2)], snap1[(CM / 2)];
-#pragma unroll
-            for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
-            int cur0 = INT32_MIN, cur1 = INT32_MIN;
-            uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
-            for (uint32_t j = jb; j <= je; ++j) {
-                int rank = INT32_MAX, t = 0, p = 0;
-                if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : (tw ? e.y : e.z); p = e.w; }   // float timestamps: the memory holds the event's RANK
-#pragma unroll
-                for (int q = 0; q < (CM / 2); ++q) {
-                    if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
-                }
-                if (j < je) {
-                    if (premap & 1) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
-                    if (p & 1) cur1 = t; else cur0 = t;
-                }
-            }
-            // pass 2
+        // pass 2 of a pixel: the slices' values from the timestamp memory each cut saw (snap: INT32_MIN = never written)
+        auto pass2 = [&](const int(&snap0)[(CM / 2)], const int(&snap1)[(CM / 2)], auto get, OutT(&vals)[CM]) {
 #pragma unroll
             for (int q = 0; q < (CM / 2); ++q) {
                 OutT v0 = bg[2 * q], v1 = bg[2 * q + 1];
@@ -1961,6 +1993,54 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv,
                 vals[2 * q + 1] = v1;
             }
         };
+        auto reduce = [&](uint32_t jb, uint32_t je, auto get, OutT(&vals)[CM]) {
+            // pass 1 (integers only): the timestamp memory of this pixel as each cut sees it, per polarity -- the record
+            // index of the last event (factorised form) or its timestamp.  INT32_MIN = never written.  Slices cut strictly
+            // before an event see the memory as it stands before it.
+            int snap0[(CM / 2)], snap1[(CM / 2)];
+#pragma unroll
+            for (int q = 0; q < (CM / 2); ++q) { snap0[q] = INT32_MIN; snap1[q] = INT32_MIN; }
+            int cur0 = INT32_MIN, cur1 = INT32_MIN;
+            uint32_t done = 0;  // bit q: slice q has taken its snapshot (all indexing stays compile-time: no scratch)
+            for (uint32_t j = jb; j <= je; ++j) {
+                int rank = INT32_MAX, t = 0, p = 0;
+                if (j < je) { const Rec e = get(j); rank = e.y; t = fact ? (int)j : (tw ? e.y : e.z); p = e.w; }   // float timestamps: the memory holds the event's RANK
+#pragma unroll
+                for (int q = 0; q < (CM / 2); ++q) {
+                    if (q < S && !((done >> q) & 1u) && cu.idx[q] < rank) { snap0[q] = cur0; snap1[q] = cur1; done |= 1u << q; }
+                }
+                if (j < je) {
+                    if (premap & 1) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);  // ((p+1)/2).astype(int8)
+                    if (p & 1) cur1 = t; else cur0 = t;
+                }
+            }
+            pass2(snap0, snap1, get, vals);
+        };
+        if (u.part == -4) {   // wave-uniform: the unit was visited, not ordered: one lane per pixel, straight from the visit words
+            constexpr int V = 16 / (int)sizeof(OutT);
+            const bool vec = (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+            w.pace();
+            for (int pt = 0; pt * kWave < g.npix; ++pt) {
+                const int np = min(kWave, g.npix - pt * kWave);
+                const uint32_t px = (uint32_t)(pt * kWave + (int)threadIdx.x);
+                int snap0[(CM / 2)], snap1[(CM / 2)];
+#pragma unroll
+                for (int q = 0; q < (CM / 2); ++q) {
+                    snap0[q] = INT32_MIN; snap1[q] = INT32_MIN;
+                    if (q < S && (int)threadIdx.x < np) {
+                        const uint32_t w0 = vw[(px * 2u) * (uint32_t)S + (uint32_t)q], w1 = vw[(px * 2u + 1u) * (uint32_t)S + (uint32_t)q];
+                        // the memory holds the event's timestamp (its RANK with float timestamps, as in reduce)
+                        if (w0) snap0[q] = tw ? (int)(w0 >> 9) - 1 : ((w0 & 511u) != 511u ? vt[w0 & 511u] : evw[(w0 >> 9) - 1u].z);
+                        if (w1) snap1[q] = tw ? (int)(w1 >> 9) - 1 : ((w1 & 511u) != 511u ? vt[w1 & 511u] : evw[(w1 >> 9) - 1u].z);
+                    }
+                }
+                OutT vals[CM];
+                pass2(snap0, snap1, [](uint32_t) -> Rec { return make_int4(0, 0, 0, 0); }, vals);
+                if ((int)threadIdx.x < np) store_pixel<OutT, CM>(dst + ((size_t)pt * kWave + threadIdx.x) * C, vals, C, vec);
+            }
+            w.mark(5);
+            return;
+        }
         emit_chunk<OutT, CM, HOT>(u, digest, [](const Rec &r) -> Rec { return r; }, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
     });
 }

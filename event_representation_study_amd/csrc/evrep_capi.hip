@@ -566,6 +566,7 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
     // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
     // when ITS unit is fully staged, whatever the binning pass (Gen1 shape 88 -> 80 us)
     const bool ts_fact = (double)plan->max_events_per_window <= kDeepStageMinPerUnit * (double)plan->H * plan->nchunk;
+    bool hot_launch = false;
     if (out_dtype == EVREP_F64) {
         const UnitCfg uc = unit_cfg(plan, (size_t)1 << 20, 0, false, false);  // one-chunk units whatever the slice count
 #define TS_LAUNCH_F(T, CM, F, GRID, SEG)                                                                             \
@@ -573,10 +574,14 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
         bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, uc, slices, tau, premap, scale, tf,   \
         static_cast<T *>(out))
     // the hot launch always takes its exponentials per slice: a unit beyond the stage does so under every binning pass
+    // (no hot launch, and no flip of the hot lists, when every unit beyond the record stage can be VISITED instead of ordered:
+    // 2 * slices words per pixel of the unit fit the part tile -- unit_records, Visit: the float64 surfaces)
 #define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
     do {                                                                                                             \
+        hot_launch = plan->reserved == 2 &&                                                                          \
+                     (size_t)(SEG) * 2 * slices * 4 > align16((size_t)kPartPx * 2 * slices * sizeof(T));                          \
         if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG);                  \
-        if (plan->reserved == 2) k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
+        if (hot_launch) k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
             bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, hot_cfg(uc), slices, tau, premap,  \
             scale, tf, static_cast<T *>(out));                                                                           \
     } while (0)
@@ -588,7 +593,7 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
     }
 #undef TS_LAUNCH
 #undef TS_LAUNCH_F
-    hot_flip(plan);
+    if (hot_launch) hot_flip(plan);
     LAUNCH_CHECK("k_time_surface");
     return EVREP_OK;
 }
