@@ -53,6 +53,15 @@ def _builders(eb, rng_seed=0):
     # the float-time TORE of n_imagenet, an explicit ev-licious time range, the raw-polarity EventStack, the EST layer
     tf = (torch.arange(eb.total, dtype=torch.float64) * 1e-6).to("cuda:0")  # any per-event float64 times: gathered by rank
     out["tore_ftime"] = eb.tore(5, frame_mode=2, times_f64=tf)
+    # ToTimesurface with the caller's indices: integer timestamps, the caller's float64 times, the array-order scan (premap + 2)
+    # and 8 slices -- units beyond the record stage are VISITED after the key-sorted pass (r04), ordered after the classic ones
+    oh = np.asarray(eb.offsets_host, dtype=np.int64)
+    n_of = oh[1:] - oh[:-1]
+    idx = torch.tensor(np.stack([(n_of * (s + 1)) // 5 for s in range(4)], axis=1).astype(np.int32))
+    out["ts_idx"] = eb.time_surface(4, tau=20000.0, indices=idx)
+    out["ts_ftime"] = eb.time_surface(4, tau=0.02, indices=idx, times_f64=tf)
+    out["ts_array_order"] = eb.time_surface(4, tau=20000.0, premap=3, indices=idx)
+    out["ts_8"] = eb.time_surface(8, tau=30000.0)
     tr = torch.tensor([[1000, 30000]] * eb.B, dtype=torch.int64)
     out["voxel_range"] = eb.voxel(4, mode=2, t_range=tr)
     out["event_stack_raw"] = eb.event_stack(7, premap=False)

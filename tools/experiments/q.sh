@@ -1,7 +1,3 @@
 #!/bin/bash
-for i in 1 2; do
-echo prev; EVREP_LIB_PATH=tools/variants/libevrep_prev.so timeout 300 python tools/experiments/pacing.py ts64 3 0 2>&1 | grep -v "amdgpu\|#"
-echo new; timeout 300 python tools/experiments/pacing.py ts64 3 0 2>&1 | grep -v "amdgpu\|#"
-echo prev; EVREP_LIB_PATH=tools/variants/libevrep_prev.so timeout 300 python tools/experiments/pacing.py ts64_1mpx 3 0 2>&1 | grep -v "amdgpu\|#"
-echo new; timeout 300 python tools/experiments/pacing.py ts64_1mpx 3 0 2>&1 | grep -v "amdgpu\|#"
-done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
