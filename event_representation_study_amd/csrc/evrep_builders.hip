@@ -318,6 +318,13 @@ __device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
 constexpr int kHotStage = EVREP_HOT_STAGE;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
 constexpr int kHotGrid = EVREP_HOT_GRID;    // workgroups of a hot launch
 constexpr int kHotParts = 8;      // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
+// A hot item's PIECE code: 0..7 = the 64-pixel part p; 8 + 4 p + s = the s-th 16-pixel quarter of part p.  A part of more
+// records than a hot wave's stage holds is deferred as four quarters (r04b): its placement and its walks -- both chains as long
+// as the part's longest pixel and its records -- split four ways, and a quarter's records mostly fit the stage (LDS walks)
+// where the part's did not (walks through the register ring).  item = uid * kHotCodes + code.
+constexpr int kHotCodes = 64;
+__device__ inline int piece_px0(int code) { return code < kHotParts ? code * kWave : ((code - kHotParts) >> 2) * kWave + ((code - kHotParts) & 3) * (kWave / 4); }
+__device__ inline int piece_npx(int code) { return code < kHotParts ? kWave : kWave / 4; }
 // Each of the two lists is kHotLists SUBLISTS with a counter of its own, 64 bytes apart: a clustered batch defers ten thousand
 // units, and device-scope atomics on ONE address retire at ~12 ns each (120 us of a 150 us launch, measured); a unit goes to
 // the sublist its id hashes to.  A sublist holds four times its fair share; a full one sends the unit to the next.
@@ -335,25 +342,32 @@ __device__ inline void run_units(const BinView &bv, Body body) {
         const uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
         for (uint32_t it = blockIdx.x / kHotLists; it < n; it += gridDim.x / kHotLists) {
             const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
-            if (item >= 0) body(item / kHotParts, item % kHotParts);   // (< 0: the unused tail of a sublist that filled up)
+            if (item >= 0) body(item / kHotCodes, item % kHotCodes);   // (< 0: the unused tail of a sublist that filled up)
             wave_phase();
         }
     }
 }
-// main launch: the `nparts` 64-pixel parts of unit `uid` go to the hot list
-__device__ inline void defer_unit(const BinView &bv, int uid, int nparts) {
+// main launch: the `nparts` 64-pixel parts of unit `uid` go to the hot list, the parts of `splitmask` as four quarters each
+__device__ inline void defer_unit(const BinView &bv, int uid, int nparts, uint32_t splitmask) {
     const uint32_t capl = hot_sublist_cap(bv.hot_cap);
+    // lane 4 p + s: quarter s of part p (a part that is not split: s == 0 stands for the whole part)
+    const int lane = threadIdx.x, p = lane >> 2, sq = lane & 3;
+    const bool split = (splitmask >> p) & 1u;
+    const bool active = p < nparts && (split || sq == 0);
+    const uint64_t am = __ballot(active);
+    const uint32_t nitems = (uint32_t)__popcll(am), pos = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+    const uint32_t code = split ? (uint32_t)(kHotParts + 4 * p + sq) : (uint32_t)p;
     uint32_t l = ((uint32_t)uid * 0x9E3779B1u) >> 26;
     for (int tries = 0; tries < kHotLists; ++tries, l = (l + 1) % kHotLists) {   // (wave-uniform)
         uint32_t at = 0;
-        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[(bv.hot_sel * kHotLists + l) * 16], (uint32_t)nparts);
+        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[(bv.hot_sel * kHotLists + l) * 16], nitems);
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
         uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
-        if (at + (uint32_t)nparts <= capl) {
-            if ((int)threadIdx.x < nparts) items[at + threadIdx.x] = (uint32_t)(uid * kHotParts + (int)threadIdx.x);
+        if (at + nitems <= capl) {
+            if (active) items[at + pos] = (uint32_t)uid * (uint32_t)kHotCodes + code;
             return;
         }
-        if (at + threadIdx.x < capl && (int)threadIdx.x < nparts) items[at + threadIdx.x] = 0xffffffffu;   // the sublist is full
+        if (active && at + pos < capl) items[at + pos] = 0xffffffffu;   // the sublist is full
     }
 }
 
@@ -592,7 +606,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     // prefetch ring (emit_part).  Four-record batches in a main launch: its register budget is the sparse paths'.
     // the pixels this wave sorts, in pixels of the unit: output pixel o = unit pixel o + (segbase - keybase)
     const int dpx = segbase - keybase;
-    const int plo = HOT ? part * kWave + dpx : 0, phi = HOT ? min(part * kWave + kWave, npix_out) + dpx : npixu;
+    const int plo = HOT ? piece_px0(part) + dpx : 0, phi = HOT ? min(piece_px0(part) + piece_npx(part), npix_out) + dpx : npixu;
     u.part = HOT ? part : -2;   // -2: a main launch's unit in its spill slot, -3: in the hot stage (emit_chunk)
     constexpr int kSpillBatch = HOT ? 16 : 4;
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
@@ -765,16 +779,21 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const bool in_lds = !HOT && nrec <= (uint32_t)w.bigcap;   // wave-uniform
     if (!HOT && !in_lds) {
         bool fits = true;   // wave-uniform: every 64-pixel part of the output fits the hot stage
+        uint32_t splitmask = 0u;   // parts beyond a HOT wave's stage (tile + kHotStage records): deferred as quarters
         for (int o0 = 0; o0 < npix_out; o0 += kWave) {
             const int lo = o0 + dpx, hi = min(o0 + kWave, npix_out) + dpx;
             const uint32_t b0 = lo < npixu ? cnt[lo] : nrec, b1 = hi < npixu ? cnt[hi] : nrec;
             fits = fits && b1 - b0 <= (uint32_t)(EVREP_DEFER_MULT * w.bigcap);
+            if (b1 - b0 > (uint32_t)(w.bigcap - w.nstage + kHotStage)) splitmask |= 1u << (o0 / kWave);
         }
+#ifdef EVREP_NO_QUARTERS
+        splitmask = 0u;
+#endif
 #ifdef EVREP_NO_DEFER
         fits = true;
 #endif
         if (!fits) {
-            defer_unit(bv, uid, (npix_out + kWave - 1) / kWave);
+            defer_unit(bv, uid, (npix_out + kWave - 1) / kWave, splitmask);
             u.deferred = true;
             u.ce = nrec;
             return u;
@@ -1185,7 +1204,9 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     constexpr bool HOT = true;
     const int lane = threadIdx.x;
     const uint32_t cap = (uint32_t)w.bigcap;
-    const int np = min(kWave, npix - part * kWave);
+    const int px0 = piece_px0(part);   // `part` = the item's piece code (a 64-pixel part or a 16-pixel quarter of one)
+    const int np = min(piece_npx(part), npix - px0);
+    if (np <= 0) return;   // (a quarter beyond the row's end)
     const bool mine = en > st && lane < np;
     const uint32_t ra = (uint32_t)wave_min(mine ? (int)st : INT32_MAX), rb = (uint32_t)wave_max(mine ? (int)en : 0);
     auto ld = [&](uint32_t j) -> Rec {
@@ -1248,7 +1269,7 @@ __device__ inline void emit_part(const Rec *__restrict__ stream, uint32_t nrec, 
     }
     wave_phase();
     if (part == 0) w.pace();
-    tile_store(w.tile, np * C, dst + (size_t)part * kWave * C);
+    tile_store(w.tile, np * C, dst + (size_t)px0 * C);
     w.mark(5);
 }
 
