@@ -610,6 +610,28 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     u.part = HOT ? part : -2;   // -2: a main launch's unit in its spill slot, -3: in the hot stage (emit_chunk)
     constexpr int kSpillBatch = HOT ? 16 : 4;
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
+    if constexpr (HOT) {
+        // The unit's MAIN wave has laid its records out in the unit's slot, pixel-sorted (r04c; until then every hot wave
+        // sorted its part out of the unit's records itself: two sweeps over ALL of them per piece, ~5 000 of a piece's ~7 000
+        // instructions -- and the hot launch is bound by VALU throughput).  Lane l finds the records of its pixel by two
+        // 11-step binary searches over the slot's pixel ids: dependent L2 round trips, which the other waves of the SIMD hide.
+        const Rec *slot = bv.spill + cs;
+        const int px = plo + lane;
+        const bool own = px >= 0 && px < phi && px < npixu;
+        uint32_t lo0 = 0, hi0 = nrec, lo1 = 0, hi1 = nrec;   // first record with pixel id >= key / >= key + 1
+        const int key = keybase + px;
+        while (__any(own && (lo0 < hi0 || lo1 < hi1))) {
+            if (own && lo0 < hi0) { const uint32_t mid = (lo0 + hi0) >> 1; if (slot[mid].x < key) lo0 = mid + 1; else hi0 = mid; }
+            if (own && lo1 < hi1) { const uint32_t mid = (lo1 + hi1) >> 1; if (slot[mid].x <= key) lo1 = mid + 1; else hi1 = mid; }
+        }
+        w.mark(3);
+        u.pst = own ? lo0 : 0u; u.pen = own ? lo1 : 0u;
+        u.hot_lds = false;
+        u.cs = cs; u.ce = cs + nrec;
+        u.nstaged = 0;
+        u.dpx = dpx; u.npixu = npixu;
+        return u;
+    }
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase();
     // The sweeps go RUN BY RUN: a batch is up to 64 consecutive records of ONE block run -- address = the run's first record of
@@ -754,7 +776,6 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         // the whole unit in ONE round: the placement below finds it still in the registers
         if (sweep_done()) { resident = round == 0; break; }
     }
-    if constexpr (HOT) w.mark(2);   // timing builds: the count sweep is done
     wave_phase();
     {
         uint32_t local = 0;
@@ -777,6 +798,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     wave_phase();
     // a main launch keeps a unit that fits the hot stage (tile + record stage) in LDS altogether: no slot, no second trip
     const bool in_lds = !HOT && nrec <= (uint32_t)w.bigcap;   // wave-uniform
+    bool defer = false;
+    uint32_t defer_mask = 0u;
     if (!HOT && !in_lds) {
         bool fits = true;   // wave-uniform: every 64-pixel part of the output fits the hot stage
         uint32_t splitmask = 0u;   // parts beyond a HOT wave's stage (tile + kHotStage records): deferred as quarters
@@ -792,29 +815,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #ifdef EVREP_NO_DEFER
         fits = true;
 #endif
-        if (!fits) {
-            defer_unit(bv, uid, (npix_out + kWave - 1) / kWave, splitmask);
-            u.deferred = true;
-            u.ce = nrec;
-            return u;
-        }
-    }
-    // lane l owns pixel plo + l of the part: its segment [pst, pen) of the unit's pixel-sorted order, read before the
-    // placement moves the cursors
-    uint32_t pst = 0, pen = 0;
-    if constexpr (HOT) {
-        const int px = plo + lane;
-        if (px >= 0 && px < phi && px < npixu) { pst = cnt[px]; pen = px + 1 < npixu ? cnt[px + 1] : nrec; }
-    }
-    // a hot wave whose part fits its stage (tile + record stage) places the part straight there: no scattered 16-byte stores
-    // into the slot, no trip through it (timing build, Gen1 circle: the placement into the slot was 30 of a 71 us item)
-    uint32_t hra = 0;
-    bool hot_lds = false;
-    if constexpr (HOT) {
-        const bool hm = pen > pst;
-        hra = (uint32_t)wave_min(hm ? (int)pst : INT32_MAX);
-        const uint32_t hrb = (uint32_t)wave_max(hm ? (int)pen : 0);
-        hot_lds = hrb > hra && hrb - hra <= (uint32_t)w.bigcap;   // wave-uniform
+        defer = !fits;   // (deferred AFTER the placement below: the hot waves read the unit from its slot)
+        defer_mask = splitmask;
     }
     wave_phase();
     volatile uint32_t *vcnt = cnt;
@@ -833,7 +835,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             if (valid) {
                 pos = vcnt[px] + rk;
                 const Rec rec = rec8_unpack(q[sl], row_base, c0, evw);
-                if (in_lds) *w.big_at(pos) = rec; else if (hot_lds) *w.big_at(pos - hra) = rec; else bv.spill[cs + pos] = rec;
+                if (in_lds) *w.big_at(pos) = rec; else bv.spill[cs + pos] = rec;
             }
             __builtin_amdgcn_wave_barrier();
             if (valid && last) vcnt[px] = pos + 1;
@@ -841,10 +843,15 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         }
     }
     wave_phase();
-    if constexpr (HOT) w.mark(3);   // timing builds: the part's records lie in the slot
-    u.pst = pst; u.pen = pen;   // hot launch: the lane's segment; a main launch reads the cursors (now every pixel's END) per part
+    if (defer) {   // wave-uniform: a part beyond this wave's stage -- the unit's pieces go to the hot launch, which finds them in the slot
+        defer_unit(bv, uid, (npix_out + kWave - 1) / kWave, defer_mask);
+        u.deferred = true;
+        u.ce = nrec;
+        return u;
+    }
+    u.pst = 0; u.pen = 0;   // (a main launch reads the cursors -- now every pixel's END -- per part)
     if (in_lds) u.part = -3;
-    u.hot_lds = hot_lds;
+    u.hot_lds = false;
     // the wave reads back what its own lanes stored: same CU, same vector L1 -- workgroup-scope release / acquire
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
