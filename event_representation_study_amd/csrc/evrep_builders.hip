@@ -307,8 +307,9 @@ __device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
 // clear the list it reads (a workgroup that is late would find it empty) without a count of the workgroups that are done --
 // one device-scope atomic per workgroup, 12 ns each on one address: 25 us per launch, measured -- so it clears the OTHER
 // list, which nothing touches while it runs and which the next call's main launch appends to.  The binning pass clears both.
-// A hot item is ONE 64-pixel part of a unit (id * 8 + part): the wave sorts the part's records out of the unit's, stages and
-// walks them with one lane per pixel -- half the latency chain of a whole 128-pixel unit, twice the waves to spread.
+// A hot item is ONE piece of a unit (a 64-pixel part or a quarter of one, below).  The unit's main wave has laid the unit out,
+// pixel-sorted, in its spill slot before deferring it (r04c); the hot wave finds its pixels' records there by binary search,
+// stages and walks them with one lane per pixel.
 #ifndef EVREP_HOT_STAGE
 #define EVREP_HOT_STAGE 256
 #endif
@@ -319,9 +320,9 @@ constexpr int kHotStage = EVREP_HOT_STAGE;    // records of a hot wave's LDS sta
 constexpr int kHotGrid = EVREP_HOT_GRID;    // workgroups of a hot launch
 constexpr int kHotParts = 8;      // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
 // A hot item's PIECE code: 0..7 = the 64-pixel part p; 8 + 4 p + s = the s-th 16-pixel quarter of part p.  A part of more
-// records than a hot wave's stage holds is deferred as four quarters (r04b): its placement and its walks -- both chains as long
-// as the part's longest pixel and its records -- split four ways, and a quarter's records mostly fit the stage (LDS walks)
-// where the part's did not (walks through the register ring).  item = uid * kHotCodes + code.
+// records than a hot wave's stage holds is deferred as four quarters (r04b): its walks -- a chain as long as the part's longest
+// pixel -- split four ways, and a quarter's records mostly fit the stage (LDS walks) where the part's did not (walks through
+// the register ring).  item = uid * kHotCodes + code.
 constexpr int kHotCodes = 64;
 __device__ inline int piece_px0(int code) { return code < kHotParts ? code * kWave : ((code - kHotParts) >> 2) * kWave + ((code - kHotParts) & 3) * (kWave / 4); }
 __device__ inline int piece_npx(int code) { return code < kHotParts ? kWave : kWave / 4; }
@@ -601,9 +602,10 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     // took one dependent L2 round trip per 64 records, twice); a unit of up to 1024 records is fetched once.
     // A MAIN launch (r04b) sorts the whole unit and emits it part by part from the slot (emit_parts_main) -- such a wave is
     // bound by latency and arithmetic and runs beside the frame's store-bound waves for free, which a separate launch cannot
-    // -- unless one of its 64-pixel parts holds more records than the hot stage (tile + record stage): then the unit's parts
-    // go to the builder's HOT launch, whose waves each sort ONE part out of the unit's records and have the registers for the
-    // prefetch ring (emit_part).  Four-record batches in a main launch: its register budget is the sparse paths'.
+    // -- unless one of its 64-pixel parts holds more records than the hot stage (tile + record stage): then the unit, sorted
+    // into its slot all the same, has its parts appended to the hot list, and the waves of the builder's HOT launch -- which have
+    // the registers for the prefetch ring (emit_part) -- each emit ONE piece of it out of the slot.  Four-record batches in a
+    // main launch: its register budget is the sparse paths'.
     // the pixels this wave sorts, in pixels of the unit: output pixel o = unit pixel o + (segbase - keybase)
     const int dpx = segbase - keybase;
     const int plo = HOT ? piece_px0(part) + dpx : 0, phi = HOT ? min(piece_px0(part) + piece_npx(part), npix_out) + dpx : npixu;

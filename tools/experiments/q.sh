@@ -1,4 +1,5 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 300 python tools/fuzz_campaign.py 700000 120 2>&1 | tail -2
-FUZZ_BIG=1 timeout 300 python tools/fuzz_campaign.py 800000 150 2>&1 | tail -2
+T="gen1@circle gen1@edges c2@circle c3@circle c3@edges c2-250k c2-dense"
+B="b=optimized_f64 b=optimized_f32 b=voxel5_f64 b=tore_full_frame_f32 b=nimagenet_acc_all_f32"
+echo "--- base"; timeout 600 python tools/sweep_table.py $T $B
+echo "--- defer0"; EVREP_LIB_PATH=tools/variants/defer0.so timeout 600 python tools/sweep_table.py $T $B
