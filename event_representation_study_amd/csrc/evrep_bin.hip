@@ -740,11 +740,15 @@ __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__rest
         for (uint32_t t = threadIdx.x; t < total; t += kBsThreads) dst[t] = stage[t];
 }
 
-// grid (ceil(H / kCsWaves), B), 256 threads = kCsWaves independent waves (no block barrier), one sensor row each;
+// grid (ceil(H / kCsWaves), B), kCsWaves * 64 threads = kCsWaves independent waves (no block barrier), one sensor row each;
 // dynamic LDS = kCsWaves * col_sort_wave_words(W) * 4.  A lane reads the row's offsets in TWO block runs (lane and
 // lane + 64): up to kCsMaxRuns = 128 runs per window, 1 048 576 events with 8192-event blocks.
 // (Several rows per wave, with all their fetches in flight together, were slower: R = 2, 4 measured in round 2.)
-constexpr int kCsWaves = 4;
+#ifndef EVREP_CS_WAVES
+#define EVREP_CS_WAVES 8   // 8 keys per workgroup share the table and record lines in one CU's L1: 4 x 10^6-event windows at 1280x720 bin in 88 us (4: 97)
+#endif
+constexpr int kCsWaves = EVREP_CS_WAVES;   // by key (128 column counters per wave)
+constexpr int kCsRowWaves = 4;             // by row (W column counters per wave: the workgroup's LDS grows with the sensor width)
 constexpr int kCsMaxRuns = 128;
 __host__ __device__ inline int col_sort_per4(int W) { return ((W + kWave - 1) / kWave + 3) / 4; }
 __host__ __device__ inline int col_sort_words(int W) { return kWave * 4 * col_sort_per4(W); }  // per-wave counter array
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_waves_per_e
     // windows want (a 1280-pixel row of a 10^6-event window holds ~1400 records: six register batches walked twice).
     extern __shared__ __align__(16) uint32_t cnt_all[];  // [kCsWaves][col_sort_wave_words(unit width)]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, unit = blockIdx.x * kCsWaves + wave;
+    const int b = blockIdx.y, unit = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // (the row form is launched with kCsRowWaves waves)
     if (unit >= (by_key ? H * kpr : H)) return;
     const int row = by_key ? unit / kpr : unit;
     const int ck = by_key ? unit - row * kpr : 0;

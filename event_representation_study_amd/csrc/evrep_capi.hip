@@ -335,8 +335,8 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         k_block_rowsort<<<xgrid, kBsThreads, lds, stream>>>(ev, offsets, B, H, W, nblk, table, stats, s1);
         LAUNCH_CHECK("k_block_rowsort");
         if (BS_DEBUG & 15) return EVREP_OK;  // timing experiments: the run table may be garbage
-        constexpr int rows_per_wg = kCsWaves;
-        k_col_sort_runs<<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsWaves * kWave, (size_t)kCsWaves * col_sort_wave_words(W) * 4, stream>>>(
+        constexpr int rows_per_wg = kCsRowWaves;
+        k_col_sort_runs<<<dim3((H + rows_per_wg - 1) / rows_per_wg, B), kCsRowWaves * kWave, (size_t)kCsRowWaves * col_sort_wave_words(W) * 4, stream>>>(
             ev, s1, offsets, table, stats, H, W, nblk, plan->nchunk, 1, 13, 0, s2, WS(uint32_t, off_chunkoff), meta);
         LAUNCH_CHECK("k_col_sort_runs");
         return EVREP_OK;

@@ -1,5 +1,6 @@
 #!/bin/bash
-T="gen1@circle gen1@edges c2@circle c3@circle c3@edges c2-250k c2-dense"
-B="b=optimized_f64 b=optimized_f32 b=voxel5_f64 b=tore_full_frame_f32 b=nimagenet_acc_all_f32"
-echo "--- base"; timeout 600 python tools/sweep_table.py $T $B
-echo "--- defer0"; EVREP_LIB_PATH=tools/variants/defer0.so timeout 600 python tools/sweep_table.py $T $B
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+export SWEEP_SHAPES="c2-1M:640,480,1000000,4;wide:2048,256,400000,8;tall:256,1024,200000,8"
+timeout 600 python tools/sweep_table.py c3-1M c2-1M wide tall b=event_stack_f32
+FUZZ_BIG=1 timeout 300 python tools/fuzz_campaign.py 900000 120 2>&1 | tail -2
+timeout 300 python tools/fuzz_campaign.py 910000 60 2>&1 | tail -2
