@@ -62,3 +62,37 @@ def test_one_hot_pixel_window(oracle):
         assert_bit_equal(eb.optimized()[0].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 hot pixel %s" % name)
         assert_bit_equal(eb.event_stack()[0].cpu().numpy(), oracle.event_stack(ev, H, W), "event_stack hot pixel %s" % name)
         np.testing.assert_allclose(eb.time_surface()[0].cpu().numpy(), oracle.time_surface(ev, H, W), rtol=1e-12)
+
+
+def test_order_free_units_with_odd_polarities_and_small_stacks():
+    """EventStack / ToTimesurface units beyond the record stage are not ordered after the key-sorted pass (one atomicMax word
+    per pixel / per pixel, polarity class and slice): polarity values outside {-1, 0, 1} (escaped in the 8-byte records),
+    stacks too small for the survivors to fit (the ordered paths and the hot launch take over), 8 slices, float32 surfaces --
+    bit for bit against the classic pass, whose builders walk an ordered stream."""
+    import torch
+    from event_representation_study_amd import engine as eng
+    W, H, N = 304, 240, 60000
+    wins = []
+    for i in range(2):
+        ev = GENERATORS["circle"](N, W, H, seed=40 + i, polarity="pm1")
+        rng = np.random.default_rng(70 + i)
+        odd = rng.random(N) < 0.1
+        ev[odd, 3] = rng.choice(np.array([-2, 3, 0, 7], dtype=np.int32), size=int(odd.sum()))
+        k = rng.integers(0, N, size=N // 4)            # a hot unit: a quarter of the window in 90 pixels of one row
+        ev[k, 0] = rng.integers(100, 190, size=len(k)); ev[k, 1] = 77 + i
+        wins.append(ev)
+    ks = _batch(eng, wins, H, W, PASSES["key_sorted"])
+    cl = _batch(eng, wins, H, W, PASSES["classic"])
+    assert ks.plan.reserved == 2 and cl.plan.reserved in (0, 1)
+    n_of = np.array([len(w) for w in wins], dtype=np.int64)
+    idx = np.stack([(n_of * (s + 1)) // 9 for s in range(8)], axis=1).astype(np.int32)
+    for tag, fn in {
+        "stack 12": lambda eb: eb.event_stack(),
+        "stack 3 (survivors do not fit the stage)": lambda eb: eb.event_stack(3),
+        "stack 16 raw polarity": lambda eb: eb.event_stack(16, premap=False),
+        "surface": lambda eb: eb.time_surface(),
+        "surface, 8 slices, caller's cuts": lambda eb: eb.time_surface(8, tau=30000.0, indices=idx),
+        "surface float32 (ordered paths)": lambda eb: eb.time_surface(dtype=torch.float32),
+        "surface, raw polarity": lambda eb: eb.time_surface(premap=False),
+    }.items():
+        assert_bit_equal(fn(ks).cpu().numpy(), fn(cl).cpu().numpy(), tag)
