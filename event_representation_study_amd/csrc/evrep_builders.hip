@@ -610,7 +610,10 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     const int dpx = segbase - keybase;
     const int plo = HOT ? piece_px0(part) + dpx : 0, phi = HOT ? min(piece_px0(part) + piece_npx(part), npix_out) + dpx : npixu;
     u.part = HOT ? part : -2;   // -2: a main launch's unit in its spill slot, -3: in the hot stage (emit_chunk)
-    constexpr int kSpillBatch = HOT ? 16 : 4;
+#ifndef EVREP_MAIN_SPILL_BATCH
+#define EVREP_MAIN_SPILL_BATCH 4
+#endif
+    constexpr int kSpillBatch = HOT ? 16 : EVREP_MAIN_SPILL_BATCH;
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
     if constexpr (HOT) {
         // The unit's MAIN wave has laid its records out in the unit's slot, pixel-sorted (r04c; until then every hot wave
