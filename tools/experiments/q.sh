@@ -1,5 +1,4 @@
 #!/bin/bash
-T="c2 gen1@circle c2@circle c3@circle c3@edges c2-250k c2-dense"
-B="b=optimized_f64 b=optimized_f32 b=voxel5_f64 b=tore_full_frame_f32 b=nimagenet_acc_all_f32"
-echo "--- base"; timeout 600 python tools/sweep_table.py $T $B
-echo "--- sb8"; EVREP_LIB_PATH=tools/variants/sb8.so timeout 600 python tools/sweep_table.py $T $B
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-700
