@@ -1,4 +1,3 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-700
+timeout 400 python tools/fuzz_campaign.py 1000000 300 2>&1 | tail -2
+FUZZ_BIG=1 timeout 400 python tools/fuzz_campaign.py 1100000 300 2>&1 | tail -2
