@@ -474,10 +474,57 @@ struct UnitVisit { static constexpr bool enabled = true; F f; int words_per_px; 
 template <typename F>
 __device__ inline UnitVisit<F> unit_visit(F f, int words_per_px) { return UnitVisit<F>{f, words_per_px}; }
 
-template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit>
+// Split (r05): MOST of the builder's per-pixel result is an order-free function of the unit's records (ERGO-12: ten of twelve
+// channels are integer sums, counts, occupancy flags and maxima -- exact in any order), only a FEW records feed accumulators
+// that have to run in time order (float64 sums of normalised timestamps over one rank window and polarity class: a sixth of the
+// records each).  A unit beyond the record stage is then swept ONCE: split.f(pixel, record, entry) accumulates the record's
+// order-free part with LDS atomics on the builder's own words (split.words_per_px per pixel of the unit, at the bottom of the
+// wave's LDS, zeroed here) and says whether the record is KEPT for the ordered part; the kept records -- 8 bytes each, `entry`
+// -- are compacted, in sweep = time order, into a list behind the words and counted per pixel (w.segs).  The kernel orders the
+// list by pixel (a third of the records, out of LDS, no second trip through the block runs), walks it with one lane per pixel
+// and emits the unit from its registers (u.part == -5; u.pst = kept records, u.pen = the list's byte offset in the wave's LDS).
+// split.begin() is the builder's late set-up (wave-uniform; false: the unit takes the ordered paths); split.done() says whether
+// the sweep saw only records it could handle (else the unit takes the ordered paths, in this launch: a builder with a split path
+// defers nothing and has no hot launch).  Kept records beyond the list's room go to the unit's slot of the spill stream.
+struct NoSplit { static constexpr bool enabled = false; };
+template <typename Begin, typename F, typename Done>
+struct UnitSplit { static constexpr bool enabled = true; Begin begin; F f; Done done; int words_per_px; };
+template <typename Begin, typename F, typename Done>
+__device__ inline UnitSplit<Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px) { return UnitSplit<Begin, F, Done>{b, f, d, words_per_px}; }
+#ifndef EVREP_SPLIT_BATCHES
+#define EVREP_SPLIT_BATCHES 8
+#endif
+constexpr int kSplitBatches = EVREP_SPLIT_BATCHES;
+// kept records the LDS list holds: 8 bytes each between the builder's words and the pixel counters
+__device__ inline uint32_t split_list_cap(uint32_t room, uint32_t wbytes) { return min((room - wbytes) / 8u, (uint32_t)(kSplitBatches * kWave)); }   // kept records are ordered out of registers: at most 8 x 64 of them
+
+// exclusive scan over `npixu` (a multiple of 128) pixel counters in LDS: 16-byte vectors, `per4` consecutive ones per lane
+__device__ inline void scan_pixel_counters(uint32_t *cnt, int npixu) {
+    const int lane = threadIdx.x;
+    uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
+    const int per4 = npixu / (4 * kWave) + ((npixu % (4 * kWave)) ? 1 : 0);
+    uint32_t local = 0;
+    for (int k = 0; k < per4; ++k) {
+        const int v = lane * per4 + k;
+        if (v * 4 < npixu) { const uint4 c = cnt4[v]; local += c.x + c.y + c.z + c.w; }
+    }
+    uint32_t run = wave_incl_scan(local) - local;
+    for (int k = 0; k < per4; ++k) {
+        const int v = lane * per4 + k;
+        if (v * 4 < npixu) {
+            const uint4 c = cnt4[v];
+            uint4 o;
+            o.x = run; o.y = o.x + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
+            run = o.w + c.w;
+            cnt4[v] = o;
+        }
+    }
+}
+
+template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit, typename Split = NoSplit>
 __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__restrict__ off, int b, int NK, int klo, int khi,
                                         int keybase, int npixu, WaveLds<OutT, HOT> &w, int segbase, int c0, int uid,
-                                        int npix_out, int part, Visit visit = Visit()) {
+                                        int npix_out, int part, Visit visit = Visit(), Split split = Split()) {
     const int lane = threadIdx.x;
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
@@ -739,6 +786,54 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             return u;
         }
     }
+    if constexpr (Split::enabled && !HOT) {
+        const uint32_t room = (uint32_t)(reinterpret_cast<const unsigned char *>(w.segs) - reinterpret_cast<const unsigned char *>(w.tile));
+        const uint32_t wbytes = ((uint32_t)npixu * (uint32_t)split.words_per_px * 4u + 15u) & ~15u;
+        // 16-bit fields in the builder's words: a unit of up to 65 535 records.  (wave-uniform)
+        if (wbytes + 64u * 8u <= room && nrec <= 65535u && dpx == 0 && split.begin()) {
+            const uint32_t lcap = split_list_cap(room, wbytes);
+            uint4 *t4 = reinterpret_cast<uint4 *>(w.tile);
+            for (uint32_t v = (uint32_t)lane; v * 16u < wbytes; v += kWave) t4[v] = make_uint4(0u, 0u, 0u, 0u);
+            wave_phase();
+            // the kept records: the first `lcap` in the list behind the words, later ones (a hot unit) in the unit's own slot of
+            // the spill stream -- 16 bytes per record of the unit: the lower half takes the list, the upper half its ordered copy
+            uint2 *list = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(w.tile) + wbytes);
+            uint2 *glist = reinterpret_cast<uint2 *>(bv.spill + cs);
+            uint32_t nk = 0;
+            sweep_begin();
+            while (load_batch()) {
+#pragma unroll
+                for (int sl = 0; sl < kSpillBatch; ++sl) {
+                    if (bcnt[sl] == 0u) break;   // uniform
+                    bool keep = false;
+                    uint2 e = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < bcnt[sl]) keep = split.f(px_of(q[sl]), q[sl], e);
+                    const uint64_t km = __ballot(keep);
+                    if (km) {
+                        const uint32_t at = nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                        if (keep) {
+                            if (at < lcap) list[at] = e; else glist[at] = e;
+                            atomicAdd(&cnt[e.y], 1u);
+                        }
+                        nk += (uint32_t)__popcll(km);
+                    }
+                }
+                if (sweep_done()) break;
+            }
+            wave_phase();
+            if (split.done()) {   // wave-uniform
+                u.part = -5;
+                u.cs = cs; u.ce = cs + nrec;
+                u.nstaged = 0;
+                u.dpx = dpx; u.npixu = npixu;
+                u.pst = nk; u.pen = wbytes;
+                return u;
+            }
+            // the ordered paths after all: they count from zero
+            for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
+            wave_phase();
+        }
+    }
     if constexpr (LAST && !HOT) {
         if (npixu <= w.bigcap) {   // wave-uniform: the survivors fit the hot stage (always, for stacks of >= 8 levels)
             sweep_begin();
@@ -820,6 +915,9 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #ifdef EVREP_NO_DEFER
         fits = true;
 #endif
+        // a builder with a split path has no hot launch behind it: the few units that fall back here (escaped polarity values,
+        // more than 65 535 records) are emitted from their slot by this wave, whatever they hold
+        if constexpr (Split::enabled) fits = true;
         defer = !fits;   // (deferred AFTER the placement below: the hot waves read the unit from its slot)
         defer_mask = splitmask;
     }
@@ -897,14 +995,14 @@ __device__ inline void stage_classic(UnitRecs &u, WaveLds<OutT, HOT> &w) {
 
 // The front end of every tile builder: the unit's geometry and its pixel-sorted records, from either binning pass.
 // uid = the unit's id (run_units).  A main launch (HOT false) defers a unit of more records than its stage (u.deferred).
-template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit>
+template <typename OutT, bool HOT, bool LAST = false, typename Visit = NoVisit, typename Split = NoSplit>
 __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restrict__ off, int H, int W, int nchunk, const UnitCfg &uc,
-                                      WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part, Visit visit = Visit()) {
+                                      WaveLds<OutT, HOT> &w, ChunkGeom &g, int uid, int part, Visit visit = Visit(), Split split = Split()) {
     int chunk, nch;
     g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
     if (bv.fused) {
         const int klo = g.row * nchunk + chunk, khi = klo + nch;
-        const UnitRecs u = unit_records<OutT, HOT, LAST, Visit>(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part, visit);
+        const UnitRecs u = unit_records<OutT, HOT, LAST, Visit, Split>(bv, off, g.b, H * nchunk, klo, khi, g.row * W + g.c0, w.segcap, w, g.row * W + g.c0, g.c0, uid, g.npix, part, visit, split);
         g.cs = u.cs; g.ce = u.ce;
         return u;
     }
@@ -1534,54 +1632,342 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 
 // grid (nchunk, H, B), 64 threads; dynamic LDS = chunk_lds_bytes(C, sizeof(OutT)).
 // One unit of MixedDensityEventStack: the window's statistics -> per-channel set-up -> digest / reduce -> emit.
-template <typename OutT, typename D, bool HOT>
-__device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double scale, const UnitRecs &u, const ChunkGeom &g,
-                                      int64_t n_win, const WindowMeta &m, OutT *__restrict__ dst, WaveLds<OutT, HOT> &w) {
-    const int32_t tmin = m.tmin;
-    // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
-    const double interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
-    // "SBT": eight windows handed over as rank ranges (k_mdes_sbt_windows).  Never with the compile-time ERGO-12 descriptors;
-    // the loaded values are made wave-uniform explicitly (readfirstlane), or every per-channel bound below moves from the
-    // scalar to the vector registers (+25 VGPRs, an occupancy step).
-    const bool custom = D::kCustomWindows && P.bounds != nullptr;
-    MdesWindows mw = mdes_windows(n_win);
-    uint32_t neg_flags = m.neg_flags, oob_flags = m.oob_flags;
-    const int fstride = custom ? 8 : 7, wmax = custom ? 7 : 6;
-    if (custom) {
-        const int32_t *bw = P.bounds + (size_t)g.b * 16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            mw.lo[i] = __builtin_amdgcn_readfirstlane(bw[2 * i]);
-            mw.hi[i] = __builtin_amdgcn_readfirstlane(bw[2 * i + 1]);
-        }
-        neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * g.b]);
-        oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * g.b + 1]);
-    }
-    w.mark(1);
+//
+// The ERGO-12 split (r05, unit_records' Split): ten of the twelve channels need no time order --
+//   ch0  (w0, polarity, variance)       n, sum p, sum p^2: integers, exact in float64 in any order (p in {-1, 0, 1})
+//   ch3  (w6, polarity, sum), ch5 (w6, count, sum)                                     integer sums
+//   ch2, ch4, ch7, ch11 (count_* , mean)                                               1 iff the pixel holds such an event
+//   ch8, ch9, ch10 (timestamp_*, max)   max of the quotients = the quotient of the max (a correctly rounded division is monotone)
+// -- and are kept as seven 32-bit words per pixel, bumped by LDS atomics in ONE unordered sweep; only ch1 (w3, timestamp_neg,
+// variance) and ch6 (w2, timestamp_pos, mean) are float64 sums that have to run in time order, each over a sixth of the records
+// (one third of the ranks, one polarity class): those records are kept, ordered by pixel out of LDS and walked.  w2's ranks lie
+// in front of w3's, so a pixel's kept records are its ch6 records, then its ch1 records: the pixel's ch6 count is all the walk
+// needs to tell them apart.  Words of pixel px (7 px + k):
+//   0: ch0 #(p > 0) | #(p < 0) << 16      1: ch0 #(p == 0) | ch5 n << 16      2: ch3 #(p > 0) | #(p < 0) << 16
+//   3: bit 0 ch2, 1 ch4, 2 ch7, 3 ch11, 4 ch8 present, 5 ch10 present, 6 ch9 present | kept ch6 records << 16
+//   4, 5, 6: max (t - tmin) of ch8, ch9, ch10
+// A record of escaped polarity (p outside {-1, 0, 1}: sum p^2 may leave the integers float64 holds exactly) sends its unit to the
+// ordered paths.
+constexpr int kErgoSplitWords = 7;
+template <typename D> struct MdesIsErgo12 { static constexpr bool value = false; };
+template <> struct MdesIsErgo12<StaticDesc<Ergo12Table>> { static constexpr bool value = true; };
+static_assert(Ergo12Table::kWin[0] == 0 && Ergo12Table::kFunc[0] == EVREP_F_POLARITY && Ergo12Table::kAgg[0] == EVREP_A_VARIANCE &&
+              Ergo12Table::kWin[1] == 3 && Ergo12Table::kFunc[1] == EVREP_F_TIMESTAMP_NEG && Ergo12Table::kAgg[1] == EVREP_A_VARIANCE &&
+              Ergo12Table::kFunc[2] == EVREP_F_COUNT_NEG && Ergo12Table::kAgg[2] == EVREP_A_MEAN &&
+              Ergo12Table::kFunc[3] == EVREP_F_POLARITY && Ergo12Table::kAgg[3] == EVREP_A_SUM &&
+              Ergo12Table::kFunc[4] == EVREP_F_COUNT_POS && Ergo12Table::kAgg[4] == EVREP_A_MEAN &&
+              Ergo12Table::kFunc[5] == EVREP_F_COUNT && Ergo12Table::kAgg[5] == EVREP_A_SUM &&
+              Ergo12Table::kWin[6] == 2 && Ergo12Table::kFunc[6] == EVREP_F_TIMESTAMP_POS && Ergo12Table::kAgg[6] == EVREP_A_MEAN &&
+              Ergo12Table::kFunc[7] == EVREP_F_COUNT_NEG && Ergo12Table::kAgg[7] == EVREP_A_MEAN &&
+              Ergo12Table::kFunc[8] == EVREP_F_TIMESTAMP_NEG && Ergo12Table::kAgg[8] == EVREP_A_MAX &&
+              Ergo12Table::kFunc[9] == EVREP_F_TIMESTAMP_POS && Ergo12Table::kAgg[9] == EVREP_A_MAX &&
+              Ergo12Table::kFunc[10] == EVREP_F_TIMESTAMP && Ergo12Table::kAgg[10] == EVREP_A_MAX &&
+              Ergo12Table::kFunc[11] == EVREP_F_COUNT && Ergo12Table::kAgg[11] == EVREP_A_MEAN,
+              "mdes_unit's split path is written against these triples");
 
-    // per-channel uniform setup
+template <typename OutT, typename D, bool HOT>
+__device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ off, const MdesParams &P, int C, int H, int W,
+                                 int nchunk, const UnitCfg &uc, double scale, OutT *__restrict__ out, WaveLds<OutT, HOT> &w,
+                                 int uid, int part, int b0, int64_t n_win, const MetaRaw &mraw) {
+    // The window's statistics and the per-channel set-up are formed AFTER the unit's front end (their loads were issued in front
+    // of it: meta_prefetch), so that they are not a dependent step of every wave's latency chain.
+    int32_t tmin = 0;
+    double interval = 0.0;
     int lo[D::kMaxC], hi[D::kMaxC], want[D::kMaxC];
     bool active[D::kMaxC];
+    auto setup = [&]() {
+        const WindowMeta m = meta_finish(bv, off, b0, mraw);
+        tmin = m.tmin;
+        const int32_t tmax = m.tmax;
+        // t = t - t.min(); t_s = t / (t.max() - t.min())  (mixed_density_event_stack.py:33,112-114)
+        interval = (double)((int64_t)tmax - (int64_t)tmin);
+        // "SBT": eight windows handed over as rank ranges (k_mdes_sbt_windows).  Never with the compile-time ERGO-12 descriptors;
+        // the loaded values are made wave-uniform explicitly (readfirstlane), or every per-channel bound below moves from the
+        // scalar to the vector registers (+25 VGPRs, an occupancy step).
+        const bool custom = D::kCustomWindows && P.bounds != nullptr;
+        MdesWindows mw = mdes_windows(n_win);
+        uint32_t neg_flags = m.neg_flags, oob_flags = m.oob_flags;
+        const int fstride = custom ? 8 : 7, wmax = custom ? 7 : 6;
+        if (custom) {
+            const int32_t *bw = P.bounds + (size_t)b0 * 16;
 #pragma unroll
-    for (int c = 0; c < D::kMaxC; ++c) {
-        lo[c] = 0; hi[c] = 0; want[c] = kWantAny; active[c] = false;
-        if (c < C) {
-            const int wi = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
-            bool ok = wi >= 0 && wi <= wmax && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
-            int l = 0, h = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (wi == i) { l = mw.lo[i]; h = mw.hi[i]; }
-            int wn = kWantAny, field = 0;
-            if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { wn = 1; field = 1; }
-            if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
-                // rows with p == -1; if the window has none, rows with p == 0 (operations.py:59-61,78-80)
-                const bool has_neg = ok && ((neg_flags >> (wi & 7)) & 1u);
-                wn = has_neg ? -1 : 0;
-                field = has_neg ? 2 : 3;
+            for (int i = 0; i < 8; ++i) {
+                mw.lo[i] = __builtin_amdgcn_readfirstlane(bw[2 * i]);
+                mw.hi[i] = __builtin_amdgcn_readfirstlane(bw[2 * i + 1]);
             }
-            // an out-of-range index inside the selected rows raises in torch_scatter -> zero channel
-            if (ok && ((oob_flags >> (fstride * field + (wi & 7))) & 1u)) ok = false;
-            lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
+            neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * b0]);
+            oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.wflags[2 * b0 + 1]);
+        }
+        // per-channel uniform setup
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) {
+            lo[c] = 0; hi[c] = 0; want[c] = kWantAny; active[c] = false;
+            if (c < C) {
+                const int wi = D::win(P, c), f = D::func(P, c), a = D::agg(P, c);
+                bool ok = wi >= 0 && wi <= wmax && f >= 0 && f <= 6 && a >= 0 && a <= 3 && n_win > 0;
+                int l = 0, h = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (wi == i) { l = mw.lo[i]; h = mw.hi[i]; }
+                int wn = kWantAny, field = 0;
+                if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { wn = 1; field = 1; }
+                if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
+                    // rows with p == -1; if the window has none, rows with p == 0 (operations.py:59-61,78-80)
+                    const bool has_neg = ok && ((neg_flags >> (wi & 7)) & 1u);
+                    wn = has_neg ? -1 : 0;
+                    field = has_neg ? 2 : 3;
+                }
+                // an out-of-range index inside the selected rows raises in torch_scatter -> zero channel
+                if (ok && ((oob_flags >> (fstride * field + (wi & 7))) & 1u)) ok = false;
+                lo[c] = l; hi[c] = h; want[c] = wn; active[c] = ok;
+            }
+        }
+    };
+
+    // (cnt, s, s2) of every channel -> the pixel's values
+    auto finish = [&](const int(&cnt)[D::kMaxC], const double(&s)[D::kMaxC], const double(&s2)[D::kMaxC], OutT(&vals)[D::kMaxC]) {
+        double rr[D::kMaxC];
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) {
+            double r = 0.0;
+            if (c < C && active[c]) {
+                const int f = D::func(P, c), a = D::agg(P, c);
+                const double n = (double)cnt[c];
+                const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
+                if (is_count_func(f) && a != EVREP_A_MAX) {
+                    // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
+                    r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
+                } else if (a == EVREP_A_SUM) r = s[c];
+                else if (a == EVREP_A_MEAN) {
+                    // x / 1.0 == x; a float64 division is ~13 double-rate instructions for the WHOLE wave, so it is only
+                    // entered when some pixel of the wave really holds more than one event of the channel
+                    r = s[c];
+                    if (__any(cnt[c] > 1)) r = cnt[c] > 1 ? s[c] / d : s[c];
+                } else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
+                else {
+                    double mean = s[c], mean2 = s2[c];
+                    if (__any(cnt[c] > 1)) {
+                        mean = cnt[c] > 1 ? s[c] / d : s[c];
+                        mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
+                    }
+                    const double mm = mean * mean;
+                    r = mean2 - mm;
+                }
+            }
+            rr[c] = r;
+        }
+        if (scale != 1.0) {   // x * 1.0 == x: the unscaled call (wave-uniform) skips its float64 multiplies
+#pragma unroll
+            for (int c = 0; c < D::kMaxC; ++c) rr[c] = rr[c] * scale;
+        }
+#pragma unroll
+        for (int c = 0; c < D::kMaxC; ++c) vals[c] = (OutT)rr[c];
+    };
+
+    constexpr bool kSplit = !HOT && MdesIsErgo12<D>::value && sizeof(OutT) == 8;
+    ChunkGeom g;
+    UnitRecs u;
+    bool esc = false;   // the split sweep met a record it cannot take
+    if constexpr (kSplit) {
+        uint32_t *words = reinterpret_cast<uint32_t *>(w.tile);
+        // What the sweep needs of the window, in a handful of scalars (the per-channel set-up proper stays behind the front end,
+        // where it always was: its values would ride through the sweep in registers): the seven rank windows, tmin, and per
+        // channel the polarity classes it takes -- bit 3 c + k of `cmask`, k = 0 / 1 / 2 for p < 0 / p == 0 / p > 0; none: the
+        // channel is inactive.
+        MdesWindows smw;
+        int32_t stmin = 0;
+        uint64_t cmask = 0ull;
+        auto sbegin = [&]() -> bool {
+            const WindowMeta m = meta_finish(bv, off, b0, mraw);
+            stmin = __builtin_amdgcn_readfirstlane(m.tmin);
+            smw = mdes_windows(n_win);
+            const uint32_t neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.neg_flags);
+            const uint32_t oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.oob_flags);
+            uint64_t cm = 0ull;
+#pragma unroll
+            for (int c = 0; c < D::kMaxC; ++c) {
+                const int wi = D::win(P, c), f = D::func(P, c);
+                uint64_t cls = 7ull;
+                int field = 0;
+                if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { cls = 4ull; field = 1; }
+                if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
+                    const bool has_neg = (neg_flags >> wi) & 1u;   // operations.py:59-61,78-80
+                    cls = has_neg ? 1ull : 2ull;
+                    field = has_neg ? 2 : 3;
+                }
+                if (n_win <= 0 || ((oob_flags >> (7 * field + wi)) & 1u)) cls = 0ull;
+                cm |= cls << (3 * c);
+            }
+            cmask = cm;
+            return true;
+        };
+        auto sf = [&](uint32_t px, const Rec8 &q, uint2 &e) -> bool {
+            const int rank = (int)(q.y >> 11);
+            const uint32_t p2 = (q.y >> 9) & 3u;
+            if (p2 == 3u) { esc = true; return false; }
+            const int p = (int)p2 - 1;
+            const uint32_t tt = (uint32_t)((int64_t)(int32_t)q.x - (int64_t)stmin);   // 0 <= t - tmin < 2^32
+            uint32_t *wd = words + px * (uint32_t)kErgoSplitWords;
+            const uint32_t inw = mdes_membership(smw, rank);
+            const uint64_t cm = cmask >> p2;
+            auto hit = [&](int c) -> bool { return ((inw >> D::win(P, c)) & 1u) && ((cm >> (3 * c)) & 1ull); };
+            const uint32_t pinc = p > 0 ? 1u : 0x10000u;
+            if (hit(0)) { if (p != 0) atomicAdd(wd + 0, pinc); else atomicAdd(wd + 1, 1u); }
+            if (hit(3) && p != 0) atomicAdd(wd + 2, pinc);
+            if (hit(5)) atomicAdd(wd + 1, 0x10000u);
+            const bool h8 = hit(8), h9 = hit(9), h10 = hit(10), h6 = hit(6), h1 = hit(1);
+            const uint32_t bits = (hit(2) ? 1u : 0u) | (hit(4) ? 2u : 0u) | (hit(7) ? 4u : 0u) | (hit(11) ? 8u : 0u) |
+                                  (h8 ? 16u : 0u) | (h10 ? 32u : 0u) | (h9 ? 64u : 0u);
+            if (bits) atomicOr(wd + 3, bits);
+            if (h6) atomicAdd(wd + 3, 0x10000u);
+            if (h8) atomicMax(wd + 4, tt);
+            if (h9) atomicMax(wd + 5, tt);
+            if (h10) atomicMax(wd + 6, tt);
+            e = make_uint2(tt, px);
+            return h6 || h1;
+        };
+        auto sdone = [&]() -> bool { return !__any(esc); };
+        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split(sbegin, sf, sdone, kErgoSplitWords));
+    } else {
+        u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
+    }
+    if (u.deferred) return;
+    w.mark(0);
+    OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
+    setup();
+    w.mark(1);
+
+    if constexpr (kSplit) {
+        if (u.part == -5) {   // wave-uniform: the unit was swept by the split; its kept records wait, in time order, in the list
+            const int lane = threadIdx.x;
+            const uint32_t nk = u.pst;
+            const uint32_t *words = reinterpret_cast<const uint32_t *>(w.tile);
+            volatile uint32_t *cnt = reinterpret_cast<volatile uint32_t *>(w.segs);
+            scan_pixel_counters(reinterpret_cast<uint32_t *>(w.segs), u.npixu);
+            const uint32_t room = (uint32_t)(reinterpret_cast<const unsigned char *>(w.segs) - reinterpret_cast<const unsigned char *>(w.tile));
+            const uint32_t lcap = split_list_cap(room, u.pen);
+            const uint32_t nrec = u.ce - u.cs;
+            const bool big = nk > lcap;   // wave-uniform: a hot unit -- its kept records are ordered in its slot of the spill stream
+            const uint2 *list = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(w.tile) + u.pen);
+            double *placed = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(w.tile) + u.pen);
+            const uint2 *glist = reinterpret_cast<const uint2 *>(bv.spill + u.cs);
+            double *gplaced = reinterpret_cast<double *>(bv.spill + u.cs) + nrec;
+            const int nbits = 32 - __builtin_clz((unsigned)u.npixu - 1u);
+            auto place = [&](const uint2 &e, bool valid, double *dstp) {
+                const uint32_t px = valid ? e.y : 0u;
+                uint32_t rk; bool last;
+                wave_match(px, nbits, valid, lane, rk, last);
+                uint32_t pos = 0;
+                // the digest: the normalised timestamp's division, one record per lane (mixed_density_event_stack.py:112-114)
+                if (valid) { pos = cnt[px] + rk; dstp[pos] = (double)e.x / interval; }
+                __builtin_amdgcn_wave_barrier();
+                if (valid && last) cnt[px] = pos + 1;
+                __builtin_amdgcn_wave_barrier();
+            };
+            if (!big) {
+                // the whole list rides in registers while its records move to their pixels' places: the ordered copy takes the list's room
+                uint2 ek[kSplitBatches];
+#pragma unroll
+                for (int i = 0; i < kSplitBatches; ++i) {
+                    const uint32_t j = (uint32_t)(i * kWave + lane);
+                    ek[i] = make_uint2(0u, 0u);
+                    if (j < nk) ek[i] = list[j];
+                }
+                wave_phase();
+#pragma unroll
+                for (int i = 0; i < kSplitBatches; ++i)
+                    if ((uint32_t)(i * kWave) < nk) place(ek[i], (uint32_t)(i * kWave + lane) < nk, placed);   // uniform
+            } else {
+                // the wave reads back what its own lanes stored in the slot: same CU, same vector L1 -- workgroup-scope release / acquire
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (uint32_t j0 = 0; j0 < nk; j0 += 4 * kWave) {
+                    uint2 ek[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
+                        ek[i] = make_uint2(0u, 0u);
+                        if (j < nk) {
+                            if (j < lcap) ek[i] = list[j];
+                            else { const double d = gload_f64(reinterpret_cast<const double *>(glist + j)); ek[i] = make_uint2((uint32_t)__double2loint(d), (uint32_t)__double2hiint(d)); }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (j0 + (uint32_t)(i * kWave) < nk) place(ek[i], j0 + (uint32_t)(i * kWave + lane) < nk, gplaced);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            wave_phase();
+            w.mark(4);
+            constexpr int V = 16 / (int)sizeof(OutT);
+            const bool vec = (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;   // wave-uniform
+            w.pace();
+            for (int pt = 0; pt * kWave < g.npix; ++pt) {
+                const int np = min(kWave, g.npix - pt * kWave);
+                const bool own = lane < np;
+                const uint32_t px = (uint32_t)(pt * kWave + lane);
+                uint32_t st = 0, en = 0, a3 = 0;
+                const uint32_t *wd = words + px * (uint32_t)kErgoSplitWords;
+                if (own) { en = cnt[px]; st = px ? cnt[px - 1] : 0u; a3 = wd[3]; }
+                // the ordered part: the pixel's ch6 records, then its ch1 records, each in time order
+                const uint32_t mid = st + (a3 >> 16);
+                double acc6 = 0.0, acc1 = 0.0, sq1 = 0.0;
+                if (!big) {
+                    for (uint32_t j = st; j < mid; ++j) acc6 = acc6 + placed[j];
+                    for (uint32_t j = mid; j < en; ++j) { const double v = placed[j]; acc1 = acc1 + v; const double vv = v * v; sq1 = sq1 + vv; }
+                } else {
+                    // the part's records, [ra, rb) of the slot, come through the list's room in LDS `lcap` at a time (coalesced loads,
+                    // all in flight together); a lane walks what the piece holds of its pixel and carries its sums to the next piece
+                    const uint32_t ra = pt ? cnt[pt * kWave - 1] : 0u, rb = cnt[pt * kWave + np - 1];   // wave-uniform
+                    for (uint32_t c0 = ra; c0 < rb; c0 += lcap) {
+                        const uint32_t n = min(lcap, rb - c0);
+                        double tmp[kSplitBatches];
+#pragma unroll
+                        for (int i = 0; i < kSplitBatches; ++i) {
+                            const uint32_t j = (uint32_t)(i * kWave + lane);
+                            tmp[i] = 0.0;
+                            if (j < n) tmp[i] = gload_f64(gplaced + c0 + j);
+                        }
+                        wave_phase();   // the previous piece's walks are done
+#pragma unroll
+                        for (int i = 0; i < kSplitBatches; ++i) {
+                            const uint32_t j = (uint32_t)(i * kWave + lane);
+                            if (j < n) placed[j] = tmp[i];
+                        }
+                        wave_phase();
+                        const uint32_t jl = max(st, c0), jh = min(en, c0 + n);
+                        for (uint32_t j = jl; j < jh; ++j) {
+                            const double v = placed[j - c0];
+                            if (j < mid) acc6 = acc6 + v;
+                            else { acc1 = acc1 + v; const double vv = v * v; sq1 = sq1 + vv; }
+                        }
+                    }
+                }
+                if (own) {
+                    const uint32_t a0 = wd[0], a1 = wd[1], a2 = wd[2], m8 = wd[4], m9 = wd[5], m10 = wd[6];
+                    int cn[D::kMaxC];
+                    double s[D::kMaxC], s2[D::kMaxC];
+#pragma unroll
+                    for (int c = 0; c < D::kMaxC; ++c) { cn[c] = 0; s[c] = 0.0; s2[c] = 0.0; }
+                    const int np0 = (int)(a0 & 0xffffu), nn0 = (int)(a0 >> 16), nz0 = (int)(a1 & 0xffffu);
+                    cn[0] = np0 + nn0 + nz0; s[0] = (double)(np0 - nn0); s2[0] = (double)(np0 + nn0);
+                    s[3] = (double)((int)(a2 & 0xffffu) - (int)(a2 >> 16));
+                    cn[5] = (int)(a1 >> 16);
+                    cn[2] = (int)(a3 & 1u); cn[4] = (int)((a3 >> 1) & 1u); cn[7] = (int)((a3 >> 2) & 1u); cn[11] = (int)((a3 >> 3) & 1u);
+                    cn[8] = (int)((a3 >> 4) & 1u); cn[10] = (int)((a3 >> 5) & 1u); cn[9] = (int)((a3 >> 6) & 1u);
+                    s[8] = (double)m8 / interval; s[9] = (double)m9 / interval; s[10] = (double)m10 / interval;
+                    cn[6] = (int)(mid - st); s[6] = acc6;
+                    cn[1] = (int)(en - mid); s[1] = acc1; s2[1] = sq1;
+                    OutT vals[D::kMaxC];
+                    finish(cn, s, s2, vals);
+                    store_pixel<OutT, D::kMaxC>(dst + ((size_t)pt * kWave + lane) * C, vals, C, vec);
+                }
+            }
+            w.mark(5);
+            return;
         }
     }
 
@@ -1629,42 +2015,7 @@ __device__ inline void mdes_emit_unit(const MdesParams &P, int C, int W, double 
                 }
             }
         }
-        double rr[D::kMaxC];
-#pragma unroll
-        for (int c = 0; c < D::kMaxC; ++c) {
-            double r = 0.0;
-            if (c < C && active[c]) {
-                const int f = D::func(P, c), a = D::agg(P, c);
-                const double n = (double)cnt[c];
-                const double d = (double)(cnt[c] < 1 ? 1 : cnt[c]);
-                if (is_count_func(f) && a != EVREP_A_MAX) {
-                    // sum = n; mean = n / max(n,1) = 1 or 0; variance = mean(1) - mean(1)^2 = 0 exactly
-                    r = (a == EVREP_A_SUM) ? n : ((a == EVREP_A_MEAN) ? (cnt[c] > 0 ? 1.0 : 0.0) : 0.0);
-                } else if (a == EVREP_A_SUM) r = s[c];
-                else if (a == EVREP_A_MEAN) {
-                    // x / 1.0 == x; a float64 division is ~13 double-rate instructions for the WHOLE wave, so it is only
-                    // entered when some pixel of the wave really holds more than one event of the channel
-                    r = s[c];
-                    if (__any(cnt[c] > 1)) r = cnt[c] > 1 ? s[c] / d : s[c];
-                } else if (a == EVREP_A_MAX) r = cnt[c] > 0 ? s[c] : 0.0;
-                else {
-                    double mean = s[c], mean2 = s2[c];
-                    if (__any(cnt[c] > 1)) {
-                        mean = cnt[c] > 1 ? s[c] / d : s[c];
-                        mean2 = cnt[c] > 1 ? s2[c] / d : s2[c];
-                    }
-                    const double mm = mean * mean;
-                    r = mean2 - mm;
-                }
-            }
-            rr[c] = r;
-        }
-        if (scale != 1.0) {   // x * 1.0 == x: the unscaled call (wave-uniform) skips its float64 multiplies
-#pragma unroll
-            for (int c = 0; c < D::kMaxC; ++c) rr[c] = rr[c] * scale;
-        }
-#pragma unroll
-        for (int c = 0; c < D::kMaxC; ++c) vals[c] = (OutT)rr[c];
+        finish(cnt, s, s2, vals);
     };
     emit_chunk<OutT, D::kMaxC, HOT>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, (const OutT *)nullptr, reduce);
 }
@@ -1681,7 +2032,6 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
 #ifdef EVREP_TIMING
         w.dbg = bv.dbg + 8 * (size_t)uid;
 #endif
-        ChunkGeom g;
         // every independent global load first: the window's extent and block statistics, the unit's run tables -- then the
         // unit's records
         int chunk0;
@@ -1689,12 +2039,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
         const int64_t n_win = off[b0 + 1] - off[b0];
         const MetaRaw mraw = meta_prefetch(bv, b0);
         w.mark(6);
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
-        if (u.deferred) return;
-        w.mark(0);
-        OutT *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
-        const WindowMeta m = meta_finish(bv, off, g.b, mraw);
-        mdes_emit_unit<OutT, D, HOT>(P, C, W, scale, u, g, n_win, m, dst, w);
+        mdes_unit<OutT, D, HOT>(bv, off, P, C, H, W, nchunk, uc, scale, out, w, uid, part, b0, n_win, mraw);
     });
 }
 

@@ -481,13 +481,16 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
     if ((plan->flags & EVREP_PLAN_X_SPAN2) && plan->nchunk >= 2) { uc.span = 2; uc.stage = 128; }
     const int span = uc.span;
     const bool pace_auto = plan->pacing < 0 && out_dtype == EVREP_F64 && C * 8 >= 64;   // the store-bound instances
+    bool hot_launch = false;
 #define MDES_LAUNCH(T, DESC)                                                                                          \
     do {                                                                                                              \
         const size_t lds_ = chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, uc.stage, uc.partpx);                       \
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
-        if (plan->reserved == 2) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it */          \
+        hot_launch = plan->reserved == 2 && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                             \
+        if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
             bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
@@ -504,7 +507,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
     }
 #undef MDES_RUNTIME
 #undef MDES_LAUNCH
-    hot_flip(plan);
+    if (hot_launch) hot_flip(plan);
     LAUNCH_CHECK("k_mdes");
     return EVREP_OK;
 }
