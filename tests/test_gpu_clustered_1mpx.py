@@ -98,7 +98,9 @@ def test_clustered_1mpx_every_builder_every_pass(oracle, dist, shape):
         for b, r in enumerate(refs):
             for k in ("ergo12", "ergo12_f32", "event_stack", "voxel"):
                 assert_bit_equal(got[k][b], r[k], "%s %s w%d" % (k, tag, b))
-            assert_bit_equal(got["evl_voxel"][b], r["evl_voxel"], "evl_voxel %s w%d" % (tag, b))
+            # ev-licious' grid is (bins, H, W) float32 (evlicious_tools.events_to_voxel_grid casts the builder's float64 counts)
+            assert_bit_equal(np.ascontiguousarray(np.moveaxis(got["evl_voxel"][b], -1, 0)).astype(np.float32), r["evl_voxel"],
+                             "evl_voxel %s w%d" % (tag, b))
             np.testing.assert_allclose(got["time_surface"][b], r["time_surface"], rtol=1e-12, err_msg="ts " + tag)
             np.testing.assert_allclose(got["tore"][b], r["tore"], rtol=1e-6, atol=1e-6, err_msg="tore " + tag)
             np.testing.assert_allclose(bbox[b], r["tore_bbox"], rtol=1e-6, atol=1e-6, err_msg="tore bbox " + tag)
@@ -132,3 +134,27 @@ def test_hot_units_under_every_pass_at_gen1(oracle):
             assert_bit_equal(vox[b], oracle.voxel(ev, H, W, 5), "voxel hot %s" % pass_name)
             want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
             np.testing.assert_allclose(tore[b], want, rtol=1e-6, atol=1e-6)
+
+
+def test_ergo12_hot_units_with_escaped_polarities(oracle):
+    """Polarity values outside {-1, 0, 1} are escaped in the 8-byte records; a unit of ERGO-12's split path that meets one takes
+    the ordered paths inside the same launch (no hot launch behind the float64 ERGO-12 builder): hot and warm units with a few
+    such records, against the oracle and the classic pass."""
+    from event_representation_study_amd import engine as eng
+    W, H, N = 304, 240, 60000
+    wins = []
+    for i in range(2):
+        ev = GENERATORS["circle"](N, W, H, seed=140 + i, polarity="pm1")
+        rng = np.random.default_rng(170 + i)
+        odd = rng.random(N) < 0.002
+        ev[odd, 3] = rng.choice(np.array([-2, 3, 7], dtype=np.int32), size=int(odd.sum()))
+        k = rng.integers(0, N, size=N // 4)            # a hot unit: a quarter of the window in 90 pixels of one row
+        ev[k, 0] = rng.integers(100, 190, size=len(k)); ev[k, 1] = 77 + i
+        wins.append(ev)
+    ks = _batch(eng, wins, H, W, PASSES["key_sorted"])
+    cl = _batch(eng, wins, H, W, PASSES["classic"])
+    assert ks.plan.reserved == 2 and cl.plan.reserved in (0, 1)
+    a, c = ks.optimized().cpu().numpy(), cl.optimized().cpu().numpy()
+    assert_bit_equal(a, c, "ergo12 escaped polarities: key-sorted vs classic")
+    for b, ev in enumerate(wins):
+        assert_bit_equal(a[b], oracle.ergo12(ev, H, W), "ergo12 escaped polarities vs oracle w%d" % b)
