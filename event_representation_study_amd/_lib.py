@@ -10,11 +10,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVREP_LIB_PATH") or os.path.join(_PKG, "libevrep.so")  # env override: A/B builds
 
 EVREP_OK, EVREP_EINVAL, EVREP_EWORKSPACE, EVREP_EHIP, EVREP_ENOTBINNED = 0, 1, 2, 3, 4
-ST_EMPTY, ST_OOB, ST_UNSORTED, ST_FLAT_TIME = 1, 2, 4, 8
+ST_EMPTY, ST_OOB, ST_UNSORTED, ST_FLAT_TIME, ST_HOT_OVERFLOW = 1, 2, 4, 8, 16
 F64, F32 = 0, 1
 MAX_CHANNELS = 16
 MAX_DIM = 4096
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FUNCS = ["timestamp", "polarity", "count", "timestamp_pos", "timestamp_neg", "count_pos", "count_neg"]
 AGGS = ["sum", "mean", "max", "variance"]
@@ -123,12 +123,15 @@ def load():
             "libevrep.so is missing (%s). Build it with `python -m event_representation_study_amd.build`; "
             "there is no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.evrep_abi_version.restype = ctypes.c_int
+    lib.evrep_abi_version.argtypes = []
+    if lib.evrep_abi_version() != ABI_VERSION:   # (before the symbols are bound: a stale library says so, not AttributeError)
+        raise EvrepError("libevrep.so ABI %d != binding ABI %d: rebuild with `python -m event_representation_study_amd.build`"
+                         % (lib.evrep_abi_version(), ABI_VERSION))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.evrep_abi_version() != ABI_VERSION:
-        raise EvrepError("libevrep.so ABI %d != binding ABI %d" % (lib.evrep_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

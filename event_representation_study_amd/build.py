@@ -8,13 +8,17 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libevrep.so")
-SOURCES = ["evrep_capi.hip"]                      # unity build: includes the kernel files
-DEPS = ["evrep_capi.hip", "evrep_bin.hip", "evrep_builders.hip", "evrep_gwd.hip", "evrep_otmi.hip", "evrep_gw.hip", "evrep_common.h",
-        os.path.join(ROOT, "include", "evrep.h")]
+# four translation units, compiled in parallel and linked into one .so (r05; a unity build until then: four minutes)
+SOURCES = ["evrep_capi.hip", "evrep_capi_mdes.hip", "evrep_capi_builders.hip", "evrep_capi_gwd.hip"]
+_BIN = ["evrep_bin.hip", "evrep_common.h", "evrep_capi_shared.h"]
+_BLD = _BIN + ["evrep_builders.hip", "evrep_capi_builders.h"]
+UNIT_DEPS = {"evrep_capi.hip": _BIN, "evrep_capi_mdes.hip": _BLD, "evrep_capi_builders.hip": _BLD,
+             "evrep_capi_gwd.hip": ["evrep_gwd.hip", "evrep_otmi.hip", "evrep_gw.hip", "evrep_common.h", "evrep_capi_shared.h"]}
+OBJDIR = os.path.join(PKG, "_obj")
 
 # -ffp-contract=off: the parity contract is bit-exactness with the reference's separate
 # multiply / add / subtract (variance = mean(x^2) - mean(x)^2, src**2, w*p), so no FMA fusion.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -25,26 +29,50 @@ def hipcc():
     return exe
 
 
+def _mtime(d):
+    return os.path.getmtime(d if os.path.isabs(d) else os.path.join(CSRC, d))
+
+
+def _unit_deps(src):
+    return [src] + UNIT_DEPS[src] + [os.path.join(ROOT, "include", "evrep.h")]
+
+
+def _obj(src, tag=""):
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + tag + ".o")
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for d in DEPS:
-        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.getmtime(p) > t:
-            return True
-    return False
+    return any(_mtime(d) > t for src in SOURCES for d in _unit_deps(src))
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=True, extra_flags=(), lib=LIB):
+    """Compile the translation units that are out of date (in parallel) and link `lib`.  Objects are cached under _obj/ per
+    set of extra flags, so experiment builds (tools/variants) do not disturb the library's own objects."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    if lib == LIB and not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[evrep build]", " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    tag = ("-" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]) if extra_flags else ""
+    todo = []
+    for src in SOURCES:
+        o = _obj(src, tag)
+        if force or not os.path.exists(o) or any(_mtime(d) > os.path.getmtime(o) for d in _unit_deps(src)):
+            todo.append([hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c",
+                                                                  os.path.join(CSRC, src), "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[evrep build]", " ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(src, tag) for src in SOURCES])
+    return lib
 
 
 EXAMPLE_SRC = os.path.join(ROOT, "examples", "capi_ergo12.cpp")
@@ -66,5 +94,14 @@ def build_example(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a != "--force"])
-    build_example(force="--force" in sys.argv)
+    # python -m event_representation_study_amd.build [--force] [-o tools/variants/libevrep_timing.so] [-DEVREP_TIMING ...]
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out = LIB
+    if "-o" in args:
+        i = args.index("-o")
+        out = os.path.abspath(args[i + 1])
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        del args[i:i + 2]
+    build(force="--force" in sys.argv, extra_flags=args, lib=out)
+    if out == LIB:
+        build_example(force="--force" in sys.argv)

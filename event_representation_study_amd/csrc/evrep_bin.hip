@@ -99,7 +99,7 @@ __device__ inline bool decode_window_block(int B, int nblk, int &b, int &blk) {
 }
 
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = H * 4 bytes.
-__global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                       int B, int H, int W, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, BlockStats *__restrict__ stats) {
     extern __shared__ uint32_t hist[];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__restrict
 // grid (B), 256 threads, dynamic LDS = (H + 8) * 4 bytes.
 // table[b][blk][row] -> exclusive prefix over blk; row_off[b][row] = global start of the row;
 // meta[b] = reduction of the window's block statistics.
-__global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
+static __global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, uint32_t *__restrict__ row_off,
                                                       const BlockStats *__restrict__ stats, WindowMeta *__restrict__ meta) {
     extern __shared__ uint32_t rowtot[];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *__restr
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = 4 * H * 4 bytes.  Stable placement by sensor row.
 // Each wave owns a contiguous quarter of the block's events and keeps them in registers between
 // the counting and the placement phase (one HBM read of the events for both).
-__global__ __launch_bounds__(kBinThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(kBinThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                          int B, int H, int W, int chunk, int nblk,
                                                          const uint32_t *__restrict__ table,
                                                          const uint32_t *__restrict__ row_off, Rec *__restrict__ sorted1) {
@@ -321,7 +321,7 @@ __host__ __device__ inline size_t fused_scatter_lds_bytes(int H) {
     return (size_t)(kBinWaves + 3) * H * sizeof(uint32_t) + (size_t)kStageRecs * sizeof(Rec);
 }
 
-__global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                                int B, int H, int W, int chunk, int nblk,
                                                                const uint32_t *__restrict__ table,
                                                                const BlockStats *__restrict__ stats,
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const int4 *_
 // (the common case) keep their records in registers between counting and placement; longer rows
 // are walked twice.  Also emits, per row, the record offsets of every kChunkPx-pixel column chunk
 // (what one builder wavefront consumes).
-__global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
+static __global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
                                                    int H, int W, int nchunk, Rec *__restrict__ sorted2,
                                                    uint32_t *__restrict__ chunk_off) {
     extern __shared__ uint32_t cnt[];  // [W]
@@ -582,7 +582,7 @@ __host__ __device__ inline size_t block_rowsort_lds_bytes(int H) {
 
 // grid (8 * ceil(B/8) * nblk), 1024 threads, dynamic LDS = block_rowsort_lds_bytes(H).
 // table: [B][nblk][H + 1] exclusive offsets of the block's rows inside its run (entry H = in-frame events).
-__global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int nblk, uint32_t *__restrict__ table,
                                                              BlockStats *__restrict__ stats, Rec *__restrict__ sorted1) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -757,7 +757,7 @@ __host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_word
 #ifndef CS_WAVES
 #define CS_WAVES 8   // 63 VGPRs, no scratch: dense binning 123 -> 119 us (1 Mpx), 80 -> 78 us (640x480)
 #endif
-__global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_waves_per_eu(CS_WAVES))) void k_col_sort_runs(const int4 *__restrict__ ev, const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_waves_per_eu(CS_WAVES))) void k_col_sort_runs(const int4 *__restrict__ ev, const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
                                                                      int nchunk, int kpr, int chunk_shift, int by_key,
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
 
 // grid (B), 64 threads: the window statistics of the key-sorted pass, for the synchronous read-backs only
 // (the builders merge the block statistics they need themselves).
-__global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
+static __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
                                                       int nblk, int chunk_shift, WindowMeta *__restrict__ meta) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t n_win = nwin[b];

@@ -244,12 +244,12 @@ struct BinView {
     const WindowMeta *meta;     // classic: [B]
     Rec *spill;                 // key-sorted: sorted2, where a unit of more than kEvStage records is laid out
     int nblk, fused, chunk_shift;  // events per block run = 1 << chunk_shift (a runtime 64-bit division costs ~130 scalar instructions)
-    // Hot units (r04): TWO lists, [0] / [1] = their counts, [4 + l * hot_cap ...] = the unit ids of list l, at most hot_cap
-    // each.  A main launch appends the units that do not fit its stage to list `hot_sel`; the hot launch behind it works that
-    // list off and clears the OTHER one, which the next builder call (the host alternates hot_sel) appends to (run_units)
+    // Hot units (run_units): [l * 16] = the item count of sublist l, [(kHotLists + l) * 16] = its exit ticket,
+    // [kHotHdrWords + l * hot_sublist_cap(hot_cap) ...] = its items.  A main launch appends the pieces of the units that do not
+    // fit its stage; the hot launch behind it works them off and leaves the list empty.
     uint32_t *hot;
     uint32_t hot_cap;
-    int hot_sel;
+    BlockStats *stats_rw;       // key-sorted: a main wave that cannot defer a unit (every sublist full) reports it in the window's status
 #ifdef EVREP_TIMING
     unsigned long long *dbg;
 #endif
@@ -302,54 +302,51 @@ __device__ inline uint32_t wave_incl_max_scan(uint32_t v) {
 // grid of one-wave workgroups striding over the list, a stage of kHotStage records, registers to spare) emits those.  One
 // kernel would have to carry the hot paths' registers (the spill sort's batches, emit_rounds' ring) through every wave of the
 // frame: the float64 12-channel builder went from 75 to 115 VGPRs -- an occupancy step of the headline launch -- when they were
-// inlined into it.  On uniform windows the list is empty and the hot launch ends at once (~1.5 us of the step).
-// There are two lists and the builder calls on a plan alternate between them (evrep_capi.hip, hot_view): a hot launch cannot
-// clear the list it reads (a workgroup that is late would find it empty) without a count of the workgroups that are done --
-// one device-scope atomic per workgroup, 12 ns each on one address: 25 us per launch, measured -- so it clears the OTHER
-// list, which nothing touches while it runs and which the next call's main launch appends to.  The binning pass clears both.
+// inlined into it.  On uniform windows the list is empty and the hot launch ends at once.
+// The list is kHotLists SUBLISTS with a counter of its own each, 64 bytes apart: a clustered batch defers ten thousand units,
+// and device-scope atomics on ONE address retire at ~12 ns each (120 us of a 150 us launch, measured); a unit goes to the
+// sublist its id hashes to, a full sublist sends it to the next.  Sublist l is worked off by the kHotGrid / kHotLists hot
+// workgroups l, l + 64, ...; each of them takes an EXIT TICKET of the sublist when it is through (r05: one atomic per workgroup
+// on 64 addresses, and only on sublists that hold anything), and the one that takes the last ticket clears the sublist -- so the
+// list is empty again when the launch ends, whatever the next call on the workspace is: the state is the workspace's (r04 kept
+// two lists and a selector bit in the caller's plan that every builder call flipped), the plan is read-only, one plan may
+// drive any number of workspaces, and a captured graph of builder calls replays.
 // A hot item is ONE piece of a unit (a 64-pixel part or a quarter of one, below).  The unit's main wave has laid the unit out,
 // pixel-sorted, in its spill slot before deferring it (r04c); the hot wave finds its pixels' records there by binary search,
 // stages and walks them with one lane per pixel.
-#ifndef EVREP_HOT_STAGE
-#define EVREP_HOT_STAGE 256
-#endif
-#ifndef EVREP_HOT_GRID
-#define EVREP_HOT_GRID 4096
-#endif
-constexpr int kHotStage = EVREP_HOT_STAGE;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
-constexpr int kHotGrid = EVREP_HOT_GRID;    // workgroups of a hot launch
-constexpr int kHotParts = 8;      // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
 // A hot item's PIECE code: 0..7 = the 64-pixel part p; 8 + 4 p + s = the s-th 16-pixel quarter of part p.  A part of more
 // records than a hot wave's stage holds is deferred as four quarters (r04b): its walks -- a chain as long as the part's longest
 // pixel -- split four ways, and a quarter's records mostly fit the stage (LDS walks) where the part's did not (walks through
 // the register ring).  item = uid * kHotCodes + code.
-constexpr int kHotCodes = 64;
 __device__ inline int piece_px0(int code) { return code < kHotParts ? code * kWave : ((code - kHotParts) >> 2) * kWave + ((code - kHotParts) & 3) * (kWave / 4); }
 __device__ inline int piece_npx(int code) { return code < kHotParts ? kWave : kWave / 4; }
-// Each of the two lists is kHotLists SUBLISTS with a counter of its own, 64 bytes apart: a clustered batch defers ten thousand
-// units, and device-scope atomics on ONE address retire at ~12 ns each (120 us of a 150 us launch, measured); a unit goes to
-// the sublist its id hashes to.  A sublist holds four times its fair share; a full one sends the unit to the next.
-constexpr int kHotLists = 64;
-constexpr int kHotHdrWords = 2 * kHotLists * 16;
-__host__ __device__ inline uint32_t hot_sublist_cap(uint32_t cap_total) { return cap_total / (kHotLists / 4) + 64u; }
 template <bool HOT, typename Body>
 __device__ inline void run_units(const BinView &bv, Body body) {
     if constexpr (!HOT) {
         body(chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z)), -1);
     } else {
         const uint32_t l = blockIdx.x % kHotLists, capl = hot_sublist_cap(bv.hot_cap);
-        const uint32_t n = min((uint32_t)__builtin_amdgcn_readfirstlane((int)bv.hot[(bv.hot_sel * kHotLists + l) * 16]), capl);
-        if (blockIdx.x < kHotLists && threadIdx.x == 0) bv.hot[((bv.hot_sel ^ 1) * kHotLists + blockIdx.x) * 16] = 0u;
-        const uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
+        const uint32_t nraw = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.hot[l * 16]);
+        if (nraw == 0u) return;   // (every workgroup of the sublist reads the same count: nothing clears it before all are through)
+        const uint32_t n = min(nraw, capl);
+        const uint32_t *items = bv.hot + kHotHdrWords + (size_t)l * capl;
         for (uint32_t it = blockIdx.x / kHotLists; it < n; it += gridDim.x / kHotLists) {
             const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
             if (item >= 0) body(item / kHotCodes, item % kHotCodes);   // (< 0: the unused tail of a sublist that filled up)
             wave_phase();
         }
+        if (threadIdx.x == 0) {
+            const uint32_t ticket = atomicAdd(&bv.hot[(kHotLists + l) * 16], 1u);
+            if (ticket + 1u == gridDim.x / kHotLists) {   // the sublist's last workgroup: every other one has read its items
+                bv.hot[(kHotLists + l) * 16] = 0u;
+                bv.hot[l * 16] = 0u;
+            }
+        }
     }
 }
-// main launch: the `nparts` 64-pixel parts of unit `uid` go to the hot list, the parts of `splitmask` as four quarters each
-__device__ inline void defer_unit(const BinView &bv, int uid, int nparts, uint32_t splitmask) {
+// main launch: the `nparts` 64-pixel parts of unit `uid` go to the hot list, the parts of `splitmask` as four quarters each.
+// False: every sublist is full (the workspace's list holds several times what evrep_plan_init's bound says a batch can defer).
+__device__ inline bool defer_unit(const BinView &bv, int uid, int nparts, uint32_t splitmask) {
     const uint32_t capl = hot_sublist_cap(bv.hot_cap);
     // lane 4 p + s: quarter s of part p (a part that is not split: s == 0 stands for the whole part)
     const int lane = threadIdx.x, p = lane >> 2, sq = lane & 3;
@@ -361,15 +358,16 @@ __device__ inline void defer_unit(const BinView &bv, int uid, int nparts, uint32
     uint32_t l = ((uint32_t)uid * 0x9E3779B1u) >> 26;
     for (int tries = 0; tries < kHotLists; ++tries, l = (l + 1) % kHotLists) {   // (wave-uniform)
         uint32_t at = 0;
-        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[(bv.hot_sel * kHotLists + l) * 16], nitems);
+        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[l * 16], nitems);
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        uint32_t *items = bv.hot + kHotHdrWords + ((size_t)bv.hot_sel * kHotLists + l) * capl;
+        uint32_t *items = bv.hot + kHotHdrWords + (size_t)l * capl;
         if (at + nitems <= capl) {
             if (active) items[at + pos] = (uint32_t)uid * (uint32_t)kHotCodes + code;
-            return;
+            return true;
         }
         if (active && at + pos < capl) items[at + pos] = 0xffffffffu;   // the sublist is full
     }
+    return false;
 }
 
 // grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks).
@@ -947,7 +945,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     }
     wave_phase();
     if (defer) {   // wave-uniform: a part beyond this wave's stage -- the unit's pieces go to the hot launch, which finds them in the slot
-        defer_unit(bv, uid, (npix_out + kWave - 1) / kWave, defer_mask);
+        if (!defer_unit(bv, uid, (npix_out + kWave - 1) / kWave, defer_mask) && lane == 0)
+            atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);   // the unit's pixels stay unwritten: the caller is told
         u.deferred = true;
         u.ce = nrec;
         return u;
@@ -2050,7 +2049,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
 // reference's own float64 comparisons (a NaN t_s -- a window of one timestamp -- fails them all: empty windows, as there).
 // grid (B), 1024 threads: bounds [B][8][2], wflags [B][2] = {bit w: window w holds a p == -1 event; bit 8 k + w: window w
 // holds an out-of-frame event of polarity class k (0 any, 1 p == 1, 2 p == -1, 3 p == 0)}.
-__global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int H, int W,
+static __global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int H, int W,
                                                           int32_t *__restrict__ bounds, uint32_t *__restrict__ wflags) {
     __shared__ int cnt[10];
     __shared__ uint32_t fl[2];
@@ -2200,11 +2199,11 @@ struct TsCuts {
     double fac[kMaxSlices];    // exp((tref - tcut[s]) / tau) * scale
     double tcutf[kMaxSlices];  // the cut's timestamp as float64: t[idx[s]], or tf[idx[s]] (float timestamps, evrep_time_surface_ftime)
 };
-static_assert(sizeof(TsCuts) == 384, "TsCuts");
+static_assert(sizeof(TsCuts) == kTsCutsBytes, "TsCuts");
 
 // grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
 // int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
-__global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
+static __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
                           const int32_t *__restrict__ indices, double tau, double scale, TsCuts *__restrict__ cuts,
                           const double *__restrict__ tf) {
     const int b = blockIdx.x, s = threadIdx.x;
@@ -2503,22 +2502,53 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
             v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
             return make_int4(r.x, __float_as_int(v), counts ? 1 : 0, r.w);
         };
+        const bool unsorted = (m.status & EVREP_ST_UNSORTED) != 0u;   // wave-uniform
         auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
             float fp[(CM / 2)], fn[(CM / 2)];  // most recent first; slots never filled keep the empty-FIFO value
 #pragma unroll
             for (int q = 0; q < (CM / 2); ++q) { fp[q] = bgv; fn[q] = bgv; }
-            for (uint32_t j = jb; j < je; ++j) {
-                const Rec e = get(j);
-                if (!e.z) continue;
-                const float v = __int_as_float(e.y);
-                if (e.w > 0) {
+            if (!unsorted) {
+                for (uint32_t j = jb; j < je; ++j) {
+                    const Rec e = get(j);
+                    if (!e.z) continue;
+                    const float v = __int_as_float(e.y);
+                    if (e.w > 0) {
 #pragma unroll
-                    for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
-                    fp[0] = v;
-                } else {
+                        for (int q = (CM / 2) - 1; q > 0; --q) fp[q] = fp[q - 1];
+                        fp[0] = v;
+                    } else {
 #pragma unroll
-                    for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
-                    fn[0] = v;
+                        for (int q = (CM / 2) - 1; q > 0; --q) fn[q] = fn[q - 1];
+                        fn[0] = v;
+                    }
+                }
+            } else {
+                // Timestamps in any order (r05; wave-uniform): the reference keeps np.partition([t] + v[:k-1], k-1)[:k] per
+                // event in ARRAY order (tore.py:22-25).  numpy's float64 partition of such a short vector SORTS it (numpy >= 2.0
+                // on AVX2 / AVX-512 hosts: x86-simd-sort's bitonic network for <= 256 elements -- what the golden of this path
+                // was generated with; the scalar introselect only swaps the maximum to the end, a different ORDER of the same
+                // values), so v stays ascending and a step inserts t into the k - 1 smallest kept so far; the largest of the k
+                // is only dropped by the NEXT event of the pixel.  A slot's value is a non-decreasing function of its interval
+                // (scale >= 0; non-increasing below), so the finished values are inserted instead of the intervals.  For
+                // ascending timestamps this IS the FIFO above.
+                const float sg = scale < 0.0f ? -1.0f : 1.0f;
+                auto insert = [&](float(&a)[(CM / 2)], float v) {
+                    float r[(CM / 2)];
+#pragma unroll
+                    for (int q = 0; q < (CM / 2); ++q) {
+                        const float below = q > 0 ? a[q - 1] : v;            // max(a[q-1], v), a[-1] = -inf
+                        const float hi = q > 0 ? (sg * below > sg * v ? below : v) : v;
+                        const bool last = q >= K - 1;                        // a'[q] = +inf: the old v[k-1] is not kept
+                        r[q] = (last || sg * hi < sg * a[q]) ? hi : a[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < (CM / 2); ++q) if (q < K) a[q] = r[q];
+                };
+                for (uint32_t j = jb; j < je; ++j) {
+                    const Rec e = get(j);
+                    if (!e.z) continue;
+                    const float v = __int_as_float(e.y);
+                    if (e.w > 0) insert(fp, v); else insert(fn, v);
                 }
             }
 #pragma unroll
@@ -2839,7 +2869,7 @@ __global__ __launch_bounds__(kThreads) void k_resize_taps(const InT *__restrict_
 // tile builder: this path serves resized event streams, not the headline windows.
 // grid (ceil(H*W / 256), B), 256 threads; out DEVICE float32 (B, H, W, bins).
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
+static __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                             const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
                                                             const double *__restrict__ xy, int H, int W, int nchunk, int bins,
                                                             const int64_t *__restrict__ t_range, float *__restrict__ out) {
@@ -2897,7 +2927,7 @@ __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restr
 // tools/microbench/placement_patterns.hip); engine.probe_output_placement times it into candidate allocations.
 // grid (tiles), 64 threads, dynamic LDS 8320 B.  Writes zeros.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void k_store_probe(float *__restrict__ out, int ntiles) {
+static __global__ __launch_bounds__(kWave) void k_store_probe(float *__restrict__ out, int ntiles) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef float nt4 __attribute__((ext_vector_type(4)));
     const int t = chunk_unit(ntiles);

@@ -1,0 +1,80 @@
+// evrep_capi_mdes.hip -- the extern "C" surface, part 2: MixedDensityEventStack / Operations / ERGO-12 (k_mdes).
+#include "evrep_capi_builders.h"
+
+extern "C" {
+
+int evrep_mdes_sbt_windows(const int32_t *events, const int64_t *offsets, int32_t B, int32_t H, int32_t W, int32_t *bounds,
+                           uint32_t *flags, void *stream_) {
+    if (!events || !offsets || !bounds || !flags || B <= 0 || B > 65535 || H <= 0 || W <= 0) return EVREP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(events) & 15u) return EVREP_EINVAL;
+    k_mdes_sbt_windows<<<B, 1024, 0, static_cast<hipStream_t>(stream_)>>>(reinterpret_cast<const int4 *>(events), offsets, H, W, bounds, flags);
+    LAUNCH_CHECK("k_mdes_sbt_windows");
+    return EVREP_OK;
+}
+
+int evrep_mdes(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
+               const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
+               void *out, void *stream_) {
+    return evrep_mdes_ex(plan, events, offsets, workspace, C, window, func, agg, scale, out_dtype, out, nullptr, nullptr, stream_);
+}
+
+int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, int32_t C,
+                  const int32_t *window, const int32_t *func, const int32_t *agg, double scale, int32_t out_dtype,
+                  void *out, const int32_t *bounds, const uint32_t *flags, void *stream_) {
+    int rc = check_common(plan, events, offsets, workspace);
+    if (rc) return rc;
+    if (C <= 0 || C > EVREP_MAX_CHANNELS || !window || !func || !agg || !out) return EVREP_EINVAL;
+    if (out_dtype != EVREP_F64 && out_dtype != EVREP_F32) return EVREP_EINVAL;
+    if ((bounds == nullptr) != (flags == nullptr)) return EVREP_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MdesParams P;
+    memset(&P, 0, sizeof(P));
+    P.C = C;
+    P.bounds = bounds;
+    P.wflags = flags;
+    for (int c = 0; c < C; ++c) { P.win[c] = window[c]; P.func[c] = func[c]; P.agg[c] = agg[c]; }
+    // the ERGO-12 triples get the kernel instance with compile-time descriptors
+    bool ergo = C == Ergo12Table::kC && bounds == nullptr;
+    for (int c = 0; ergo && c < C; ++c)
+        ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
+    UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+    if ((plan->flags & EVREP_PLAN_X_SPAN2) && plan->nchunk >= 2) { uc.span = 2; uc.stage = 128; }
+    const int span = uc.span;
+    const bool pace_auto = plan->pacing < 0 && out_dtype == EVREP_F64 && C * 8 >= 64;   // the store-bound instances
+#define MDES_LAUNCH(T, DESC)                                                                                          \
+    do {                                                                                                              \
+        const size_t lds_ = chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, uc.stage, uc.partpx);                       \
+        if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
+        k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
+                                                                  plan->nchunk, uc, scale, static_cast<T *>(out));           \
+        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it */          \
+        const bool hot_launch = plan->reserved == 2 && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                             \
+        if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
+            bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
+    } while (0)
+#define MDES_RUNTIME(T)                                     \
+    do {                                                    \
+        if (C <= 4) MDES_LAUNCH(T, RuntimeDesc<4>);         \
+        else if (C <= 8) MDES_LAUNCH(T, RuntimeDesc<8>);    \
+        else if (C <= 12) MDES_LAUNCH(T, RuntimeDesc<12>);  \
+        else MDES_LAUNCH(T, RuntimeDesc<16>);               \
+    } while (0)
+    if (out_dtype == EVREP_F64) {
+        if (ergo) MDES_LAUNCH(double, StaticDesc<Ergo12Table>); else MDES_RUNTIME(double);
+    } else {
+        if (ergo) MDES_LAUNCH(float, StaticDesc<Ergo12Table>); else MDES_RUNTIME(float);
+    }
+#undef MDES_RUNTIME
+#undef MDES_LAUNCH
+    LAUNCH_CHECK("k_mdes");
+    return EVREP_OK;
+}
+
+int evrep_optimized(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
+                    double scale, int32_t out_dtype, void *out, void *stream) {
+    int32_t win[12], func[12], agg[12];
+    for (int c = 0; c < 12; ++c) { win[c] = Ergo12Table::kWin[c]; func[c] = Ergo12Table::kFunc[c]; agg[c] = Ergo12Table::kAgg[c]; }
+    return evrep_mdes(plan, events, offsets, workspace, 12, win, func, agg, scale, out_dtype, out, stream);
+}
+
+}  // extern "C"

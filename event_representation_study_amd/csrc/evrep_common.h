@@ -12,6 +12,26 @@ constexpr int kWaves = 4;
 constexpr int kWave = 64;
 constexpr int kChunkPx = 128;  // pixels of one row that one builder wavefront owns
 
+// The hot list of a workspace (evrep_builders.hip, run_units / defer_unit; sized by evrep_plan_init, cleared by the binning
+// pass): kHotLists SUBLISTS of unit-piece ids, each with a counter and an exit ticket of its own, 64 bytes apart.
+#ifndef EVREP_HOT_STAGE
+#define EVREP_HOT_STAGE 256
+#endif
+#ifndef EVREP_HOT_GRID
+#define EVREP_HOT_GRID 4096
+#endif
+constexpr size_t kTsCutsBytes = 384;             // sizeof(TsCuts) (evrep_builders.hip: a window's TimeSurface cuts in the workspace)
+constexpr int kHotStage = EVREP_HOT_STAGE;    // records of a hot wave's LDS stage (4 KB; with the tile: 640 records for float64 x 12)
+constexpr int kHotGrid = EVREP_HOT_GRID;      // workgroups of a hot launch
+constexpr int kHotParts = 8;                  // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
+constexpr int kHotCodes = 64;                 // item = unit id * kHotCodes + piece code
+constexpr int kHotLists = 64;
+constexpr int kHotHdrWords = 2 * kHotLists * 16;   // [l * 16]: sublist l's item count, [(kHotLists + l) * 16]: its exit ticket
+static_assert(kHotGrid % kHotLists == 0, "every sublist is worked off by kHotGrid / kHotLists workgroups");
+// items one sublist holds: eight times its fair share (a full one sends the unit to the next)
+__host__ __device__ inline uint32_t hot_sublist_cap(uint32_t cap_total) { return 2u * (cap_total / (kHotLists / 4) + 64u); }
+__host__ __device__ inline uint32_t hot_items_total(int64_t total_events) { return (uint32_t)(kHotParts * ((size_t)total_events / 65 + 1)); }
+
 // Per-window statistics produced by the binning pass (workspace, one per window).
 struct WindowMeta {
     int32_t tmin, tmax;              // over all events of the window

@@ -150,7 +150,13 @@ class Dataset:
             if mask & (1 << k):
                 continue
             if fid == 1:
-                raw = zlib.decompress(raw)
+                # bounded (r05): a chunk never inflates past its declared size (+ a trailing fletcher32 word, + slack for
+                # filters further up the pipeline whose output is a few bytes longer): more is a corrupt file, not a bomb
+                d = zlib.decompressobj()
+                cap = int(nbytes) + 64
+                raw = d.decompress(raw, cap + 1)
+                if len(raw) > cap or d.unconsumed_tail:
+                    raise ValueError("corrupt HDF5 chunk: deflate stream inflates past the chunk's %d bytes" % nbytes)
             elif fid == 2:                                     # shuffle: bytes of equal significance were grouped
                 es = cd[0] if cd else self.dtype.itemsize
                 n = len(raw) // es

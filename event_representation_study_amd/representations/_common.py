@@ -28,7 +28,8 @@ from ..engine import EventBatch, _ptr, _require_gpu, _stream_ptr
 from ..synthetic import from_structured, narrow_to_int32
 
 RESULT_POOL_DEPTH = int(os.environ.get("EVREP_RESULT_POOL", os.environ.get("EVREP_RESULT_RING", "8")))
-_CONTEXTS = {}
+_CONTEXTS = {}            # insertion-ordered: least recently used first (_context)
+MAX_CONTEXTS = 32         # (a context a caller still holds results of stays alive through their references)
 _CONTEXTS_LOCK = threading.Lock()
 
 
@@ -100,11 +101,21 @@ def _context(height, width, n):
     key = (os.getpid(), threading.get_ident(), str(dev), int(torch.cuda.current_stream(dev).cuda_stream), int(height),
            int(width), cap, flags, pacing)
     with _CONTEXTS_LOCK:
-        ctx = _CONTEXTS.get(key)
+        ctx = _CONTEXTS.pop(key, None)
+        if ctx is not None:
+            _CONTEXTS[key] = ctx            # most recently used last
     if ctx is None:
         ctx = _SampleContext(height, width, cap, dev, flags, pacing)
         with _CONTEXTS_LOCK:
             _CONTEXTS[key] = ctx
+            # bounded (r05): contexts of threads that have ended go first, then the least recently used ones -- an application
+            # that makes a thread or a stream per sample would otherwise pin cap x 16 B and hold 29.5 MB of device output each
+            if len(_CONTEXTS) > MAX_CONTEXTS:
+                alive = {t.ident for t in threading.enumerate()}
+                for k in [k for k in _CONTEXTS if k[0] == os.getpid() and k[1] not in alive]:
+                    del _CONTEXTS[k]
+                while len(_CONTEXTS) > MAX_CONTEXTS:
+                    del _CONTEXTS[next(iter(_CONTEXTS))]
     return ctx
 
 
@@ -214,7 +225,13 @@ def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None, 
     return arr if slot is not None else arr.copy()      # the pool is exhausted (the caller holds it all): a plain fresh array
 
 
+def _raise_for_hot_overflow(st, what):
+    if st & _lib.ST_HOT_OVERFLOW:   # cannot happen within evrep_plan_init's bounds; never hand out unwritten pixels
+        raise _lib.EvrepError("%s: the workspace's hot-unit list overflowed (EVREP_ST_HOT_OVERFLOW): the tensor is incomplete" % what)
+
+
 def _raise_for_status_word(st, batch, allow_oob, what, allow_unsorted=False):
+    _raise_for_hot_overflow(st, what)
     if st & _lib.ST_EMPTY:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")  # t.min() on no events
     if (st & _lib.ST_OOB) and not allow_oob:
@@ -249,6 +266,8 @@ def raise_for_status(batch, allow_oob=False, what="builder", any_window_oob=Fals
     ``any_window_oob``: the out-of-frame check covers every window of the batch)."""
     sts = batch.status()
     st = int(sts[0])
+    for s_ in sts:
+        _raise_for_hot_overflow(int(s_), what)
     if st & _lib.ST_EMPTY:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")  # t.min() on no events
     oob = any(int(s) & _lib.ST_OOB for s in sts) if any_window_oob else (st & _lib.ST_OOB)

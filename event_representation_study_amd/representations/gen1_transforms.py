@@ -44,7 +44,7 @@ def _event_stack(events, transform, height, width, num_events, device_out=False)
     # event_stack.py:125).  On ascending timestamps the past half is the whole window; otherwise it is the events with
     # t <= t[-1], in array order (r04: unsorted windows are built in array order, as the reference does)
     t = np.asarray(events["t"])
-    past = t <= t[-1] if len(t) else None
+    past = (t.astype(np.int64) <= t[-1] if t.dtype.kind == "f" else t <= t[-1]) if len(t) else None   # pre_stack compares t.astype(int64) (event_stack.py:36-38)
     sb = sample_batch(events if past is None or past.all() else events[past], height, width, device_out=device_out)
     events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34)
     return finish(sb, sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE)), what="EventStack", allow_unsorted=True)
@@ -63,12 +63,10 @@ def _histogram(events, transform, height, width, num_events, device_out=False):
 
 
 def _tore(events, transform, height, width, num_events, device_out=False):
-    # (timestamps that are not ascending are refused: the reference keeps a pixel's k most recent intervals with np.partition
-    # on a k-vector (tore.py:22-25), which is a FIFO only while every new interval is the smallest; otherwise the order of
-    # the kept values is whatever numpy's introselect leaves behind -- no semantics to mirror)
+    # (timestamps that are not ascending: array order, the reference's np.partition on its k-vector -- tore.py:22-25, k_tore)
     sb = sample_batch(events, height, width, device_out=device_out)
     # bounding-box frame, origin-shifted, sample time t[-1] (:61-66): frame_mode 0; the box travels with the result
-    return finish(sb, sb.tore_full(k=TORE_K, frame_mode=0, scale=float(SCALE)), what="TORE", tore_k=TORE_K)
+    return finish(sb, sb.tore_full(k=TORE_K, frame_mode=0, scale=float(SCALE)), what="TORE", tore_k=TORE_K, allow_unsorted=True)
 
 
 def _time_surface(events, transform, height, width, num_events, device_out=False):

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from ._common import events_from_fields, raise_for_status
+from .. import _lib
 from ..engine import EventBatch
 
 
@@ -42,7 +43,7 @@ class ToTimesurface:
         tf_dev = None if tf is None else torch.from_numpy(tf).to(batch.device)
         # the scan of time_surface.py:66-74 runs in array order: timestamps that are not ascending only forbid the factorised
         # exponentials (premap bit 1)
-        unsorted = bool(raise_for_status(batch, what="ToTimesurface", allow_unsorted=True) & 4)
+        unsorted = bool(raise_for_status(batch, what="ToTimesurface", allow_unsorted=True) & _lib.ST_UNSORTED)
         # the reference's scan tests `index == indices[pos]` once per event: only a strictly increasing
         # prefix of in-range indices is ever reached, every later surface stays all-zero
         live, prev = 0, -1

@@ -9,7 +9,9 @@ from ..synthetic import field_to_int64, int64_to_int32
 
 def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     """TORE volume for one sample time.  x, y are 1-based (the reference indexes ``[i - 1, j - 1]``);
-    returns (frameSize[0], frameSize[1], 2k) float32: the k most recent log-intervals per polarity.
+    returns (frameSize[0], frameSize[1], 2k) float32: the k most recent log-intervals per polarity.  Timestamps need not
+    be ascending: the kernel then keeps, per event in array order, what the reference's ``np.partition`` on its k-vector
+    keeps (tore.py:22-25; the order of the kept values is the sorting numpy's -- see oracle/evrep_oracle.c, oracle_tore).
 
     Float inputs behave as in the reference: float coordinates cannot index (IndexError), so it falls into its
     ``except`` branch and truncates them with int() (tore.py:29-33); float timestamps are used as they are --
@@ -41,12 +43,12 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     if float_time:
         ev[:, 2] = np.arange(n, dtype=np.int32) if np.all(np.diff(ts) >= 0) else -np.arange(n, dtype=np.int32)  # order marker only
         batch = EventBatch.from_numpy(ev, Hf, Wf)
-        raise_for_status(batch, what="events2ToreFeature")
+        raise_for_status(batch, what="events2ToreFeature", allow_unsorted=True)   # array order, as the reference (r05)
         tf = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.float64)).to(batch.device)
         rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, times_f64=tf, sample_times_f64=[st])
     else:
         ev[:, 2] = int64_to_int32(field_to_int64(ts, "t"), "t")
         batch = EventBatch.from_numpy(ev, Hf, Wf)
-        raise_for_status(batch, what="events2ToreFeature")
+        raise_for_status(batch, what="events2ToreFeature", allow_unsorted=True)   # array order, as the reference (r05)
         rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(st)])
     return rep[0].cpu().numpy()

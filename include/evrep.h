@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVREP_ABI_VERSION 2
+#define EVREP_ABI_VERSION 3
 
 /* return codes */
 #define EVREP_OK 0
@@ -45,6 +45,7 @@ extern "C" {
 #define EVREP_ST_OOB 2u        /* some x + y*W outside [0, H*W) (reference: IndexError in put / zero channel in MDES) */
 #define EVREP_ST_UNSORTED 4u   /* timestamps not ascending: evrep_mdes / evrep_optimized work in array order as the reference does; the other builders' tensors are undefined */
 #define EVREP_ST_FLAT_TIME 8u  /* t[-1] == t[0] (reference divides by zero) */
+#define EVREP_ST_HOT_OVERFLOW 16u /* a builder could not queue a unit of a clustered window (the workspace's hot list was full): pixels of the window are unwritten */
 
 /* MDES function / aggregation codes (representation_search/operations.py:42-87, :16-34) */
 enum evrep_func { EVREP_F_TIMESTAMP = 0, EVREP_F_POLARITY, EVREP_F_COUNT, EVREP_F_TIMESTAMP_POS,
@@ -66,8 +67,7 @@ typedef struct evrep_plan {
                                       2 = key-sorted (k_block_keysort alone; the builder waves finish the order by pixel),
                                       3 = k_block_keysort + the column sort per (row, chunk) key (dense windows),
                                       1 = k_block_rowsort + the column sort per row, 0 = the three-kernel pass */
-    int32_t flags;                 /* EVREP_PLAN_* bits the plan was made with; bit 30 is the library's own (it alternates with
-                                    * every builder call on the plan: which of the workspace's two hot-unit lists is in use) */
+    int32_t flags;                 /* EVREP_PLAN_* bits the plan was made with */
     int32_t pacing;                /* store pacing of the wide float64 builders (evrep_plan_set_pacing): -1 = automatic,
                                       0 = off, > 0 = every builder wave starts its stores no earlier than this many
                                       10 ns ticks after it started */

@@ -288,9 +288,15 @@ int oracle_time_surface(const int32_t *ev, int64_t n, int H, int W, int S, doubl
 /* ---------------------------------------------------------------------------------------------
  * A8: events2ToreFeature (tore.py:6-83) for a single sample time T.  x, y are the 1-based
  * coordinates the caller built (gen1_transforms.py:61-64); pixel = [y-1, x-1] in a (Hf, Wf) frame.
- * Events with ts >= T are excluded (:17).  Per pixel and polarity (pol > 0 / pol <= 0) a k-deep
- * FIFO of dt = T - ts, newest first, +inf when missing (:22-47; time-sorted input makes the
- * np.partition result fully ordered).  Then float32: clamp to 5e8, log(v+1) - log(151), floor 0.
+ * Events with ts >= T are excluded (:17).  Per pixel and polarity (pol > 0 / pol <= 0) a k-vector v of dt = T - ts,
+ * +inf when missing; every event, in ARRAY order, replaces it by np.partition([dt] + v[:k-1], k-1)[:k] (:22-47).
+ * numpy's float64 partition of so short a vector returns it SORTED (numpy >= 2.0 on AVX2 / AVX-512 hosts dispatches to
+ * x86-simd-sort, whose qselect runs a bitonic sorting network on arrays of <= 256 elements; pinned by
+ * tests/golden/tore_unsorted_*.npz, generated here with numpy 2.2.6 on an AVX-512 host), so a step inserts dt into the
+ * ascending k - 1 smallest kept so far, and the largest of the k is dropped by the pixel's NEXT event.  (The scalar
+ * introselect of other numpy builds only swaps the maximum to the end: the same values in another order whenever the
+ * timestamps are not ascending.)  On time-sorted input every new dt is the smallest: a k-deep FIFO, newest first.
+ * Then float32: clamp to 5e8, log(v+1) - log(151), floor 0.
  * out is (Hf, Wf, 2k) float32: pos[0..k), neg[0..k).
  * ------------------------------------------------------------------------------------------- */
 int oracle_tore(const int32_t *x, const int32_t *y, const int32_t *ts, const int32_t *pol, int64_t n,
@@ -309,8 +315,11 @@ int oracle_tore(const int32_t *x, const int32_t *y, const int32_t *ts, const int
             if (r < 0) r += Hf; /* numpy negative-index wrap */
             if (c < 0) c += Wf;
             double *f = fifo + ((r * Wf + c) * 2 + (is_pos ? 0 : 1)) * k;
-            for (int j = k - 1; j > 0; --j) f[j] = f[j - 1];
-            f[0] = T - (double)ts[i];
+            /* w = [dt] + f[:k-1], sorted ascending (insertion of dt into the sorted k - 1 kept values) */
+            double dt = T - (double)ts[i];
+            int j = k - 1;
+            while (j > 0 && f[j - 1] > dt) { f[j] = f[j - 1]; --j; }
+            f[j] = dt;
         }
     }
     const double log_min = log(150.0 + 1.0);

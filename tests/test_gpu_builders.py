@@ -164,10 +164,44 @@ def test_status_bits_and_exceptions(eng):
     from conftest import assert_bit_equal as abe
     import oracle as orc
     abe(get_optimized_representation(to_structured(unsorted), 500, H, W), orc.ergo12(unsorted, H, W))
-    # TORE's order on such a window is whatever numpy's introselect leaves behind (tore.py:22-25: np.partition of a 6-vector
-    # whose new element is not the smallest): refused, loudly
-    with pytest.raises(NotImplementedError):
-        gen1_transforms.get_item_transform(to_structured(unsorted), "<function events2ToreFeature at 0x0>", None, H, W, 500, 50000)
+    # TORE runs in array order too (r05; goldens: test_tore_on_unsorted_timestamps): here against the oracle
+    rep = gen1_transforms.get_item_transform(to_structured(unsorted), "<function events2ToreFeature at 0x0>", None, H, W, 500, 50000)
+    np.testing.assert_allclose(rep, orc.tore_bbox(unsorted, 6) * 255, rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("enc", ["pm1", "01"])
+def test_tore_on_unsorted_timestamps(enc):
+    """events2ToreFeature on timestamps that are NOT ascending (r05): the reference keeps np.partition([t] + v[:k-1], k-1)[:k]
+    per event in array order (tore.py:22-25); goldens from the reference's own function and dispatcher
+    (tests/golden/make_golden_r05.py; numpy's sorting partition), host result and device result, and every binning pass."""
+    import torch
+    from event_representation_study_amd import _lib, engine as eng
+    from event_representation_study_amd.representations import gen1_transforms
+    from event_representation_study_amd.representations.tore import events2ToreFeature
+    g = load_golden("tore_unsorted_40x30_n3000")
+    H, W = int(g["H"]), int(g["W"])
+    ev = g["events_" + enc]
+    N = ev.shape[0]
+    x, y, ts, pol = ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3]
+    np.testing.assert_allclose(events2ToreFeature(x, y, ts, pol, ts[-1], 6, (H, W)), g["tore6_" + enc], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(events2ToreFeature(x, y, ts, pol, 30000, 3, (H, W)), g["tore3_mid_" + enc], rtol=1e-6, atol=1e-6)
+    # float64 timestamps (seconds), the same order: the float path of the kernel
+    np.testing.assert_allclose(events2ToreFeature(x, y, ts + 0.25, pol, float(ts[-1]) + 0.25, 6, (H, W)),
+                               g["tore6_" + enc], rtol=0, atol=2e-3)     # (non-integral microseconds: the same intervals)
+    rec = to_structured(ev)
+    rep = gen1_transforms.get_item_transform(rec, "<function events2ToreFeature at 0x0>", None, H, W, N, 50000)
+    want = g["dispatch_" + enc]
+    assert rep.shape == want.shape and rep.dtype == want.dtype
+    np.testing.assert_allclose(rep, want, rtol=1e-6, atol=1e-4)
+    assert np.array_equal(rec["p"], g["p_after_" + enc])
+    dev = gen1_transforms.get_item_transform_cuda(to_structured(ev), "<function events2ToreFeature at 0x0>", None, H, W, N, 50000)
+    assert np.array_equal(dev.cpu().numpy(), rep)
+    for flags in (None, _lib.PLAN_NO_KEY_PASS, _lib.PLAN_FORCE_KEY_SORTED, _lib.PLAN_THREE_KERNEL):
+        offs = torch.tensor([0, N, 2 * N], dtype=torch.int64)
+        eb = eng.EventBatch(torch.from_numpy(np.concatenate([ev, ev])).cuda(), offs, H, W, plan_flags=flags)
+        got = eb.tore(6, frame_mode=2).cpu().numpy()
+        for b in range(2):
+            np.testing.assert_allclose(got[b], g["tore6_" + enc], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("enc", ["pm1", "01"])

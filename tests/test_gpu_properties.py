@@ -281,3 +281,88 @@ def test_two_plans_two_streams_two_host_threads(eng, oracle):
     for k in range(2):
         for b in range(2):
             assert np.array_equal(results[k][b], want[k])
+
+
+def _clustered_batch(eng, seeds, H=240, W=304, N=50000):
+    from event_representation_study_amd.synthetic import GENERATORS
+    wins = [GENERATORS["circle"](N, W, H, seed=s) for s in seeds]
+    return wins, eng.EventBatch.from_numpy(wins, H, W)
+
+
+def test_one_plan_two_workspaces_two_streams_two_host_threads(eng, oracle):
+    """ABI 3: a plan is read-only after evrep_plan_init (the hot-unit list and its state live in the workspace), so ONE plan
+    may drive two workspaces on two streams from two host threads.  Clustered windows: the voxel / TORE builders defer hot
+    units to their hot launch on every call, which is what used to flip a bit in the caller's plan."""
+    import threading
+    import torch
+    H, W = 240, 304
+    sets = [[301, 302], [303, 304]]
+    batches, wants = [], []
+    for seeds in sets:
+        wins, eb = _clustered_batch(eng, seeds, H, W)
+        batches.append(eb)
+        wants.append([(oracle.voxel(ev, H, W, 5), oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W)))
+                      for ev in wins])
+    plan_bytes = bytes(batches[0].plan)
+    assert bytes(batches[1].plan) == plan_bytes      # same geometry and sizes: the same plan
+    batches[1].plan = batches[0].plan                # ... literally the same struct
+    errors, results = [], [None, None]
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                eb = batches[k]
+                for _ in range(20):
+                    eb.rebin()
+                    vox = eb.voxel(5)
+                    tore = eb.tore(6, frame_mode=2)
+                stream.synchronize()
+                results[k] = (vox.cpu().numpy(), tore.cpu().numpy())
+        except Exception as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert bytes(batches[0].plan) == plan_bytes      # nothing wrote through the const pointer
+    for k in range(2):
+        for b in range(2):
+            assert np.array_equal(results[k][0][b].view(np.uint64), wants[k][b][0].view(np.uint64))
+            np.testing.assert_allclose(results[k][1][b], wants[k][b][1], rtol=1e-6, atol=1e-6)
+
+
+def test_graph_of_builder_calls_with_hot_units_replays(eng, oracle):
+    """Two builder calls that both defer hot units, captured in ONE hipGraph: every replay leaves the workspace's hot list
+    empty again (exit tickets), so replays neither accumulate items nor depend on host state."""
+    H, W = 240, 304
+    wins, eb = _clustered_batch(eng, [311, 312], H, W)
+    vox = torch.empty((2, H, W, 5), dtype=torch.float64, device="cuda:0")
+    acc = None
+
+    def step():
+        eb.voxel(5, out=vox)
+        return eb.optimized(dtype=torch.float32)
+
+    eb.rebin()
+    ref32 = step().clone()
+    refv = vox.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            acc = step()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        vox.zero_()
+        acc.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(vox, refv) and torch.equal(acc, ref32)
+    for b, ev in enumerate(wins):
+        assert np.array_equal(refv[b].cpu().numpy().view(np.uint64), oracle.voxel(ev, H, W, 5).view(np.uint64))
