@@ -99,6 +99,7 @@ __device__ inline bool decode_window_block(int B, int nblk, int &b, int &blk) {
 }
 
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = H * 4 bytes.
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                       int B, int H, int W, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, BlockStats *__restrict__ stats) {
@@ -169,10 +170,12 @@ static __global__ __launch_bounds__(kBinThreads) void k_row_hist(const int4 *__r
     uint32_t *dst = table + ((size_t)b * nblk + blk) * H;
     for (int i = threadIdx.x; i < H; i += kBinThreads) dst[i] = hist[i];
 }
+#endif
 
 // grid (B), 256 threads, dynamic LDS = (H + 8) * 4 bytes.
 // table[b][blk][row] -> exclusive prefix over blk; row_off[b][row] = global start of the row;
 // meta[b] = reduction of the window's block statistics.
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *__restrict__ off, int H, int chunk, int nblk,
                                                       uint32_t *__restrict__ table, uint32_t *__restrict__ row_off,
                                                       const BlockStats *__restrict__ stats, WindowMeta *__restrict__ meta) {
@@ -228,10 +231,12 @@ static __global__ __launch_bounds__(kBinThreads) void k_row_scan(const int64_t *
         meta[b] = m;
     }
 }
+#endif
 
 // grid (8 * ceil(B/8) * nblk), 256 threads, dynamic LDS = 4 * H * 4 bytes.  Stable placement by sensor row.
 // Each wave owns a contiguous quarter of the block's events and keeps them in registers between
 // the counting and the placement phase (one HBM read of the events for both).
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kBinThreads) void k_row_scatter(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                          int B, int H, int W, int chunk, int nblk,
                                                          const uint32_t *__restrict__ table,
@@ -307,6 +312,7 @@ static __global__ __launch_bounds__(kBinThreads) void k_row_scatter(const int4 *
         }
     }
 }
+#endif
 
 // Fused form of k_row_scan + k_row_scatter for sensors whose per-row tables fit one workgroup's LDS
 // (fused_scatter_lds_bytes() <= 64 KB; 640x480 and 1280x720 do): every block derives its own
@@ -321,6 +327,7 @@ __host__ __device__ inline size_t fused_scatter_lds_bytes(int H) {
     return (size_t)(kBinWaves + 3) * H * sizeof(uint32_t) + (size_t)kStageRecs * sizeof(Rec);
 }
 
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                                int B, int H, int W, int chunk, int nblk,
                                                                const uint32_t *__restrict__ table,
@@ -467,12 +474,14 @@ static __global__ __launch_bounds__(kBinThreads) void k_row_scatter_fused(const 
         sorted1[delta[row] + t] = rec;
     }
 }
+#endif
 
 // grid (H, B), 64 threads, dynamic LDS = W * 4 bytes.  Stable placement by column inside one row,
 // by ONE wave: afterwards sorted2 is ordered by (window, pixel id, rank).  Rows of up to 256 records
 // (the common case) keep their records in registers between counting and placement; longer rows
 // are walked twice.  Also emits, per row, the record offsets of every kChunkPx-pixel column chunk
 // (what one builder wavefront consumes).
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict__ sorted1, const uint32_t *__restrict__ row_off,
                                                    int H, int W, int nchunk, Rec *__restrict__ sorted2,
                                                    uint32_t *__restrict__ chunk_off) {
@@ -548,6 +557,7 @@ static __global__ __launch_bounds__(kWave) void k_col_sort(const Rec *__restrict
         }
     }
 }
+#endif
 
 // =====================================================================================================
 // Two-kernel binning pass (windows of up to kBsMaxBlocks * 8192 events on sensors of up to ~720 rows; the
@@ -582,6 +592,7 @@ __host__ __device__ inline size_t block_rowsort_lds_bytes(int H) {
 
 // grid (8 * ceil(B/8) * nblk), 1024 threads, dynamic LDS = block_rowsort_lds_bytes(H).
 // table: [B][nblk][H + 1] exclusive offsets of the block's rows inside its run (entry H = in-frame events).
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 *__restrict__ ev, const int64_t *__restrict__ off,
                                                              int B, int H, int W, int nblk, uint32_t *__restrict__ table,
                                                              BlockStats *__restrict__ stats, Rec *__restrict__ sorted1) {
@@ -678,6 +689,7 @@ static __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 
         if (in && !(BS_DEBUG & 1)) {
             if (valid) ++st.n_valid;
             if (tprev[i] > e[i].z) st.status |= EVREP_ST_UNSORTED;
+            if ((uint32_t)(e[i].w + 1) > 2u) st.status |= kStEscaped;   // (rec8_pack escapes it: builders that hand hot units to a split sweep need to know)
             st.tmin = min(st.tmin, e[i].z); st.tmax = max(st.tmax, e[i].z);
             st.xmin = min(st.xmin, e[i].x); st.xmax = max(st.xmax, e[i].x);
             st.ymin = min(st.ymin, e[i].y); st.ymax = max(st.ymax, e[i].y);
@@ -739,6 +751,7 @@ static __global__ __launch_bounds__(kBsThreads) void k_block_rowsort(const int4 
     if (!(BS_DEBUG & (4 | 16)))
         for (uint32_t t = threadIdx.x; t < total; t += kBsThreads) dst[t] = stage[t];
 }
+#endif
 
 // grid (ceil(H / kCsWaves), B), kCsWaves * 64 threads = kCsWaves independent waves (no block barrier), one sensor row each;
 // dynamic LDS = kCsWaves * col_sort_wave_words(W) * 4.  A lane reads the row's offsets in TWO block runs (lane and
@@ -757,6 +770,7 @@ __host__ __device__ inline int col_sort_wave_words(int W) { return col_sort_word
 #ifndef CS_WAVES
 #define CS_WAVES 8   // 63 VGPRs, no scratch: dense binning 123 -> 119 us (1 Mpx), 80 -> 78 us (640x480)
 #endif
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_waves_per_eu(CS_WAVES))) void k_col_sort_runs(const int4 *__restrict__ ev, const Rec *__restrict__ sorted1, const int64_t *__restrict__ off,
                                                                      const uint32_t *__restrict__ table,
                                                                      const BlockStats *__restrict__ stats, int H, int W, int nblk,
@@ -809,7 +823,7 @@ static __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_wave
         if (lane == 0) {
             WindowMeta m;
             m.tmin = st.tmin; m.tmax = st.tmax; m.xmin = st.xmin; m.xmax = st.xmax; m.ymin = st.ymin; m.ymax = st.ymax;
-            m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status; m.n_valid = st.n_valid;
+            m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status & 0xffffu; m.n_valid = st.n_valid;   // (upper half: the library's own bits)
             if (n_win <= 0) m.status |= EVREP_ST_EMPTY;
             else if (st.tmin == st.tmax) m.status |= EVREP_ST_FLAT_TIME;
             for (int i = 0; i < 6; ++i) m.pad[i] = 0;
@@ -944,6 +958,7 @@ static __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_wave
         }
     }
 }
+#endif
 
 // =====================================================================================================
 // Key-sorted binning pass (plan->reserved == 2): ONE kernel.  A workgroup orders its 8192 events by the KEY
@@ -1085,6 +1100,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
         if (in) {
             if (valid) ++st.n_valid;
             if (tprev[i] > e[i].z) st.status |= EVREP_ST_UNSORTED;
+            if ((uint32_t)(e[i].w + 1) > 2u) st.status |= kStEscaped;   // (rec8_pack escapes it: builders that hand hot units to a split sweep need to know)
             st.tmin = min(st.tmin, e[i].z); st.tmax = max(st.tmax, e[i].z);
             st.xmin = min(st.xmin, e[i].x); st.xmax = max(st.xmax, e[i].x);
             st.ymin = min(st.ymin, e[i].y); st.ymax = max(st.ymax, e[i].y);
@@ -1228,6 +1244,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
 
 // grid (B), 64 threads: the window statistics of the key-sorted pass, for the synchronous read-backs only
 // (the builders merge the block statistics they need themselves).
+#ifdef EVREP_TU_CORE   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__restrict__ nwin, const BlockStats *__restrict__ stats,
                                                       int nblk, int chunk_shift, WindowMeta *__restrict__ meta) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1240,12 +1257,13 @@ static __global__ __launch_bounds__(kWave) void k_window_meta(const int64_t *__r
     if (lane == 0) {
         WindowMeta m;
         m.tmin = st.tmin; m.tmax = st.tmax; m.xmin = st.xmin; m.xmax = st.xmax; m.ymin = st.ymin; m.ymax = st.ymax;
-        m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status; m.n_valid = st.n_valid;
+        m.neg_flags = st.neg_flags; m.oob_flags = st.oob_flags; m.status = st.status & 0xffffu; m.n_valid = st.n_valid;   // (upper half: the library's own bits)
         if (n_win <= 0) m.status |= EVREP_ST_EMPTY;
         else if (st.tmin == st.tmax) m.status |= EVREP_ST_FLAT_TIME;
         for (int i = 0; i < 6; ++i) m.pad[i] = 0;
         meta[b] = m;
     }
 }
+#endif
 
 }  // namespace evrep

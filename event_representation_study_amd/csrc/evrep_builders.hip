@@ -370,6 +370,22 @@ __device__ inline bool defer_unit(const BinView &bv, int uid, int nparts, uint32
     return false;
 }
 
+// main launch: unit `uid` goes to the hot list as ONE item, untouched (Split::in_hot)
+__device__ inline bool defer_whole(const BinView &bv, int uid) {
+    const uint32_t capl = hot_sublist_cap(bv.hot_cap);
+    uint32_t l = ((uint32_t)uid * 0x9E3779B1u) >> 26;
+    for (int tries = 0; tries < kHotLists; ++tries, l = (l + 1) % kHotLists) {   // (wave-uniform)
+        uint32_t at = 0;
+        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[l * 16], 1u);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at < capl) {
+            if (threadIdx.x == 0) bv.hot[kHotHdrWords + (size_t)l * capl + at] = (uint32_t)uid * (uint32_t)kHotCodes + (uint32_t)kHotWhole;
+            return true;
+        }
+    }
+    return false;
+}
+
 // grid (ceil(nchunk/span), H, B): unit -> (window, sensor row, `span` consecutive 128-pixel chunks).
 // span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
 __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, const UnitCfg &uc, int &chunk, int &nch, int u) {
@@ -484,11 +500,18 @@ __device__ inline UnitVisit<F> unit_visit(F f, int words_per_px) { return UnitVi
 // split.begin() is the builder's late set-up (wave-uniform; false: the unit takes the ordered paths); split.done() says whether
 // the sweep saw only records it could handle (else the unit takes the ordered paths, in this launch: a builder with a split path
 // defers nothing and has no hot launch).  Kept records beyond the list's room go to the unit's slot of the spill stream.
-struct NoSplit { static constexpr bool enabled = false; };
-template <typename Begin, typename F, typename Done>
-struct UnitSplit { static constexpr bool enabled = true; Begin begin; F f; Done done; int words_per_px; };
-template <typename Begin, typename F, typename Done>
-__device__ inline UnitSplit<Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px) { return UnitSplit<Begin, F, Done>{b, f, d, words_per_px}; }
+// IN_HOT (r05b): the split sweep runs in the builder's HOT launch instead -- the float32 builders' main waves have neither the LDS
+// (half the tile, twice the pixels per unit: the words alone would fill it) nor the registers for it (their budget is the sparse
+// paths': inlined, the sweep cost the float32 ERGO-12 main launch an occupancy step and 10-18 % on uniform windows).  A main wave
+// hands a unit beyond its record stage to the hot launch AS A WHOLE and at once -- no sweep, no slot (item code kHotWhole;
+// st_lane = lane k: the status word of the window's block k, whose kStEscaped bit says that the window holds records the split
+// cannot take: its units go the ordered ways) -- and the hot wave, with a stage of kHotSplitStage records and deeper batches,
+// sweeps, orders the kept records and emits it.
+struct NoSplit { static constexpr bool enabled = false; static constexpr bool in_hot = false; };
+template <bool IN_HOT, typename Begin, typename F, typename Done>
+struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; Begin begin; F f; Done done; int words_per_px; uint32_t st_lane; };
+template <bool IN_HOT = false, typename Begin, typename F, typename Done>
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane}; }
 #ifndef EVREP_SPLIT_BATCHES
 #define EVREP_SPLIT_BATCHES 8
 #endif
@@ -658,9 +681,13 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #ifndef EVREP_MAIN_SPILL_BATCH
 #define EVREP_MAIN_SPILL_BATCH 4
 #endif
-    constexpr int kSpillBatch = HOT ? 16 : EVREP_MAIN_SPILL_BATCH;
+#ifndef EVREP_HOT_SPILL_BATCH
+#define EVREP_HOT_SPILL_BATCH 16   // 8 KB of records in flight per hot wave: a unit of 20 000 records is 20 rounds of latency, not 80
+#endif
+    constexpr int kSpillBatch = HOT ? EVREP_HOT_SPILL_BATCH : EVREP_MAIN_SPILL_BATCH;   // (a hot wave only sweeps on the split path)
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
-    if constexpr (HOT) {
+    if (HOT && !(Split::enabled && Split::in_hot && part == kHotWhole)) {
+      if constexpr (HOT) {
         // The unit's MAIN wave has laid its records out in the unit's slot, pixel-sorted (r04c; until then every hot wave
         // sorted its part out of the unit's records itself: two sweeps over ALL of them per piece, ~5 000 of a piece's ~7 000
         // instructions -- and the hot launch is bound by VALU throughput).  Lane l finds the records of its pixel by two
@@ -681,6 +708,19 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         u.nstaged = 0;
         u.dpx = dpx; u.npixu = npixu;
         return u;
+      }
+    }
+    if constexpr (Split::enabled && Split::in_hot && !HOT) {
+        // (wave-uniform) a window without escaped polarities: the unit goes to the hot launch's split sweep, whole and untouched
+        const uint32_t stw = wave_or(lane < nb ? split.st_lane : 0u);
+        // (warm units too -- those that would fit this wave's hot stage: measured, r05b, ordering them here makes the main launch
+        //  of a clustered batch 30-40 % longer, which the hot launch they spare does not give back)
+        if (!(stw & kStEscaped) && nrec <= 65535u && dpx == 0) {
+            if (!defer_whole(bv, uid) && lane == 0) atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);
+            u.deferred = true;
+            u.ce = nrec;
+            return u;
+        }
     }
     for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
     wave_phase();
@@ -784,7 +824,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             return u;
         }
     }
-    if constexpr (Split::enabled && !HOT) {
+    if constexpr (Split::enabled && HOT == Split::in_hot) {
         const uint32_t room = (uint32_t)(reinterpret_cast<const unsigned char *>(w.segs) - reinterpret_cast<const unsigned char *>(w.tile));
         const uint32_t wbytes = ((uint32_t)npixu * (uint32_t)split.words_per_px * 4u + 15u) & ~15u;
         // 16-bit fields in the builder's words: a unit of up to 65 535 records.  (wave-uniform)
@@ -830,6 +870,11 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             // the ordered paths after all: they count from zero
             for (int v = lane; v * 4 < npixu; v += kWave) cnt4[v] = make_uint4(0u, 0u, 0u, 0u);
             wave_phase();
+        }
+        if constexpr (HOT) {   // (cannot happen: the main wave has checked what the sweep checks; a hot wave has no ordered way for a whole unit)
+            if (lane == 0) atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);
+            u.deferred = true;
+            return u;
         }
     }
     if constexpr (LAST && !HOT) {
@@ -915,7 +960,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #endif
         // a builder with a split path has no hot launch behind it: the few units that fall back here (escaped polarity values,
         // more than 65 535 records) are emitted from their slot by this wave, whatever they hold
-        if constexpr (Split::enabled) fits = true;
+        if constexpr (Split::enabled && !Split::in_hot) fits = true;
         defer = !fits;   // (deferred AFTER the placement below: the hot waves read the unit from its slot)
         defer_mask = splitmask;
     }
@@ -1762,7 +1807,11 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
         for (int c = 0; c < D::kMaxC; ++c) vals[c] = (OutT)rr[c];
     };
 
-    constexpr bool kSplit = !HOT && MdesIsErgo12<D>::value && sizeof(OutT) == 8;
+    // the float64 instance sweeps in its MAIN launch, the float32 instance in its HOT launch (UnitSplit, IN_HOT): kSplit = this
+    // instance runs the sweep and emits from it, kSplitDefer = this instance hands such units over
+    constexpr bool kSplitHot = MdesIsErgo12<D>::value && sizeof(OutT) < 8;
+    constexpr bool kSplit = MdesIsErgo12<D>::value && (kSplitHot ? HOT : !HOT);
+    constexpr bool kSplitDefer = kSplitHot && !HOT;
     ChunkGeom g;
     UnitRecs u;
     bool esc = false;   // the split sweep met a record it cannot take
@@ -1825,7 +1874,18 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             return h6 || h1;
         };
         auto sdone = [&]() -> bool { return !__any(esc); };
-        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split(sbegin, sf, sdone, kErgoSplitWords));
+        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split<kSplitHot>(sbegin, sf, sdone, kErgoSplitWords));
+    } else if constexpr (kSplitDefer) {
+        auto never = []() -> bool { return false; };
+        auto nof = [](uint32_t, const Rec8 &, uint2 &) -> bool { return false; };
+        // lane k: the status word of the window's block k (meta_prefetch: q2.x), merged by unit_records only when a unit is hot
+        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
+                                                  unit_split<true>(never, nof, never, kErgoSplitWords,
+                                                                   (uint32_t)mraw.q2.x | (uc.span > 1 ? kStEscaped : 0u)));
+        // (two-chunk units -- sparse windows, 640x480 / 1280x720 at 50 000 - 200 000 events -- keep the ordered ways: measured, r05b,
+        //  their hot units are few and huge -- 4 000 to 20 000 records, one wave's instruction stream each, 30 to 100 us of sweep --
+        //  and the hot launch's tail costs 5-8 % more than it saves; at the reference's Gen1 shape the hand-over takes the
+        //  circle / edge streams from 133 / 125 us to 90 / 106)
     } else {
         u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
     }
@@ -2020,7 +2080,7 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
 }
 
 template <typename OutT, typename D, bool HOT = false>
-__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave, HOT ? ((MdesIsErgo12<D>::value && sizeof(OutT) < 8) ? 3 : 4) : 1) void k_mdes(BinView bv, const int64_t *__restrict__ off,
                                                MdesParams P, int H, int W, int nchunk, UnitCfg uc, double scale,
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2049,6 +2109,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_mdes(BinView bv, const i
 // reference's own float64 comparisons (a NaN t_s -- a window of one timestamp -- fails them all: empty windows, as there).
 // grid (B), 1024 threads: bounds [B][8][2], wflags [B][2] = {bit w: window w holds a p == -1 event; bit 8 k + w: window w
 // holds an out-of-frame event of polarity class k (0 any, 1 p == 1, 2 p == -1, 3 p == 0)}.
+#ifdef EVREP_TU_MDES   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int H, int W,
                                                           int32_t *__restrict__ bounds, uint32_t *__restrict__ wflags) {
     __shared__ int cnt[10];
@@ -2120,6 +2181,7 @@ static __global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__
     __syncthreads();
     if (tid < 2) wflags[2 * b + tid] = fl[tid];
 }
+#endif
 
 // --------------------------------------------------------------------------------------------
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
@@ -2203,6 +2265,7 @@ static_assert(sizeof(TsCuts) == kTsCutsBytes, "TsCuts");
 
 // grid (B), 64 threads.  indices == nullptr: the dispatcher's searchsorted cuts; otherwise DEVICE
 // int32 [B, S] event indices as ToTimesurface.__call__(events, indices) receives them.
+#ifdef EVREP_TU_BUILDERS   // (compiled by the one translation unit that launches it)
 static __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__restrict__ off, int S,
                           const int32_t *__restrict__ indices, double tau, double scale, TsCuts *__restrict__ cuts,
                           const double *__restrict__ tf) {
@@ -2275,6 +2338,7 @@ static __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__r
         cuts[b].direct = tf ? 1 : direct;   // float timestamps: exponentials per slice
     }
 }
+#endif
 
 // CM = compile-time channel capacity, 2 * slices <= CM (12 or 16); FACT = the factorised exponentials are compiled in
 // (launches on sparse windows; dense windows run the leaner per-slice form)
@@ -2869,6 +2933,7 @@ __global__ __launch_bounds__(kThreads) void k_resize_taps(const InT *__restrict_
 // tile builder: this path serves resized event streams, not the headline windows.
 // grid (ceil(H*W / 256), B), 256 threads; out DEVICE float32 (B, H, W, bins).
 // --------------------------------------------------------------------------------------------
+#ifdef EVREP_TU_BUILDERS   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *__restrict__ ev, const Rec *__restrict__ sorted,
                                                             const uint32_t *__restrict__ chunk_off, const int64_t *__restrict__ off,
                                                             const double *__restrict__ xy, int H, int W, int nchunk, int bins,
@@ -2919,6 +2984,7 @@ static __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *
 #pragma unroll
     for (int c = 0; c < EVREP_MAX_CHANNELS; ++c) if (c < bins) dst[c] = acc[c];
 }
+#endif
 
 // --------------------------------------------------------------------------------------------
 // Placement probe: the write footprint of the float64 12-channel builder (one wave per 12 KiB tile, XCD-contiguous
@@ -2927,6 +2993,7 @@ static __global__ __launch_bounds__(kThreads) void k_voxel_subpixel(const int4 *
 // tools/microbench/placement_patterns.hip); engine.probe_output_placement times it into candidate allocations.
 // grid (tiles), 64 threads, dynamic LDS 8320 B.  Writes zeros.
 // --------------------------------------------------------------------------------------------
+#ifdef EVREP_TU_BUILDERS   // (compiled by the one translation unit that launches it)
 static __global__ __launch_bounds__(kWave) void k_store_probe(float *__restrict__ out, int ntiles) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef float nt4 __attribute__((ext_vector_type(4)));
@@ -2937,5 +3004,6 @@ static __global__ __launch_bounds__(kWave) void k_store_probe(float *__restrict_
 #pragma unroll
     for (int q = 0; q < 12; ++q) __builtin_nontemporal_store(z, b + q * kWave);
 }
+#endif
 
 }  // namespace evrep

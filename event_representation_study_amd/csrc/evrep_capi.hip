@@ -1,6 +1,7 @@
 // evrep_capi.hip -- the extern "C" surface declared in include/evrep.h, part 1: plans, the binning pass, the read-backs
 // (argument checks, workspace carving and kernel launches).  The builders are in evrep_capi_mdes.hip /
 // evrep_capi_builders.hip, the Gromov-Wasserstein side in evrep_capi_gwd.hip; evrep_capi_shared.h is what they share.
+#define EVREP_TU_CORE 1
 #include "evrep_capi_shared.h"
 
 // kernels

@@ -1,5 +1,6 @@
 // evrep_capi_builders.hip -- the extern "C" surface, part 3: EventStack, TimeSurface, TORE, the voxel grids, the n_imagenet
 // accumulators, EST, the resize taps and the store probe.
+#define EVREP_TU_BUILDERS 1
 #include "evrep_capi_builders.h"
 
 extern "C" {

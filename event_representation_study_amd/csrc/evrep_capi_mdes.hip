@@ -1,4 +1,5 @@
 // evrep_capi_mdes.hip -- the extern "C" surface, part 2: MixedDensityEventStack / Operations / ERGO-12 (k_mdes).
+#define EVREP_TU_MDES 1
 #include "evrep_capi_builders.h"
 
 extern "C" {
@@ -47,10 +48,13 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
-        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it */          \
+        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it; the float32 one   \
+           hands hot units to its hot launch whole (Split, IN_HOT): a stage of kHotSplitStage records there */                   \
         const bool hot_launch = plan->reserved == 2 && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                             \
-        if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(  \
-            bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), scale, static_cast<T *>(out)); \
+        UnitCfg hc = hot_cfg(uc);                                                                                             \
+        if (MdesIsErgo12<DESC>::value) hc.stage = kHotSplitStage;                                                             \
+        if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(  \
+            bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hc, scale, static_cast<T *>(out)); \
     } while (0)
 #define MDES_RUNTIME(T)                                     \
     do {                                                    \

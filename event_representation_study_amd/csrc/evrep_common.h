@@ -26,6 +26,9 @@ constexpr int kHotGrid = EVREP_HOT_GRID;      // workgroups of a hot launch
 constexpr int kHotParts = 8;                  // parts per unit at most (TORE's two-chunk units straddle three chunks: six)
 constexpr int kHotCodes = 64;                 // item = unit id * kHotCodes + piece code
 constexpr int kHotLists = 64;
+constexpr int kHotWhole = kHotCodes - 1;      // piece code: the WHOLE unit, taken by the hot wave's split sweep (unit_records, Split::in_hot)
+constexpr int kHotSplitStage = 576;           // records of the LDS stage of a hot launch whose waves take whole units by the split path
+constexpr uint32_t kStEscaped = 1u << 16;     // BlockStats::status, internal: the block holds a polarity outside {-1, 0, 1} (escaped in its 8-byte record)
 constexpr int kHotHdrWords = 2 * kHotLists * 16;   // [l * 16]: sublist l's item count, [(kHotLists + l) * 16]: its exit ticket
 static_assert(kHotGrid % kHotLists == 0, "every sublist is worked off by kHotGrid / kHotLists workgroups");
 // items one sublist holds: eight times its fair share (a full one sends the unit to the next)

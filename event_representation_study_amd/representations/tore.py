@@ -11,7 +11,7 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
     """TORE volume for one sample time.  x, y are 1-based (the reference indexes ``[i - 1, j - 1]``);
     returns (frameSize[0], frameSize[1], 2k) float32: the k most recent log-intervals per polarity.  Timestamps need not
     be ascending: the kernel then keeps, per event in array order, what the reference's ``np.partition`` on its k-vector
-    keeps (tore.py:22-25; the order of the kept values is the sorting numpy's -- see oracle/evrep_oracle.c, oracle_tore).
+    keeps (tore.py:22-25; the order of the kept values is the sorting numpy's -- see k_tore in csrc/evrep_builders.hip).
 
     Float inputs behave as in the reference: float coordinates cannot index (IndexError), so it falls into its
     ``except`` branch and truncates them with int() (tore.py:29-33); float timestamps are used as they are --

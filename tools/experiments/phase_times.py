@@ -21,7 +21,8 @@ if os.environ.get("SHAPE"):   # SHAPE=W,H,N,B: another workload (dense windows: 
 DIST = os.environ.get("DIST", "uniform")   # uniform | circle | edges (synthetic.GENERATORS)
 eb = EventBatch.from_numpy([GENERATORS[DIST](N, W, H, seed=i) for i in range(B)], H, W)
 eb.bin()
-outs = [torch.empty((B, H, W, 12), dtype=torch.float64, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
+DT = torch.float32 if os.environ.get("DTYPE") == "f32" else torch.float64   # DTYPE=f32: the float32 ERGO-12 instance
+outs = [torch.empty((B, H, W, 12), dtype=DT, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
 holds = [int(v) for v in sys.argv[1:]] or [0, 600, 670]
 nunit = B * H * ((W + 127) // 128)
 assert nunit * 64 <= (eb.total + 1) * 8, "the idle half of the record stream is too small for the marks"
@@ -31,13 +32,13 @@ for o in outs:
     for h in holds:
         check(eb.lib.evrep_plan_set_pacing(ctypes.byref(eb.plan), h), "pacing")
         for _ in range(3):
-            eb.optimized(out=o)
+            eb.optimized(out=o, dtype=DT)
         torch.cuda.synchronize()
         dbg.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
-            eb.optimized(out=o)
+            eb.optimized(out=o, dtype=DT)
         b.record()
         torch.cuda.synchronize()
         d = dbg.cpu().numpy().astype(float) / 100.0

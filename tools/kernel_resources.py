@@ -7,9 +7,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "event_representation_study_amd", "csrc")
+# usage: kernel_resources.py [translation unit, default evrep_capi_mdes.hip] [extra hipcc flags]
+unit = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "evrep_capi_mdes.hip"
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-       "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, "evrep_capi.hip"), "-o", "/tmp/_kr.o",
-       "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
+       "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, unit), "-o", "/tmp/_kr.o",
+       "-Rpass-analysis=kernel-resource-usage"] + [a for a in sys.argv[1:] if not a.endswith(".hip")]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
