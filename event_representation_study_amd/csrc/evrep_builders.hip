@@ -60,10 +60,27 @@ struct UnitCfg {
     int partpx;  // pixels of one part tile: 64 (kPartPx), or 128 for narrow pixels, whose 64-pixel tiles are too small to
                  // pay for their own fill / store / phase sequence (n_imagenet accumulators 67 -> 62 us, EventStack 87 -> 81)
     int hold;    // store pacing: the wave starts its stores no earlier than `hold` x 10 ns after it started (0 = off)
+    // Unit id -> (window, row, unit of the row) without integer divisions (r05b: the front of every builder wave ran four of
+    // them -- ~35 dependent scalar / reciprocal instructions each -- before its first load could be issued): the host hands the
+    // units per row and two multiply-shift reciprocals over (fastdiv_make; exact for ids < 2^31, which evrep_plan_init ensures)
+    int nunit;
+    uint32_t nunit_m, nunit_sh, h_m, h_sh;
+    int xflags;  // experiment switches (EVREP_PLAN_X_*): bit 0 = two-chunk float32 ERGO-12 units also go to the hot launch whole
     int merge;   // 1: the row's last unit also takes the short tail chunk of a sensor whose width is not a multiple of 128 (r04:
                  // Gen1's 304-pixel rows are 128 + 128 + 48 -- a third of the units were 48-pixel tails with a full unit's
                  // fixed cost; now a row is two units, 128 and 176 pixels)
 };
+// floor(n / d) for 0 <= n < 2^31 as mulhi(n, m) >> sh (Granlund-Montgomery: l = ceil(log2 d), m = floor(2^(31 + l) / d) + 1,
+// sh = l - 1; m == 0 stands for d == 1)
+__host__ inline void fastdiv_make(uint32_t d, uint32_t &m, uint32_t &sh) {
+    m = 0; sh = 0;
+    if (d <= 1) return;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (uint32_t)(((1ull << (31 + l)) / d) + 1ull);
+    sh = l - 1;
+}
+__device__ inline uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t sh) { return m ? (__umulhi(n, m) >> sh) : n; }
 // units per sensor row / the chunks of unit `ur` of a row
 __host__ __device__ inline int units_per_row(int nchunk, int span, int merge) {
     return merge ? ((nchunk - 1 + span - 1) / span > 0 ? (nchunk - 1 + span - 1) / span : 1) : (nchunk + span - 1) / span;
@@ -249,6 +266,7 @@ struct BinView {
     // fit its stage; the hot launch behind it works them off and leaves the list empty.
     uint32_t *hot;
     uint32_t hot_cap;
+    double *placed_pool;        // key-sorted: the idle upper half of sorted1 (8 bytes per event of the batch): where a sliced hot unit's kept records are ordered
     BlockStats *stats_rw;       // key-sorted: a main wave that cannot defer a unit (every sublist full) reports it in the window's status
 #ifdef EVREP_TIMING
     unsigned long long *dbg;
@@ -272,6 +290,7 @@ struct UnitRecs {
     uint32_t pst, pen;   // hot launch, per lane: the segment of pixel part * 64 + lane in the unit's spill slot
     bool hot_lds;        // hot launch: the part's records lie RAW in the hot stage already (not in the slot)
     int dpx, npixu;      // main launch, a unit in the spill slot: output pixel o = unit pixel o + dpx; w.segs holds every pixel's END
+    int sub;             // split path, hot launch: > 0 = the unit was swept in `sub` time slices; this wave, the last to finish, emits it
 };
 
 // inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts), no LDS crossbar
@@ -370,18 +389,20 @@ __device__ inline bool defer_unit(const BinView &bv, int uid, int nparts, uint32
     return false;
 }
 
-// main launch: unit `uid` goes to the hot list as ONE item, untouched (Split::in_hot)
-__device__ inline bool defer_whole(const BinView &bv, int uid) {
+// main launch: unit `uid` goes to the hot list untouched (Split::in_hot): `count` items, codes code0 .. code0 + count - 1
+__device__ inline bool defer_items(const BinView &bv, int uid, uint32_t code0, uint32_t count) {
     const uint32_t capl = hot_sublist_cap(bv.hot_cap);
     uint32_t l = ((uint32_t)uid * 0x9E3779B1u) >> 26;
     for (int tries = 0; tries < kHotLists; ++tries, l = (l + 1) % kHotLists) {   // (wave-uniform)
         uint32_t at = 0;
-        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[l * 16], 1u);
+        if (threadIdx.x == 0) at = atomicAdd(&bv.hot[l * 16], count);
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        if (at < capl) {
-            if (threadIdx.x == 0) bv.hot[kHotHdrWords + (size_t)l * capl + at] = (uint32_t)uid * (uint32_t)kHotCodes + (uint32_t)kHotWhole;
+        uint32_t *items = bv.hot + kHotHdrWords + (size_t)l * capl;
+        if (at + count <= capl) {
+            if (threadIdx.x < count) items[at + threadIdx.x] = (uint32_t)uid * (uint32_t)kHotCodes + code0 + threadIdx.x;
             return true;
         }
+        if (threadIdx.x < count && at + threadIdx.x < capl) items[at + threadIdx.x] = 0xffffffffu;   // the sublist is full
     }
     return false;
 }
@@ -390,12 +411,13 @@ __device__ inline bool defer_whole(const BinView &bv, int uid) {
 // span = 2 gives float32 builders the same 12 KB per wave as float64 ones.
 __device__ inline ChunkGeom unit_geom(int H, int W, int nchunk, const UnitCfg &uc, int &chunk, int &nch, int u) {
     ChunkGeom g;
-    const int nunit = units_per_row(nchunk, uc.span, uc.merge);
-    const int ur = u % nunit;
+    const int nunit = uc.nunit;   // = units_per_row(nchunk, uc.span, uc.merge), see UnitCfg
+    const uint32_t urow = fastdiv((uint32_t)u, uc.nunit_m, uc.nunit_sh);   // u / nunit = window * H + row
+    const int ur = u - (int)urow * nunit;
     chunk = ur * uc.span;
     nch = (uc.merge && ur == nunit - 1) ? nchunk - chunk : min(uc.span, nchunk - chunk);
-    g.row = (u / nunit) % H;
-    g.b = (u / nunit) / H;
+    g.b = (int)fastdiv(urow, uc.h_m, uc.h_sh);
+    g.row = (int)urow - g.b * H;
     g.c0 = chunk * kChunkPx;
     g.npix = min(nch * kChunkPx, W - g.c0);
     g.cs = 0; g.ce = 0;
@@ -508,10 +530,15 @@ __device__ inline UnitVisit<F> unit_visit(F f, int words_per_px) { return UnitVi
 // cannot take: its units go the ordered ways) -- and the hot wave, with a stage of kHotSplitStage records and deeper batches,
 // sweeps, orders the kept records and emits it.
 struct NoSplit { static constexpr bool enabled = false; static constexpr bool in_hot = false; };
-template <bool IN_HOT, typename Begin, typename F, typename Done>
-struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; Begin begin; F f; Done done; int words_per_px; uint32_t st_lane; };
+struct NoMerge { __device__ inline void operator()(const uint32_t *, uint32_t *) const {} };
+template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge>
+struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; Begin begin; F f; Done done; int words_per_px; uint32_t st_lane;
+                   Merge merge;   // merge(mine, unit): a time slice's words of one pixel into the unit's words in global memory (atomics; sub-waves)
+};
 template <bool IN_HOT = false, typename Begin, typename F, typename Done>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, NoMerge()}; }
+template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge>
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, m}; }
 #ifndef EVREP_SPLIT_BATCHES
 #define EVREP_SPLIT_BATCHES 8
 #endif
@@ -550,7 +577,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     UnitRecs u;
     u.sorted = bv.spill; u.cs = 0; u.ce = 0; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = lane; u.deferred = false; u.part = -1; u.hot_lds = false;
+    u.nseg = -1; u.pos = lane; u.deferred = false; u.part = -1; u.hot_lds = false; u.sub = 0;
     if (khi <= klo) return u;
     // the window's extent and the run tables are loaded together (the table address does not depend on the extent;
     // runs beyond the window's block count are masked afterwards): two dependent global latencies, not three
@@ -686,7 +713,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #endif
     constexpr int kSpillBatch = HOT ? EVREP_HOT_SPILL_BATCH : EVREP_MAIN_SPILL_BATCH;   // (a hot wave only sweeps on the split path)
     const uint32_t cs = (uint32_t)beg + (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a), 63);
-    if (HOT && !(Split::enabled && Split::in_hot && part == kHotWhole)) {
+    const bool hot_sub = HOT && Split::enabled && Split::in_hot && part >= kHotSub0 && part < kHotSub0 + kHotSubMax;   // wave-uniform
+    if (HOT && !(Split::enabled && Split::in_hot && (part == kHotWhole || hot_sub))) {
       if constexpr (HOT) {
         // The unit's MAIN wave has laid its records out in the unit's slot, pixel-sorted (r04c; until then every hot wave
         // sorted its part out of the unit's records itself: two sweeps over ALL of them per piece, ~5 000 of a piece's ~7 000
@@ -716,7 +744,21 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         // (warm units too -- those that would fit this wave's hot stage: measured, r05b, ordering them here makes the main launch
         //  of a clustered batch 30-40 % longer, which the hot launch they spare does not give back)
         if (!(stw & kStEscaped) && nrec <= 65535u && dpx == 0) {
-            if (!defer_whole(bv, uid) && lane == 0) atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);
+            // A unit of >= kHotSubMin records is taken in TIME slices (r05b): S hot waves sweep ~1 000 consecutive records each into
+            // their own words, merge them into the unit's words in its spill slot (global atomics: sums, flags, maxima), leave their
+            // kept records there, and the last one to finish orders the kept records and emits the unit.  One wave's instruction
+            // stream bounds a sweep at ~250 instructions per 64 records: a 20 000-record unit of a 1 Mpx circle window took one
+            // hot wave 100 us, the whole launch's tail.  This wave clears the slot's header and words (visible at the launch boundary).
+            bool ok;
+            if (nrec >= kHotSubMin) {
+                uint4 *z = reinterpret_cast<uint4 *>(bv.spill + cs);
+                const uint32_t nz = (kHotSubHdrBytes + 32u * (uint32_t)npixu) / 16u;
+                for (uint32_t i = (uint32_t)lane; i < nz; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
+                ok = defer_items(bv, uid, (uint32_t)kHotSub0, hot_sub_count(nrec));
+            } else {
+                ok = defer_items(bv, uid, (uint32_t)kHotWhole, 1u);
+            }
+            if (!ok && lane == 0) atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);
             u.deferred = true;
             u.ce = nrec;
             return u;
@@ -732,7 +774,14 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     // unit whose runs hold a handful of records each (a window of 250 000 events: 31 runs of 4) would load a mostly empty
     // batch per run: there a batch is 64 consecutive records of the UNIT and every lane finds its record's run itself (the
     // readlane chain / LDS search of r03).
-    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+    // a hot launch's sub-wave (hot_sub) sweeps records [jlo, jhi) of the unit only: its time slice
+    uint32_t jlo = 0, jhi = nrec;
+    if (hot_sub) {
+        const uint32_t S = hot_sub_count(nrec), qs = hot_sub_quota(nrec, S);
+        jlo = min(nrec, (uint32_t)(part - kHotSub0) * qs);
+        jhi = min(nrec, jlo + qs);
+    }
+    const bool by_run = !hot_sub && nrec >= 12u * (uint32_t)nb;   // wave-uniform
     const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;   // lane k: the unit's first record in run k
     uint32_t *runs2 = cnt + npixu;   // (behind the pixel counters: a main launch places a warm unit over the record stage)
     if (!by_run && nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
@@ -762,13 +811,13 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
     uint32_t ro_ = 0;
     uint32_t addr[kSpillBatch], bcnt[kSpillBatch];
     Rec8 q[kSpillBatch];
-    auto sweep_begin = [&]() { rk_ = 0; ro_ = 0; };
+    auto sweep_begin = [&]() { rk_ = 0; ro_ = by_run ? 0u : jlo; };
     auto skip_empty = [&]() {   // by run: the cursor moves to the next record there is
         uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
         while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
         return lk;
     };
-    auto sweep_done = [&]() -> bool { if (by_run) { skip_empty(); return rk_ >= nb; } return ro_ >= nrec; };
+    auto sweep_done = [&]() -> bool { if (by_run) { skip_empty(); return rk_ >= nb; } return ro_ >= jhi; };
     auto load_batch = [&]() -> bool {   // fills bcnt / q; false: the sweep is over (nothing was filled)
         bool any = false;
         if (by_run) {
@@ -792,11 +841,11 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
 #pragma unroll
             for (int sl = 0; sl < kSpillBatch; ++sl) {
                 const uint32_t j0 = ro_ + (uint32_t)(sl * kWave);
-                bcnt[sl] = j0 < nrec ? min(nrec - j0, (uint32_t)kWave) : 0u;
+                bcnt[sl] = j0 < jhi ? min(jhi - j0, (uint32_t)kWave) : 0u;
                 q[sl] = make_uint2(0u, 0u);
                 if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[src_of(j0 + (uint32_t)lane)];
             }
-            any = ro_ < nrec;
+            any = ro_ < jhi;
             ro_ += (uint32_t)(kSpillBatch * kWave);
         }
         return any;
@@ -837,6 +886,12 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             // the spill stream -- 16 bytes per record of the unit: the lower half takes the list, the upper half its ordered copy
             uint2 *list = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(w.tile) + wbytes);
             uint2 *glist = reinterpret_cast<uint2 *>(bv.spill + cs);
+            // a sub-wave's kept records all go to ITS region of the unit's slot (behind the header and the unit's words): the
+            // compacted kept records of records [jlo, jhi), from offset jlo
+            unsigned char *slot = reinterpret_cast<unsigned char *>(bv.spill + cs);
+            uint2 *sublists = reinterpret_cast<uint2 *>(slot + kHotSubHdrBytes + 32u * (uint32_t)npixu);
+            if (hot_sub) glist = sublists + jlo;
+            const uint32_t lcap_eff = hot_sub ? 0u : lcap;
             uint32_t nk = 0;
             sweep_begin();
             while (load_batch()) {
@@ -850,7 +905,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                     if (km) {
                         const uint32_t at = nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
                         if (keep) {
-                            if (at < lcap) list[at] = e; else glist[at] = e;
+                            if (at < lcap_eff) list[at] = e; else glist[at] = e;
                             atomicAdd(&cnt[e.y], 1u);
                         }
                         nk += (uint32_t)__popcll(km);
@@ -859,6 +914,38 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                 if (sweep_done()) break;
             }
             wave_phase();
+            if (hot_sub) {
+                // merge this slice's words and kept counts into the unit's (8 words per pixel in the slot: the builder's
+                // split.words_per_px <= 7, then the pixel's kept records), then take the unit's ticket
+                uint32_t *gw = reinterpret_cast<uint32_t *>(slot + kHotSubHdrBytes);
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(slot);
+                const uint32_t *lw = reinterpret_cast<const uint32_t *>(w.tile);
+                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) split.merge(lw + px * (uint32_t)split.words_per_px, gw + px * 8u);
+                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) { const uint32_t kc = cnt[px]; if (kc) atomicAdd(gw + px * 8u + 7u, kc); }
+                const uint32_t S = hot_sub_count(nrec);
+                uint32_t ticket = 0;
+                __threadfence();   // this wave's list and merges before its ticket
+                if (lane == 0) {
+                    hdr[1 + (part - kHotSub0)] = nk;
+                    __threadfence();
+                    ticket = atomicAdd(hdr, 1u);
+                }
+                ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+                if (ticket + 1u != S) { u.deferred = true; return u; }   // (a later slice's wave emits the unit)
+                __threadfence();   // the other slices' words, lists and counts are complete: read them past this CU's L1
+                uint32_t *lwm = reinterpret_cast<uint32_t *>(w.tile);
+                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) {
+                    for (uint32_t k = 0; k < (uint32_t)split.words_per_px; ++k)
+                        lwm[px * (uint32_t)split.words_per_px + k] = __hip_atomic_load(gw + px * 8u + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cnt[px] = __hip_atomic_load(gw + px * 8u + 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t tot = 0;
+                if (lane < (int)S) tot = __hip_atomic_load(hdr + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t incl = wave_incl_scan(tot);
+                nk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                wave_phase();
+                u.sub = (int)S;
+            }
             if (split.done()) {   // wave-uniform
                 u.part = -5;
                 u.cs = cs; u.ce = cs + nrec;
@@ -1056,7 +1143,7 @@ __device__ inline UnitRecs unit_front(const BinView &bv, const int64_t *__restri
     UnitRecs u;
     u.sorted = bv.sorted; u.cs = g.cs; u.ce = g.ce; u.nstaged = kEvStage;
     u.r0 = make_int4(INT32_MIN, 0, 0, 0);
-    u.nseg = -1; u.pos = (int)threadIdx.x; u.deferred = false; u.part = -1; u.hot_lds = false;
+    u.nseg = -1; u.pos = (int)threadIdx.x; u.deferred = false; u.part = -1; u.hot_lds = false; u.sub = 0;
     if ((int)threadIdx.x < (int)(g.ce - g.cs)) u.r0 = bv.sorted[g.cs + threadIdx.x];
     stage_classic(u, w);
     return u;
@@ -1874,14 +1961,26 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             return h6 || h1;
         };
         auto sdone = [&]() -> bool { return !__any(esc); };
-        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split<kSplitHot>(sbegin, sf, sdone, kErgoSplitWords));
+        // a time slice's words of one pixel into the unit's (sub-waves of a sliced hot unit, unit_records): the 16-bit counts add, the
+        // flags or, the maxima max; word 3 holds both flags (low half) and a count (high half)
+        auto smerge = [](const uint32_t *m, uint32_t *gw) {
+            if (m[0]) atomicAdd(gw + 0, m[0]);
+            if (m[1]) atomicAdd(gw + 1, m[1]);
+            if (m[2]) atomicAdd(gw + 2, m[2]);
+            if (m[3] & 0xffffu) atomicOr(gw + 3, m[3] & 0xffffu);
+            if (m[3] >> 16) atomicAdd(gw + 3, m[3] & 0xffff0000u);
+            if (m[4]) atomicMax(gw + 4, m[4]);
+            if (m[5]) atomicMax(gw + 5, m[5]);
+            if (m[6]) atomicMax(gw + 6, m[6]);
+        };
+        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split_merge<kSplitHot>(sbegin, sf, sdone, kErgoSplitWords, smerge));
     } else if constexpr (kSplitDefer) {
         auto never = []() -> bool { return false; };
         auto nof = [](uint32_t, const Rec8 &, uint2 &) -> bool { return false; };
         // lane k: the status word of the window's block k (meta_prefetch: q2.x), merged by unit_records only when a unit is hot
         u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
                                                   unit_split<true>(never, nof, never, kErgoSplitWords,
-                                                                   (uint32_t)mraw.q2.x | (uc.span > 1 ? kStEscaped : 0u)));
+                                                                   (uint32_t)mraw.q2.x | ((uc.span > 1 && !(uc.xflags & 1)) ? kStEscaped : 0u)));
         // (two-chunk units -- sparse windows, 640x480 / 1280x720 at 50 000 - 200 000 events -- keep the ordered ways: measured, r05b,
         //  their hot units are few and huge -- 4 000 to 20 000 records, one wave's instruction stream each, 30 to 100 us of sweep --
         //  and the hot launch's tail costs 5-8 % more than it saves; at the reference's Gen1 shape the hand-over takes the
@@ -1905,11 +2004,34 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             const uint32_t room = (uint32_t)(reinterpret_cast<const unsigned char *>(w.segs) - reinterpret_cast<const unsigned char *>(w.tile));
             const uint32_t lcap = split_list_cap(room, u.pen);
             const uint32_t nrec = u.ce - u.cs;
-            const bool big = nk > lcap;   // wave-uniform: a hot unit -- its kept records are ordered in its slot of the spill stream
+            const bool sliced = u.sub > 0;   // wave-uniform: the unit was swept in time slices; their kept lists lie in its slot, one region each
+            const bool big = nk > lcap || sliced;   // wave-uniform: a hot unit -- its kept records are ordered in global memory
             const uint2 *list = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(w.tile) + u.pen);
             double *placed = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(w.tile) + u.pen);
             const uint2 *glist = reinterpret_cast<const uint2 *>(bv.spill + u.cs);
-            double *gplaced = reinterpret_cast<double *>(bv.spill + u.cs) + nrec;
+            double *gplaced = sliced ? bv.placed_pool + u.cs : reinterpret_cast<double *>(bv.spill + u.cs) + nrec;
+            // sliced: kept record j of the unit = record j - spre of the slice whose exclusive kept prefix spre covers j; lane s
+            // holds slice s's prefix and its region's first slot
+            uint32_t spre = 0xffffffffu, soff = 0u;
+            const unsigned long long *sublists = reinterpret_cast<const unsigned long long *>(
+                reinterpret_cast<const unsigned char *>(bv.spill + u.cs) + kHotSubHdrBytes + 32u * (uint32_t)u.npixu);
+            if (sliced) {
+                const uint32_t *hdr = reinterpret_cast<const uint32_t *>(bv.spill + u.cs);
+                uint32_t tot = 0;
+                if (lane < u.sub) tot = __hip_atomic_load(hdr + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t incl = wave_incl_scan(tot);
+                if (lane < u.sub) { spre = incl - tot; soff = (uint32_t)lane * hot_sub_quota(nrec, (uint32_t)u.sub); }
+            }
+            auto sub_at = [&](uint32_t j) -> uint2 {
+                uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)soff, 0) + j;
+                for (int k = 1; k < u.sub; ++k) {
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)spre, k);
+                    const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)soff, k);
+                    if (j >= pk) at = ok + (j - pk);
+                }
+                const unsigned long long v = __hip_atomic_load(sublists + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+            };
             const int nbits = 32 - __builtin_clz((unsigned)u.npixu - 1u);
             auto place = [&](const uint2 &e, bool valid, double *dstp) {
                 const uint32_t px = valid ? e.y : 0u;
@@ -1947,7 +2069,8 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
                         const uint32_t j = j0 + (uint32_t)(i * kWave + lane);
                         ek[i] = make_uint2(0u, 0u);
                         if (j < nk) {
-                            if (j < lcap) ek[i] = list[j];
+                            if (sliced) ek[i] = sub_at(j);
+                            else if (j < lcap) ek[i] = list[j];
                             else { const double d = gload_f64(reinterpret_cast<const double *>(glist + j)); ek[i] = make_uint2((uint32_t)__double2loint(d), (uint32_t)__double2hiint(d)); }
                         }
                     }
@@ -2505,9 +2628,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         const int span = uc.span;
         WaveLds<float, HOT> w(smem, C, (span + 1) * kChunkPx, uc.stage);
         w.arm(uc.hold);
-        const int nunit = (nchunk + span - 1) / span;
+        const int nunit = uc.nunit;   // = (nchunk + span - 1) / span: TORE's units never merge (unit_cfg, extra_chunks)
         const int u = uid;
-        const int b = (u / nunit) / H, orow = (u / nunit) % H, oc0 = (u % nunit) * span * kChunkPx;
+        const uint32_t urow = fastdiv((uint32_t)u, uc.nunit_m, uc.nunit_sh);
+        const int b = (int)fastdiv(urow, uc.h_m, uc.h_sh), orow = (int)urow - b * H, oc0 = (u - (int)urow * nunit) * span * kChunkPx;
         const int64_t beg = off[b];
         const int64_t n_win = off[b + 1] - beg;
         // an empty window has no bounding box: mode 0 has nothing to write (the dispatcher raises on it), the
@@ -2531,7 +2655,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         UnitRecs ur;
         ur.sorted = bv.sorted; ur.cs = 0; ur.ce = 0; ur.nstaged = kEvStage;
         ur.r0 = make_int4(INT32_MIN, 0, 0, 0);
-        ur.nseg = -1; ur.pos = (int)threadIdx.x; ur.deferred = false; ur.part = -1; ur.hot_lds = false;
+        ur.nseg = -1; ur.pos = (int)threadIdx.x; ur.deferred = false; ur.part = -1; ur.hot_lds = false; ur.sub = 0;
         if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
             const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
             if (bv.fused) {

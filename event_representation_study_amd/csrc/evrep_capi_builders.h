@@ -24,6 +24,7 @@ static inline BinView bin_view(const evrep_plan *plan, const int32_t *events, vo
     bv.hot = WS(uint32_t, off_scratch);
     bv.hot_cap = hot_items_total(plan->total_events);
     bv.stats_rw = WS(BlockStats, off_stats);
+    bv.placed_pool = reinterpret_cast<double *>(static_cast<char *>(workspace) + plan->off_sorted1 + up256((size_t)plan->total_events * 8));   // the key-sorted pass moves 8-byte records: the upper half of sorted1 is idle
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
 #ifdef EVREP_TIMING
     // 8 slots per builder wave: behind the 8-byte records of the key-sorted pass (the upper half of sorted1 is idle; sorted2 is
@@ -45,6 +46,12 @@ static inline int ensure_column_sorted(const evrep_plan *plan, const int32_t *ev
 // sparse windows (<= 30 records per chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel
 // fast path), else 1.  stage = records its LDS stage holds: 64 for one-chunk units, 128 for wider ones (they hold ~65
 // records on the sparse windows they are chosen for).
+// the division-free unit decode of the builder waves (UnitCfg::nunit ...): after every change of span / merge
+static inline void unit_cfg_geometry(UnitCfg &uc, const evrep_plan *plan) {
+    uc.nunit = units_per_row(plan->nchunk, uc.span, uc.merge);
+    fastdiv_make((uint32_t)uc.nunit, uc.nunit_m, uc.nunit_sh);
+    fastdiv_make((uint32_t)plan->H, uc.h_m, uc.h_sh);
+}
 static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int extra_chunks = 0, bool wide_part = false, bool deep_stage = true) {
     UnitCfg uc;
     const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
@@ -53,6 +60,7 @@ static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int e
     // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
     // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
     uc.stage = (deep_stage && plan->reserved != 2 && per_chunk > kDeepStageMinPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
+    if ((plan->flags & 512) && plan->reserved == 2 && uc.span == 1) uc.stage = 64;   // experiment (EVREP_X_STAGE64): units of > 64 records leave the two-batch path
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     // a short tail chunk (<= 64 of 128 pixels: Gen1's 304-pixel rows end in 48) rides with the row's last unit (UnitCfg::merge);
@@ -61,6 +69,8 @@ static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int e
     // (an experiment switch, off by default: measured at the Gen1 shape the 176-pixel unit loses the sparse emit -- ~95 records
     //  in ~80 pixels -- and its three-part tile sequence costs more than the 48-pixel tail unit it saves: ERGO-12 68 -> 82 us)
     uc.merge = (extra_chunks == 0 && tail != 0 && tail <= kChunkPx / 2 && plan->nchunk >= 2 && (plan->flags & EVREP_PLAN_X_TAIL_MERGE)) ? 1 : 0;
+    uc.xflags = (plan->flags & 1024) ? 1 : 0;   // EVREP_X_HANDOVER2
+    unit_cfg_geometry(uc, plan);
     return uc;
 }
 #define SPAN_GRID(span) dim3(units_per_row(plan->nchunk, (span), uc.merge), plan->H, plan->B)

@@ -27,6 +27,16 @@ constexpr int kHotParts = 8;                  // parts per unit at most (TORE's 
 constexpr int kHotCodes = 64;                 // item = unit id * kHotCodes + piece code
 constexpr int kHotLists = 64;
 constexpr int kHotWhole = kHotCodes - 1;      // piece code: the WHOLE unit, taken by the hot wave's split sweep (unit_records, Split::in_hot)
+constexpr int kHotSub0 = 40, kHotSubMax = 16; // piece codes kHotSub0 + s: the s-th TIME slice of a hot unit of >= kHotSubMin records (unit_records, sub-waves)
+#ifdef EVREP_TIMING
+constexpr uint32_t kHotSubMin = 0x7fffffffu, kHotSubRecs = 1024u;   // (the experiment build keeps its phase marks where sliced units order their kept records)
+#else
+constexpr uint32_t kHotSubMin = 4096u, kHotSubRecs = 1024u;   // (measured, r05b: slicing units of 2 000 - 4 000 records costs the Gen1 circle stream 7 %: zeroing, merging and the ticket outweigh the shorter sweep)
+#endif
+// slices of a hot unit of nrec >= kHotSubMin records, and the records of a slice (a multiple of 64; every slice is non-empty)
+__host__ __device__ inline uint32_t hot_sub_count(uint32_t nrec) { const uint32_t s = nrec / kHotSubRecs; return s > (uint32_t)kHotSubMax ? (uint32_t)kHotSubMax : s; }
+__host__ __device__ inline uint32_t hot_sub_quota(uint32_t nrec, uint32_t S) { return (((nrec + S - 1u) / S) + 63u) & ~63u; }
+constexpr uint32_t kHotSubHdrBytes = 128u;    // a sliced unit's slot: ticket, kept counts of the slices; then 8 words per pixel, then the slices' kept lists
 constexpr int kHotSplitStage = 576;           // records of the LDS stage of a hot launch whose waves take whole units by the split path
 constexpr uint32_t kStEscaped = 1u << 16;     // BlockStats::status, internal: the block holds a polarity outside {-1, 0, 1} (escaped in its 8-byte record)
 constexpr int kHotHdrWords = 2 * kHotLists * 16;   // [l * 16]: sublist l's item count, [(kHotLists + l) * 16]: its exit ticket
