@@ -324,6 +324,7 @@ def sweep_leg(device):
     rows = bench_sweep.sweep(("gen1", "c2", "c3"), iters=10, device=str(device))
     three = ("optimized_f64", "event_stack_f32", "time_surface_f64")
     rows += bench_sweep.sweep(("gen1@circle", "gen1@edges", "c2@circle", "c2@edges"), iters=10, builders=three, device=str(device))
+    rows += bench_sweep.sweep(("c3@circle", "c3@edges"), iters=10, builders=three + ("tore_full_frame_f32",), device=str(device))   # config 3 names TORE
     rows += bench_sweep.sweep(("c2-dense", "c3-1M"), iters=10, builders=three + ("tore_full_frame_f32", "voxel5_f64"), device=str(device))
     keep = ("config", "distribution", "builder", "binning_pass", "bin_ms", "build_ms", "build_GBps", "build_frac_of_8TBps",
             "events_per_s_bin_plus_build")

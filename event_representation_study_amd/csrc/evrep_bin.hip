@@ -975,6 +975,9 @@ static __global__ __launch_bounds__(kCsWaves * kWave) __attribute__((amdgpu_wave
 // windows; a group of g records costs g reads per member, so a hot pixel makes its own block slower, never
 // wrong).  Nothing depends on another workgroup.
 // =====================================================================================================
+#ifndef KS_DIRECT_WRITE
+#define KS_DIRECT_WRITE 0
+#endif
 #ifndef KS_DEBUG
 #define KS_DEBUG 0  // timing experiments only (tools/experiments): 1 = no group repair, 2 = no stage / write-out, 4 = no statistics, 8 = no table copy
 #endif
@@ -1225,6 +1228,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB == 1024
     }
     if (nhot) __syncthreads();   // the hot-group counters live in the stage: every wave has read its own before the write-out
     Rec8 *dst = reinterpret_cast<Rec8 *>(sorted1) + beg + lo;   // the block's own slot, 8 bytes per record
+#if KS_DIRECT_WRITE
+    // experiment: the records go from the lanes' registers straight to their places in the block's slot (scattered 8-byte stores
+    // that meet in the XCD's L2 and leave it as full lines) -- no stage, no barrier, no second pass over the block
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+        if (ko[i] != 0xffffffffu && !(KS_DEBUG & 2)) {
+            int col = e[i].x;
+            if ((uint32_t)col >= (uint32_t)W) { const uint32_t key = (uint32_t)(e[i].x + e[i].y * W); col = (int)(key % (uint32_t)W); }
+            dst[ko[i]] = rec8_pack(col, lo32 + w0 + i * kWave + lane, e[i].z, e[i].w);
+        }
+    }
+    return;
+#endif
     for (uint32_t pb = 0; pb < total && !(KS_DEBUG & 2); pb += (uint32_t)cap) {
         if (pb) __syncthreads();  // the previous round has left the stage
 #pragma unroll

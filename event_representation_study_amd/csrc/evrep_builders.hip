@@ -65,7 +65,10 @@ struct UnitCfg {
     // units per row and two multiply-shift reciprocals over (fastdiv_make; exact for ids < 2^31, which evrep_plan_init ensures)
     int nunit;
     uint32_t nunit_m, nunit_sh, h_m, h_sh;
-    int xflags;  // experiment switches (EVREP_PLAN_X_*): bit 0 = two-chunk float32 ERGO-12 units also go to the hot launch whole
+    int xflags;  // bit 1: builders with a hot-launch split sweep (float32 ERGO-12) hand units beyond the record stage over whole -- set by
+                 // the host for one-chunk units of windows whose AVERAGE unit fits the stage (hot units are the exception: on dense
+                 // windows every unit would go, and the hot launch is the slower place: 8 x 500 000 events 82 -> 134 us, measured);
+                 // EVREP_PLAN_X_HANDOVER2 (experiment) also sets it for two-chunk units
     int merge;   // 1: the row's last unit also takes the short tail chunk of a sensor whose width is not a multiple of 128 (r04:
                  // Gen1's 304-pixel rows are 128 + 128 + 48 -- a third of the units were 48-pixel tails with a full unit's
                  // fixed cost; now a row is two units, 128 and 176 pixels)
@@ -530,15 +533,23 @@ __device__ inline UnitVisit<F> unit_visit(F f, int words_per_px) { return UnitVi
 // cannot take: its units go the ordered ways) -- and the hot wave, with a stage of kHotSplitStage records and deeper batches,
 // sweeps, orders the kept records and emits it.
 struct NoSplit { static constexpr bool enabled = false; static constexpr bool in_hot = false; };
+// words per pixel of a sliced hot unit in its spill slot: the builder's words, the pixel's kept-record count last; even, so that
+// 64-bit words stay 8-byte aligned
+__host__ __device__ inline uint32_t split_gwpp(int words_per_px) { return ((uint32_t)words_per_px + 2u) & ~1u; }
 struct NoMerge { __device__ inline void operator()(const uint32_t *, uint32_t *) const {} };
-template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge>
+struct NoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
+template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge, typename Pre = NoPre>
 struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; Begin begin; F f; Done done; int words_per_px; uint32_t st_lane;
                    Merge merge;   // merge(mine, unit): a time slice's words of one pixel into the unit's words in global memory (atomics; sub-waves)
+                   Pre pre;       // pre(record) -> 8 bytes the builder wants of the record from global memory (its caller-side time): gathered for every
+                                  // batch of a round before the first f() -- all in flight together -- and handed to f as `aux`
 };
 template <bool IN_HOT = false, typename Begin, typename F, typename Done>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, NoMerge()}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, NoMerge(), NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, m}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, m, NoPre()}; }
+template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge, typename Pre>
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre> unit_split_full(Begin b, F f, Done d, int words_per_px, Merge m, Pre pr) { return UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre>{b, f, d, words_per_px, 0u, m, pr}; }
 #ifndef EVREP_SPLIT_BATCHES
 #define EVREP_SPLIT_BATCHES 8
 #endif
@@ -752,7 +763,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             bool ok;
             if (nrec >= kHotSubMin) {
                 uint4 *z = reinterpret_cast<uint4 *>(bv.spill + cs);
-                const uint32_t nz = (kHotSubHdrBytes + 32u * (uint32_t)npixu) / 16u;
+                const uint32_t nz = (kHotSubHdrBytes + 4u * split_gwpp(split.words_per_px) * (uint32_t)npixu + 15u) / 16u;
                 for (uint32_t i = (uint32_t)lane; i < nz; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
                 ok = defer_items(bv, uid, (uint32_t)kHotSub0, hot_sub_count(nrec));
             } else {
@@ -889,18 +900,25 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             // a sub-wave's kept records all go to ITS region of the unit's slot (behind the header and the unit's words): the
             // compacted kept records of records [jlo, jhi), from offset jlo
             unsigned char *slot = reinterpret_cast<unsigned char *>(bv.spill + cs);
-            uint2 *sublists = reinterpret_cast<uint2 *>(slot + kHotSubHdrBytes + 32u * (uint32_t)npixu);
+            const uint32_t gwpp = split_gwpp(split.words_per_px);   // a sliced unit's words per pixel in its slot: the builder's, [pad,] the pixel's kept records
+            uint2 *sublists = reinterpret_cast<uint2 *>(slot + ((kHotSubHdrBytes + 4u * gwpp * (uint32_t)npixu + 15u) & ~15u));
             if (hot_sub) glist = sublists + jlo;
             const uint32_t lcap_eff = hot_sub ? 0u : lcap;
             uint32_t nk = 0;
             sweep_begin();
             while (load_batch()) {
+                uint2 aux[kSpillBatch];
+#pragma unroll
+                for (int sl = 0; sl < kSpillBatch; ++sl) {
+                    aux[sl] = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < bcnt[sl]) aux[sl] = split.pre(q[sl]);
+                }
 #pragma unroll
                 for (int sl = 0; sl < kSpillBatch; ++sl) {
                     if (bcnt[sl] == 0u) break;   // uniform
                     bool keep = false;
                     uint2 e = make_uint2(0u, 0u);
-                    if ((uint32_t)lane < bcnt[sl]) keep = split.f(px_of(q[sl]), q[sl], e);
+                    if ((uint32_t)lane < bcnt[sl]) keep = split.f(px_of(q[sl]), q[sl], e, aux[sl]);
                     const uint64_t km = __ballot(keep);
                     if (km) {
                         const uint32_t at = nk + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
@@ -920,8 +938,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                 uint32_t *gw = reinterpret_cast<uint32_t *>(slot + kHotSubHdrBytes);
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(slot);
                 const uint32_t *lw = reinterpret_cast<const uint32_t *>(w.tile);
-                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) split.merge(lw + px * (uint32_t)split.words_per_px, gw + px * 8u);
-                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) { const uint32_t kc = cnt[px]; if (kc) atomicAdd(gw + px * 8u + 7u, kc); }
+                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) split.merge(lw + px * (uint32_t)split.words_per_px, gw + px * gwpp);
+                for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) { const uint32_t kc = cnt[px]; if (kc) atomicAdd(gw + px * gwpp + (gwpp - 1u), kc); }
                 const uint32_t S = hot_sub_count(nrec);
                 uint32_t ticket = 0;
                 __threadfence();   // this wave's list and merges before its ticket
@@ -936,8 +954,8 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
                 uint32_t *lwm = reinterpret_cast<uint32_t *>(w.tile);
                 for (uint32_t px = (uint32_t)lane; px < (uint32_t)npixu; px += kWave) {
                     for (uint32_t k = 0; k < (uint32_t)split.words_per_px; ++k)
-                        lwm[px * (uint32_t)split.words_per_px + k] = __hip_atomic_load(gw + px * 8u + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cnt[px] = __hip_atomic_load(gw + px * 8u + 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lwm[px * (uint32_t)split.words_per_px + k] = __hip_atomic_load(gw + px * gwpp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cnt[px] = __hip_atomic_load(gw + px * gwpp + (gwpp - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 uint32_t tot = 0;
                 if (lane < (int)S) tot = __hip_atomic_load(hdr + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1935,7 +1953,7 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             cmask = cm;
             return true;
         };
-        auto sf = [&](uint32_t px, const Rec8 &q, uint2 &e) -> bool {
+        auto sf = [&](uint32_t px, const Rec8 &q, uint2 &e, const uint2 &) -> bool {
             const int rank = (int)(q.y >> 11);
             const uint32_t p2 = (q.y >> 9) & 3u;
             if (p2 == 3u) { esc = true; return false; }
@@ -1976,11 +1994,11 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
         u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), unit_split_merge<kSplitHot>(sbegin, sf, sdone, kErgoSplitWords, smerge));
     } else if constexpr (kSplitDefer) {
         auto never = []() -> bool { return false; };
-        auto nof = [](uint32_t, const Rec8 &, uint2 &) -> bool { return false; };
+        auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
         // lane k: the status word of the window's block k (meta_prefetch: q2.x), merged by unit_records only when a unit is hot
         u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
                                                   unit_split<true>(never, nof, never, kErgoSplitWords,
-                                                                   (uint32_t)mraw.q2.x | ((uc.span > 1 && !(uc.xflags & 1)) ? kStEscaped : 0u)));
+                                                                   (uint32_t)mraw.q2.x | ((uc.xflags & 2) ? 0u : kStEscaped)));
         // (two-chunk units -- sparse windows, 640x480 / 1280x720 at 50 000 - 200 000 events -- keep the ordered ways: measured, r05b,
         //  their hot units are few and huge -- 4 000 to 20 000 records, one wave's instruction stream each, 30 to 100 us of sweep --
         //  and the hot launch's tail costs 5-8 % more than it saves; at the reference's Gen1 shape the hand-over takes the
@@ -2014,7 +2032,7 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             // holds slice s's prefix and its region's first slot
             uint32_t spre = 0xffffffffu, soff = 0u;
             const unsigned long long *sublists = reinterpret_cast<const unsigned long long *>(
-                reinterpret_cast<const unsigned char *>(bv.spill + u.cs) + kHotSubHdrBytes + 32u * (uint32_t)u.npixu);
+                reinterpret_cast<const unsigned char *>(bv.spill + u.cs) + ((kHotSubHdrBytes + 4u * split_gwpp(kErgoSplitWords) * (uint32_t)u.npixu + 15u) & ~15u));
             if (sliced) {
                 const uint32_t *hdr = reinterpret_cast<const uint32_t *>(bv.spill + u.cs);
                 uint32_t tot = 0;
