@@ -2888,7 +2888,63 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
         WaveLds<float, HOT> w(smem, C, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
         ChunkGeom g;
-        const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
+        // Every statistic here is order-free (counts, maxima and minima of the caller's per-event time, per polarity class), so
+        // a unit beyond the record stage needs no order at all (r05b, unit_records' Split, IN_HOT): the main wave hands it to the
+        // hot launch whole, where ONE sweep keeps fourteen words per pixel by LDS atomics --
+        //   0: #(p > 0) | #(p < 0) << 16     1: #(p == 0)     then per class (p > 0, p < 0, p == 0) two 64-bit words:
+        //   max key(t_n), max ~key(t_n)  (key = the order-preserving integer image of a float64; ~key turns the minimum into a maximum,
+        //   so that zero-filled words are the identity of both)
+        // -- and the pixels are emitted from them (u.part == -5).  No record is kept.
+        constexpr int kPsWords = 14;
+        auto dkey = [](double v) -> unsigned long long {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        };
+        auto dval = [](unsigned long long k) -> double {
+            const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+            return __longlong_as_double((long long)b);
+        };
+        int chunk0_;
+        const int b0 = unit_geom(H, W, nchunk, uc, chunk0_, uid).b;
+        const double *tw0 = tnorm + off[b0];
+        const int4 *evw0 = bv.ev + off[b0];
+        UnitRecs u;
+        if constexpr (HOT) {
+            uint32_t *words = reinterpret_cast<uint32_t *>(w.tile);
+            auto yes = []() -> bool { return true; };
+            auto ppre = [&](const Rec8 &q) -> uint2 {   // the record's time, gathered for every batch of a round before the first atomic
+                const double tn = tw0[q.y >> 11];
+                return make_uint2((uint32_t)__double2loint(tn), (uint32_t)__double2hiint(tn));
+            };
+            auto psf = [&](uint32_t px, const Rec8 &q, uint2 &, const uint2 &aux) -> bool {
+                const uint32_t p2 = (q.y >> 9) & 3u;
+                int p = (int)p2 - 1;
+                if (p2 == 3u) p = evw0[q.y >> 11].w;   // an escaped polarity value: only its sign counts
+                const int cls = p > 0 ? 0 : (p < 0 ? 1 : 2);
+                uint32_t *wd = words + px * (uint32_t)kPsWords;
+                if (cls == 2) atomicAdd(wd + 1, 1u); else atomicAdd(wd, cls == 0 ? 1u : 0x10000u);
+                const unsigned long long k = dkey(__hiloint2double((int)aux.y, (int)aux.x));
+                unsigned long long *w64 = reinterpret_cast<unsigned long long *>(wd + 2 + 4 * cls);
+                atomicMax(w64, k);
+                atomicMax(w64 + 1, ~k);
+                return false;
+            };
+            auto pmerge = [](const uint32_t *m, uint32_t *gw) {
+                if (m[0]) atomicAdd(gw, m[0]);
+                if (m[1]) atomicAdd(gw + 1, m[1]);
+                const unsigned long long *m64 = reinterpret_cast<const unsigned long long *>(m + 2);
+                unsigned long long *g64 = reinterpret_cast<unsigned long long *>(gw + 2);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (m64[k]) atomicMax(g64 + k, m64[k]);
+            };
+            u = unit_front<float, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
+                                                       unit_split_full<true>(yes, psf, yes, kPsWords, pmerge, ppre));
+        } else {
+            auto never = []() -> bool { return false; };
+            auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
+            u = unit_front<float, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
+                                                       unit_split<true>(never, nof, never, kPsWords, (uc.xflags & 2) && uc.span == 1 ? 0u : kStEscaped));
+        }
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;
         const int lane = threadIdx.x;
@@ -2906,6 +2962,53 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
             wave_phase();
         }
         const float *bg = any_bg ? w.bg : nullptr;
+        // a pixel's statistics -> its C values
+        auto channels = [&](int n_any, int n_pos, int n_neg, double mx_any, double mx_pos, double mx_neg, double mn_any, double mn_pos,
+                            double mn_neg, float(&vals)[CM]) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                float v = 0.0f;
+                if (c < C) {
+                    const int k = P.pol[c], st = P.stat[c];
+                    const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
+                    const double mx = k == EVREP_PS_POS ? mx_pos : (k == EVREP_PS_NEG ? mx_neg : mx_any);
+                    const double mn = k == EVREP_PS_POS ? mn_pos : (k == EVREP_PS_NEG ? mn_neg : mn_any);
+                    if (st == EVREP_PS_COUNT) v = (float)n;
+                    else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
+                    else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
+                    else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
+                    else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
+                    else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+                }
+                vals[c] = v;
+            }
+        };
+        if constexpr (HOT) {
+            if (u.part == -5) {   // wave-uniform: the unit was swept by the split; every pixel's statistics wait in its words
+                const uint32_t *words = reinterpret_cast<const uint32_t *>(w.tile);
+                const bool vec = (C % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+                for (int pt = 0; pt * kWave < g.npix; ++pt) {
+                    const int np = min(kWave, g.npix - pt * kWave);
+                    const uint32_t *wd = words + (uint32_t)(pt * kWave + lane) * (uint32_t)kPsWords;
+                    float vals[CM];
+                    if (lane < np) {
+                        const int n_pos = (int)(wd[0] & 0xffffu), n_neg = (int)(wd[0] >> 16), n_zero = (int)wd[1];
+                        const unsigned long long *w64 = reinterpret_cast<const unsigned long long *>(wd + 2);
+                        const double mxp = n_pos ? dval(w64[0]) : 0.0, mnp = n_pos ? dval(~w64[1]) : 0.0;
+                        const double mxn = n_neg ? dval(w64[2]) : 0.0, mnn = n_neg ? dval(~w64[3]) : 0.0;
+                        const double mxz = n_zero ? dval(w64[4]) : 0.0, mnz = n_zero ? dval(~w64[5]) : 0.0;
+                        double mxa = 0.0, mna = 0.0;
+                        bool have = false;
+                        if (n_pos) { mxa = mxp; mna = mnp; have = true; }
+                        if (n_neg) { mxa = have ? fmax(mxa, mxn) : mxn; mna = have ? fmin(mna, mnn) : mnn; have = true; }
+                        if (n_zero) { mxa = have ? fmax(mxa, mxz) : mxz; mna = have ? fmin(mna, mnz) : mnz; }
+                        channels(n_pos + n_neg + n_zero, n_pos, n_neg, mxa, mxp, mxn, mna, mnp, mnn, vals);
+                        store_pixel<float, CM>(dst + ((size_t)pt * kWave + lane) * C, vals, C, vec);
+                    }
+                }
+                return;
+            }
+        }
         auto reduce = [&](uint32_t jb, uint32_t je, auto get, float(&vals)[CM]) {
             int n_any = 0, n_pos = 0, n_neg = 0;
             double mx_any = 0.0, mx_pos = 0.0, mx_neg = 0.0, mn_any = 0.0, mn_pos = 0.0, mn_neg = 0.0;
@@ -2925,23 +3028,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
                     ++n_neg;
                 }
             }
-#pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                float v = 0.0f;
-                if (c < C) {
-                    const int k = P.pol[c], st = P.stat[c];
-                    const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
-                    const double mx = k == EVREP_PS_POS ? mx_pos : (k == EVREP_PS_NEG ? mx_neg : mx_any);
-                    const double mn = k == EVREP_PS_POS ? mn_pos : (k == EVREP_PS_NEG ? mn_neg : mn_any);
-                    if (st == EVREP_PS_COUNT) v = (float)n;
-                    else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
-                    else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
-                    else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
-                    else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
-                    else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
-                }
-                vals[c] = v;
-            }
+            channels(n_any, n_pos, n_neg, mx_any, mx_pos, mx_neg, mn_any, mn_pos, mn_neg, vals);
         };
         // the record's normalised time is gathered from the caller's array by the DIGEST -- one load per record, all lanes at once,
         // staged in place of the fields the walks do not need -- instead of one dependent global load per step of the divergent

@@ -198,8 +198,11 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     do {                                                                                                              \
         k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
-        if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, kHotStage, uc.partpx), stream>>>(   \
-            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hot_cfg(uc), out);   \
+        /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \
+        UnitCfg hc = hot_cfg(uc);                                                                                     \
+        if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;                                                  \
+        if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
+            bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hc, out);   \
     } while (0)
     if (C <= 8) PS_LAUNCH(8); else PS_LAUNCH(16);
 #undef PS_LAUNCH

@@ -158,3 +158,44 @@ def test_ergo12_hot_units_with_escaped_polarities(oracle):
     assert_bit_equal(a, c, "ergo12 escaped polarities: key-sorted vs classic")
     for b, ev in enumerate(wins):
         assert_bit_equal(a[b], oracle.ergo12(ev, H, W), "ergo12 escaped polarities vs oracle w%d" % b)
+
+
+def test_hand_over_whole_units_and_time_slices_at_gen1(oracle):
+    """r05b: at the reference's own shape, sparse enough that hot units are the exception (<= 90 records per unit on average),
+    the float32 ERGO-12 and the n_imagenet accumulators hand every unit beyond their record stage to the hot launch WHOLE
+    (order-free sweep there); a unit of >= 4096 records is swept in time slices by several hot waves that merge through its
+    spill slot (here: ~15 000 records on 90 pixels of one row, and a flickering pixel).  Window 2 holds escaped polarity values:
+    its units keep the ordered ways (float32 ERGO-12), in the same launches.  Against the oracle, under every pass."""
+    import torch
+    from event_representation_study_amd import engine as eng
+    W, H, N = 304, 240, 60000
+    wins = []
+    for i in range(3):
+        ev = GENERATORS["circle"](N, W, H, seed=240 + i, polarity=("pm1", "01", "pm1")[i])
+        rng = np.random.default_rng(250 + i)
+        k = rng.integers(0, N, size=N // 4)
+        ev[k, 0] = rng.integers(100, 190, size=len(k)); ev[k, 1] = 99 + i
+        k = rng.integers(0, N, size=N // 12)
+        ev[k, 0], ev[k, 1] = 17, 200 + i
+        if i == 2:
+            odd = rng.random(N) < 0.002
+            ev[odd, 3] = rng.choice(np.array([-2, 3, 7], dtype=np.int32), size=int(odd.sum()))
+        wins.append(ev)
+    ni_wins = [_ni_events(ev) for ev in wins]
+    tn = torch.from_numpy(np.concatenate([_tnorm(ev) for ev in wins])).cuda()
+    refs = [(oracle.ergo12(ev, H, W), oracle.nimagenet_acc("acc_all", _ni_rows(ev), H, W),
+             oracle.nimagenet_acc("acc_time_pol", _ni_rows(ev), H, W)) for ev in wins]
+    for pass_name, flags in PASSES.items():
+        eb = _batch(eng, wins, H, W, flags)
+        if pass_name in ("auto", "key_sorted"):
+            assert eb.plan.reserved == 2
+        rep, rep32 = eb.optimized().cpu().numpy(), eb.optimized(dtype=torch.float32).cpu().numpy()
+        eb_ni = _batch(eng, ni_wins, H, W, flags)
+        acc_all = eb_ni.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2]).cpu().numpy()
+        acc_tp = eb_ni.polstats(tn, [1, 2], [1, 1]).cpu().numpy()
+        assert not any(int(s) & _lib.ST_HOT_OVERFLOW for s in eb.status())
+        for b, (ref, a_all, a_tp) in enumerate(refs):
+            assert_bit_equal(rep[b], ref, "ergo12 %s w%d" % (pass_name, b))
+            assert_bit_equal(rep32[b], ref.astype(np.float32), "ergo12 f32 %s w%d" % (pass_name, b))
+            np.testing.assert_array_equal(np.moveaxis(acc_all[b], -1, 0), a_all, err_msg="acc_all %s w%d" % (pass_name, b))
+            np.testing.assert_array_equal(np.moveaxis(acc_tp[b], -1, 0), a_tp, err_msg="acc_time_pol %s w%d" % (pass_name, b))
