@@ -538,8 +538,9 @@ struct NoSplit { static constexpr bool enabled = false; static constexpr bool in
 __host__ __device__ inline uint32_t split_gwpp(int words_per_px) { return ((uint32_t)words_per_px + 2u) & ~1u; }
 struct NoMerge { __device__ inline void operator()(const uint32_t *, uint32_t *) const {} };
 struct NoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
-template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge, typename Pre = NoPre>
-struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; Begin begin; F f; Done done; int words_per_px; uint32_t st_lane;
+template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge, typename Pre = NoPre, bool SLICEABLE = true>
+struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; static constexpr bool sliceable = SLICEABLE;   // (time slices need Merge)
+                   Begin begin; F f; Done done; int words_per_px; uint32_t st_lane;
                    Merge merge;   // merge(mine, unit): a time slice's words of one pixel into the unit's words in global memory (atomics; sub-waves)
                    Pre pre;       // pre(record) -> 8 bytes the builder wants of the record from global memory (its caller-side time): gathered for every
                                   // batch of a round before the first f() -- all in flight together -- and handed to f as `aux`
@@ -548,6 +549,8 @@ template <bool IN_HOT = false, typename Begin, typename F, typename Done>
 __device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, NoMerge(), NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge>
 __device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, m, NoPre()}; }
+template <bool IN_HOT, typename Begin, typename F, typename Done>
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false> unit_split_whole(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false>{b, f, d, words_per_px, st_lane, NoMerge(), NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge, typename Pre>
 __device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre> unit_split_full(Begin b, F f, Done d, int words_per_px, Merge m, Pre pr) { return UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre>{b, f, d, words_per_px, 0u, m, pr}; }
 #ifndef EVREP_SPLIT_BATCHES
@@ -761,7 +764,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
             // stream bounds a sweep at ~250 instructions per 64 records: a 20 000-record unit of a 1 Mpx circle window took one
             // hot wave 100 us, the whole launch's tail.  This wave clears the slot's header and words (visible at the launch boundary).
             bool ok;
-            if (nrec >= kHotSubMin) {
+            if (Split::sliceable && nrec >= kHotSubMin) {
                 uint4 *z = reinterpret_cast<uint4 *>(bv.spill + cs);
                 const uint32_t nz = (kHotSubHdrBytes + 4u * split_gwpp(split.words_per_px) * (uint32_t)npixu + 15u) / 16u;
                 for (uint32_t i = (uint32_t)lane; i < nz; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -2677,8 +2680,37 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
             const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
             if (bv.fused) {
-                ur = unit_records(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
-                                  row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part);
+                // TORE keeps, per pixel and polarity, the K most recent events: order-free too (r05b) -- a unit beyond the record stage
+                // whose frame is not shifted against the sensor chunks goes to the hot launch whole, where one sweep pushes every
+                // counted event's time (t - tmin + 1, one word) down a K-deep cascade of LDS atomicMax per (pixel, polarity): slot k
+                // ends up holding the (k + 1)-th largest, whatever the order of arrival.  Ascending integer timestamps only (array
+                // order is not time order otherwise; float times live in the caller's array).
+                uint32_t *words = reinterpret_cast<uint32_t *>(w.tile);
+                const int32_t tmin_w = m.tmin;
+                if constexpr (HOT) {
+                    auto yes = []() -> bool { return true; };
+                    auto tsf = [&](uint32_t px, const Rec8 &q, uint2 &, const uint2 &) -> bool {
+                        const int32_t t = (int32_t)q.x;
+                        if (!(t < T)) return false;   // events at the sample time are dropped (tore.py:17)
+                        const uint32_t p2 = (q.y >> 9) & 3u;
+                        int p = (int)p2 - 1;
+                        if (p2 == 3u) p = ev[beg + (q.y >> 11)].w;
+                        uint32_t *wd = words + px * (uint32_t)(2 * K) + (p > 0 ? 0u : (uint32_t)K);
+                        uint32_t v = (uint32_t)((int64_t)t - (int64_t)tmin_w) + 1u;
+                        for (int k = 0; k < K && v != 0u; ++k) { const uint32_t old = atomicMax(wd + k, v); v = min(old, v); }
+                        return false;
+                    };
+                    ur = unit_records<float, HOT, false, NoVisit>(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
+                                      row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part,
+                                      NoVisit(), unit_split_whole<true>(yes, tsf, yes, 2 * K));
+                } else {
+                    auto never = []() -> bool { return false; };
+                    auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
+                    const bool hand = (uc.xflags & 2) && span == 1 && tf == nullptr && !(m.status & EVREP_ST_UNSORTED);   // wave-uniform
+                    ur = unit_records<float, HOT, false, NoVisit>(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
+                                      row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part,
+                                      NoVisit(), unit_split_whole<true>(never, nof, never, 2 * K, hand ? 0u : kStEscaped));
+                }
             } else {
                 const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);
                 ur.cs = co[ch_lo];
@@ -2692,9 +2724,39 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         // empty FIFO slot: inf -> clamp 5e8 -> log(5e8 + 1) - log(151)   (tore.py:69-79)
         const double log_min = log(151.0);
         const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
-        if ((int)threadIdx.x < CM) w.bg[threadIdx.x] = bgv;
+        // (a unit swept by the split keeps its words where the background vector lies: it is emitted from registers, below)
+        if ((int)threadIdx.x < CM && ur.part != -5) w.bg[threadIdx.x] = bgv;
         wave_phase();
         float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
+        if constexpr (HOT) {
+            if (ur.part == -5) {   // wave-uniform: the unit was swept by the cascade; slot k of a pixel holds its (k + 1)-th latest time
+                const uint32_t *words = reinterpret_cast<const uint32_t *>(w.tile);
+                const int lane = threadIdx.x;
+                const bool vec = (C % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+                for (int pt = 0; pt * kWave < npix; ++pt) {
+                    if (pt * kWave + lane < npix) {
+                        const uint32_t *wd = words + (uint32_t)(pt * kWave + lane) * (uint32_t)(2 * K);
+                        float vals[CM];
+#pragma unroll
+                        for (int c = 0; c < CM; ++c) {
+                            float v = bgv;
+                            if (c < C) {
+                                const uint32_t wv = wd[c];
+                                if (wv) {
+                                    const int64_t t = (int64_t)m.tmin + (int64_t)(wv - 1u);
+                                    v = (float)(double)((int64_t)T - t);
+                                    v = fminf(v, 500e6f);
+                                    v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+                                }
+                            }
+                            vals[c] = v;
+                        }
+                        store_pixel<float, CM>(dst + ((size_t)pt * kWave + lane) * C, vals, C, vec);
+                    }
+                }
+                return;
+            }
+        }
         // The value of a FIFO slot depends on its event alone (one sample time per window): log(min(T - t, 5e8) + 1) - log(151),
         // floored at 0 (tore.py:63-79).  So the digest forms it per EVENT -- one record per lane, all lanes at once, one logf --
         // and the FIFOs hold finished values: 2 K logarithms per touched pixel become one per event.  Digest:
@@ -2953,7 +3015,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
         bool any_bg = false;
 #pragma unroll
         for (int c = 0; c < CM; ++c) any_bg |= (c < C && P.stat[c] == EVREP_PS_EXP);
-        if (any_bg) {
+        if (any_bg && u.part != -5) {   // (a unit swept by the split keeps its words where the background vector lies)
             if (lane < CM) {
                 float v = 0.0f;
                 if (lane < C && P.stat[lane] == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - 0.0) / P.tau);

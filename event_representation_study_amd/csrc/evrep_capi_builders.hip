@@ -105,9 +105,11 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
-    if (plan->reserved == 2) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, kHotStage), stream>>>(     \
+    UnitCfg hc = hot_cfg(uc);                                                                                       \
+    if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;   /* whole units by the order-free sweep: room for their words */ \
+    if (plan->reserved == 2) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
-        plan->H, plan->W, plan->nchunk, hot_cfg(uc), k, frame_mode, scale, out);                                    \
+        plan->H, plan->W, plan->nchunk, hc, k, frame_mode, scale, out);                                    \
     } while (0)
     if (k <= 6) TORE_LAUNCH(12); else TORE_LAUNCH(16);
 #undef TORE_LAUNCH

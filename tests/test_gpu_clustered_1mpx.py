@@ -185,6 +185,9 @@ def test_hand_over_whole_units_and_time_slices_at_gen1(oracle):
     tn = torch.from_numpy(np.concatenate([_tnorm(ev) for ev in wins])).cuda()
     refs = [(oracle.ergo12(ev, H, W), oracle.nimagenet_acc("acc_all", _ni_rows(ev), H, W),
              oracle.nimagenet_acc("acc_time_pol", _ni_rows(ev), H, W)) for ev in wins]
+    # TORE (full frame and the bounding-box frame) and the accumulators with an empty-pixel background (acc_exp)
+    tore_refs = [(oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W)), oracle.tore_bbox(ev, 6),
+                  oracle.nimagenet_acc("acc_exp", _ni_rows(ev), H, W)) for ev in wins]
     for pass_name, flags in PASSES.items():
         eb = _batch(eng, wins, H, W, flags)
         if pass_name in ("auto", "key_sorted"):
@@ -194,6 +197,13 @@ def test_hand_over_whole_units_and_time_slices_at_gen1(oracle):
         acc_all = eb_ni.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2]).cpu().numpy()
         acc_tp = eb_ni.polstats(tn, [1, 2], [1, 1]).cpu().numpy()
         assert not any(int(s) & _lib.ST_HOT_OVERFLOW for s in eb.status())
+        tore = eb.tore(6, frame_mode=2).cpu().numpy()
+        bbox = [t.cpu().numpy() for t in eb.tore(6, frame_mode=0)]
+        acc_exp = eb_ni.polstats(tn, [1, 2], [4, 4], tau=0.3).cpu().numpy()
+        for b, (t_full, t_bbox, a_exp) in enumerate(tore_refs):
+            np.testing.assert_allclose(tore[b], t_full, rtol=1e-6, atol=1e-6, err_msg="tore %s w%d" % (pass_name, b))
+            np.testing.assert_allclose(bbox[b], t_bbox, rtol=1e-6, atol=1e-6, err_msg="tore bbox %s w%d" % (pass_name, b))
+            np.testing.assert_allclose(np.moveaxis(acc_exp[b], -1, 0), a_exp, rtol=1e-6, atol=1e-7, err_msg="acc_exp %s w%d" % (pass_name, b))
         for b, (ref, a_all, a_tp) in enumerate(refs):
             assert_bit_equal(rep[b], ref, "ergo12 %s w%d" % (pass_name, b))
             assert_bit_equal(rep32[b], ref.astype(np.float32), "ergo12 f32 %s w%d" % (pass_name, b))
