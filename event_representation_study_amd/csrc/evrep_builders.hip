@@ -2706,7 +2706,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
                 } else {
                     auto never = []() -> bool { return false; };
                     auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
-                    const bool hand = (uc.xflags & 2) && span == 1 && tf == nullptr && !(m.status & EVREP_ST_UNSORTED);   // wave-uniform
+                    const bool hand = (uc.xflags & 2) && tf == nullptr && !(m.status & EVREP_ST_UNSORTED);   // wave-uniform
                     ur = unit_records<float, HOT, false, NoVisit>(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
                                       row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part,
                                       NoVisit(), unit_split_whole<true>(never, nof, never, 2 * K, hand ? 0u : kStEscaped));
@@ -3005,7 +3005,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
             auto never = []() -> bool { return false; };
             auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
             u = unit_front<float, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
-                                                       unit_split<true>(never, nof, never, kPsWords, (uc.xflags & 2) && uc.span == 1 ? 0u : kStEscaped));
+                                                       unit_split<true>(never, nof, never, kPsWords, (uc.xflags & 2) ? 0u : kStEscaped));
         }
         if (u.deferred) return;
         float *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * C;

@@ -69,7 +69,7 @@ static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int e
     // (an experiment switch, off by default: measured at the Gen1 shape the 176-pixel unit loses the sparse emit -- ~95 records
     //  in ~80 pixels -- and its three-part tile sequence costs more than the 48-pixel tail unit it saves: ERGO-12 68 -> 82 us)
     uc.merge = (extra_chunks == 0 && tail != 0 && tail <= kChunkPx / 2 && plan->nchunk >= 2 && (plan->flags & EVREP_PLAN_X_TAIL_MERGE)) ? 1 : 0;
-    uc.xflags = ((uc.span == 1 && per_chunk <= 90.0) || ((plan->flags & 1024) && uc.span > 1)) ? 2 : 0;   // see UnitCfg::xflags
+    uc.xflags = ((uc.span == 1 && (per_chunk <= 90.0 || (plan->flags & 2048))) || ((plan->flags & 1024) && uc.span > 1)) ? 2 : 0;   // see UnitCfg::xflags (2048: EVREP_X_HANDOVER_DENSE, experiment)
     unit_cfg_geometry(uc, plan);
     return uc;
 }

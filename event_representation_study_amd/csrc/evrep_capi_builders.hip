@@ -106,7 +106,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
     UnitCfg hc = hot_cfg(uc);                                                                                       \
-    if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;   /* whole units by the order-free sweep: room for their words */ \
+    if (uc.xflags & 2) hc.stage = kHotSplitStage * span;   /* whole units by the order-free sweep: room for their words */ \
     if (plan->reserved == 2) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, hc, k, frame_mode, scale, out);                                    \
@@ -194,15 +194,19 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
         P.stat[c] = stat[c];
     }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const UnitCfg uc = unit_cfg(plan, (size_t)C * 4, 0, true);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
+    UnitCfg uc = unit_cfg(plan, (size_t)C * 4, 0, true);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
+    // every statistic is order-free: two-chunk units (sparse windows) go to the hot launch whole as well -- measured, r05b: 1 Mpx
+    // circle windows 230 -> 129 us, the other clustered streams within 3 % (TORE, whose sweep is heavier and cannot be sliced: 124
+    // -> 142 us on the config 2 circle, so its two-chunk units stay)
+    if (span == 2) uc.xflags |= 2;
 #define PS_LAUNCH(CM)                                                                                                 \
     do {                                                                                                              \
         k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
         /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \
         UnitCfg hc = hot_cfg(uc);                                                                                     \
-        if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;                                                  \
+        if (uc.xflags & 2) hc.stage = kHotSplitStage * span;                                                          \
         if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hc, out);   \
     } while (0)
