@@ -125,7 +125,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.evrep_abi_version.restype = ctypes.c_int
     lib.evrep_abi_version.argtypes = []
-    if lib.evrep_abi_version() != ABI_VERSION:   # (before the symbols are bound: a stale library says so, not AttributeError)
+    if lib.evrep_abi_version() != ABI_VERSION and not (os.environ.get("EVREP_LIB_PATH") and os.environ.get("EVREP_ABI_ANY")):   # (before the symbols are bound: a stale library says so, not AttributeError; EVREP_ABI_ANY: A/B timing of an older build through EVREP_LIB_PATH, tools only)
         raise EvrepError("libevrep.so ABI %d != binding ABI %d: rebuild with `python -m event_representation_study_amd.build`"
                          % (lib.evrep_abi_version(), ABI_VERSION))
     for name, (res, args) in SYMBOLS.items():
