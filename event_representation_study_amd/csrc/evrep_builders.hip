@@ -2637,7 +2637,7 @@ constexpr int kMaxToreK = 8;
 
 // grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
-template <int CM, bool HOT = false>  // compile-time channel capacity, 2 * K <= CM (12 or 16)
+template <int CM, bool HOT = false, bool SM = false>  // compile-time channel capacity, 2 * K <= CM (12 or 16); SM: the main launch sweeps itself (see k_polstats)
 __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
@@ -2687,8 +2687,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
                 // order is not time order otherwise; float times live in the caller's array).
                 uint32_t *words = reinterpret_cast<uint32_t *>(w.tile);
                 const int32_t tmin_w = m.tmin;
-                if constexpr (HOT) {
-                    auto yes = []() -> bool { return true; };
+                if constexpr (HOT || SM) {
+                    // (the sweeping main launch, SM: only where the order-free form holds -- else the ordered ways, in this launch or deferred)
+                    const bool sweepable = HOT || (tf == nullptr && !(m.status & EVREP_ST_UNSORTED));   // wave-uniform
+                    auto yes = [&]() -> bool { return sweepable; };
                     auto tsf = [&](uint32_t px, const Rec8 &q, uint2 &, const uint2 &) -> bool {
                         const int32_t t = (int32_t)q.x;
                         if (!(t < T)) return false;   // events at the sample time are dropped (tore.py:17)
@@ -2702,7 +2704,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
                     };
                     ur = unit_records<float, HOT, false, NoVisit>(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
                                       row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part,
-                                      NoVisit(), unit_split_whole<true>(yes, tsf, yes, 2 * K));
+                                      NoVisit(), unit_split_whole<HOT>(yes, tsf, yes, 2 * K));
                 } else {
                     auto never = []() -> bool { return false; };
                     auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
@@ -2728,7 +2730,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
         if ((int)threadIdx.x < CM && ur.part != -5) w.bg[threadIdx.x] = bgv;
         wave_phase();
         float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
-        if constexpr (HOT) {
+        if constexpr (HOT || SM) {
             if (ur.part == -5) {   // wave-uniform: the unit was swept by the cascade; slot k of a pixel holds its (k + 1)-th latest time
                 const uint32_t *words = reinterpret_cast<const uint32_t *>(w.tile);
                 const int lane = threadIdx.x;
@@ -2939,8 +2941,10 @@ struct PolStatParams {
 // grid (ceil(nchunk/span), H, B), 64 threads.  tnorm[off[b] + rank] = the record's normalised float64 time.
 // (6 waves per SIMD asked for: 110 -> 80 VGPRs with 52 bytes of scratch, 81 -> 64 us at 32 x 50 000 events, 640x480x6;
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
-template <int CM, bool HOT = false>
-__global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
+// SM (r05b): the MAIN launch runs the order-free sweep itself (dense windows: every unit is beyond the record stage and the hot launch
+// is the slower place for bulk work; the host gives this instance a stage that holds the words) -- nothing is deferred, no hot launch
+template <int CM, bool HOT = false, bool SM = false>
+__global__ __launch_bounds__(kWave, (HOT || SM) ? 4 : 6) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, UnitCfg uc,
                                                    float *__restrict__ out) {
@@ -2971,7 +2975,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
         const double *tw0 = tnorm + off[b0];
         const int4 *evw0 = bv.ev + off[b0];
         UnitRecs u;
-        if constexpr (HOT) {
+        if constexpr (HOT || SM) {
             uint32_t *words = reinterpret_cast<uint32_t *>(w.tile);
             auto yes = []() -> bool { return true; };
             auto ppre = [&](const Rec8 &q) -> uint2 {   // the record's time, gathered for every batch of a round before the first atomic
@@ -3000,7 +3004,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
                 for (int k = 0; k < 6; ++k) if (m64[k]) atomicMax(g64 + k, m64[k]);
             };
             u = unit_front<float, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
-                                                       unit_split_full<true>(yes, psf, yes, kPsWords, pmerge, ppre));
+                                                       unit_split_full<HOT>(yes, psf, yes, kPsWords, pmerge, ppre));
         } else {
             auto never = []() -> bool { return false; };
             auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
@@ -3045,7 +3049,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 6) void k_polstats(BinView bv,
                 vals[c] = v;
             }
         };
-        if constexpr (HOT) {
+        if constexpr (HOT || SM) {
             if (u.part == -5) {   // wave-uniform: the unit was swept by the split; every pixel's statistics wait in its words
                 const uint32_t *words = reinterpret_cast<const uint32_t *>(w.tile);
                 const bool vec = (C % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;

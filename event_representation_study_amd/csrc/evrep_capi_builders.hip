@@ -100,14 +100,30 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
     const int span = uc.span;
+    // dense windows: the main launch runs the order-free cascade itself (k_tore, SM), as k_polstats does
+    const double per_chunk_t = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    const bool sweep_main = plan->reserved == 2 && span == 1 && per_chunk_t > 150.0 && !(plan->flags & 4096) && tf == nullptr;
+    UnitCfg um = uc;
+    if (sweep_main) {
+        const size_t need = (size_t)kChunkPx * 2 * k * 4 + 1024, have = align16((size_t)kPartPx * 2 * k * 4) + align16((size_t)EVREP_MAX_CHANNELS * 4);
+        const int st = (int)((need > have ? need - have : 0) + 15) / 16;
+        if (um.stage < st) um.stage = (st + 63) & ~63;
+    }
 #define TORE_LAUNCH(CM)                                                                                             \
     do {                                                                                                            \
+    if (sweep_main) {                                                                                               \
+        k_tore<CM, false, true><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, um.stage), stream>>>(   \
+            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f, \
+            plan->H, plan->W, plan->nchunk, um, k, frame_mode, scale, out);                                         \
+    } else {                                                                                                        \
     k_tore<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, uc.stage), stream>>>(          \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
+    }                                                                                                               \
     UnitCfg hc = hot_cfg(uc);                                                                                       \
-    if (uc.xflags & 2) hc.stage = kHotSplitStage * span;   /* whole units by the order-free sweep: room for their words */ \
-    if (plan->reserved == 2) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
+    if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;   /* whole units by the order-free sweep: room for their words */ \
+    /* (none behind the sweeping main launch: it defers nothing -- units with a shifted frame or unsorted timestamps are emitted from their slot by the main wave) */ \
+    if (plan->reserved == 2 && !sweep_main) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, hc, k, frame_mode, scale, out);                                    \
     } while (0)
@@ -200,8 +216,22 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     // circle windows 230 -> 129 us, the other clustered streams within 3 % (TORE, whose sweep is heavier and cannot be sliced: 124
     // -> 142 us on the config 2 circle, so its two-chunk units stay)
     if (span == 2) uc.xflags |= 2;
+    // dense windows (every unit beyond the record stage): the main launch sweeps order-free itself (k_polstats, SM) with a stage
+    // that holds the unit's fourteen words per pixel; nothing is deferred and there is no hot launch
+    const double per_chunk_ps = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    const bool sweep_main = plan->reserved == 2 && span == 1 && per_chunk_ps > 150.0 && !(plan->flags & 4096);   // (measured: 8 x 500 000 events at 640x480 74 -> 63 us; at 250 000 -- 104 per unit, most of them inside the stage -- 52 -> 58: the instance's budget is the sweep's); 4096: EVREP_X_NO_SWEEP_MAIN
+    if (sweep_main) {
+        const size_t need = (size_t)kChunkPx * 14 * 4 + 1024, have = align16((size_t)uc.partpx * C * 4) + align16((size_t)EVREP_MAX_CHANNELS * 4);
+        const int st = (int)((need > have ? need - have : 0) + 15) / 16;
+        if (uc.stage < st) uc.stage = (st + 63) & ~63;
+    }
 #define PS_LAUNCH(CM)                                                                                                 \
     do {                                                                                                              \
+        if (sweep_main) {                                                                                             \
+            k_polstats<CM, false, true><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
+                bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);        \
+            break;                                                                                                    \
+        }                                                                                                             \
         k_polstats<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
         /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \

@@ -79,6 +79,30 @@ def test_dense_stress_500k(eng, oracle):
     eb = eng.EventBatch.from_numpy(ev, H, W)
     assert_bit_equal(eb.optimized()[0].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 dense")
     assert_bit_equal(eb.voxel(5)[0].cpu().numpy(), oracle.voxel(ev, H, W, 5), "voxel dense")
+    # r05b: on windows this dense the MAIN launches of TORE and of the n_imagenet accumulators run their order-free sweeps
+    # themselves (k_tore / k_polstats, SM): full frame, the shifted bounding-box frame (ordered ways inside the same launch), a
+    # second window in array order (unsorted timestamps: ordered ways), the accumulators incl. one with an empty-pixel background
+    np.testing.assert_allclose(eb.tore(6, frame_mode=2)[0].cpu().numpy(),
+                               oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W)), rtol=1e-6, atol=1e-6)
+    ev2 = ev.copy()
+    ev2[:, 0] = 5 + ev2[:, 0] % 600          # a bounding box that does not start at a chunk boundary
+    un = ev.copy()
+    k = np.random.default_rng(3).random(N) < 0.2
+    un[k, 2] = np.random.default_rng(4).integers(0, 60000, size=int(k.sum()))
+    eb2 = eng.EventBatch.from_numpy([ev2, un], H, W)
+    tb = eb2.tore(6, frame_mode=0)
+    np.testing.assert_allclose(tb[0].cpu().numpy(), oracle.tore_bbox(ev2, 6), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(eb2.tore(6, frame_mode=2)[1].cpu().numpy(),
+                               oracle.tore(un[:, 0] + 1, un[:, 1] + 1, un[:, 2], un[:, 3], un[-1, 2], 6, (H, W)), rtol=1e-6, atol=1e-6)
+    ni = ev.copy()
+    ni[:, 3] = np.where(ev[:, 3] > 0, 1, -1)
+    rows = ni.astype(np.float64)
+    t = ev[:, 2].astype(np.float64)
+    tn = torch.from_numpy((t - t[0]) / (t[-1] - t[0])).cuda()
+    ebn = eng.EventBatch.from_numpy(ni, H, W)
+    for name, pol, stat in (("acc_all", [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2]), ("acc_exp", [1, 2], [4, 4])):
+        got = np.moveaxis(ebn.polstats(tn, pol, stat, tau=0.3)[0].cpu().numpy(), -1, 0)
+        np.testing.assert_allclose(got, oracle.nimagenet_acc(name, rows, H, W), rtol=1e-6, atol=1e-7, err_msg=name)
 
 
 def test_hot_pixels_and_hot_rows(eng, oracle):
