@@ -12,6 +12,13 @@ def builders(eb):
     out = {"ergo12": eb.optimized(), "ergo12_f32": eb.optimized(dtype=torch.float32), "es": eb.event_stack(),
            "ts": eb.time_surface(), "tore": eb.tore(6, frame_mode=2), "tore1": eb.tore(5, frame_mode=1), "vox": eb.voxel(5), "vox2": eb.voxel(9, mode=2),
            "mdes": eb.mdes([0, 1, 2, 3, 4, 5, 6, 2], [0, 1, 2, 3, 4, 5, 6, 0], [0, 1, 2, 3, 0, 1, 2, 3])}
+    # r05: the n_imagenet accumulators (order-free hand-over / sweeping main launch): counts, time maxima / minima, the exp channel
+    ev = eb.events.cpu().numpy(); off = eb.offsets_host.numpy()
+    tn = np.zeros(len(ev), np.float64)
+    for b in range(len(off) - 1):
+        t = ev[off[b]:off[b + 1], 2].astype(np.float64)
+        if len(t) and t[-1] != t[0]: tn[off[b]:off[b + 1]] = (t - t[0]) / (t[-1] - t[0])
+    out["acc"] = eb.polstats(torch.from_numpy(tn).cuda(), [1, 2, 1, 2, 1, 2, 0, 1], [0, 0, 1, 1, 2, 2, 5, 4], tau=0.3)
     return {k: v.cpu().numpy() for k, v in out.items()}
 t0 = time.time(); n = 0; seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
