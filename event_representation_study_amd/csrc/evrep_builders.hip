@@ -2486,8 +2486,13 @@ static __global__ void k_ts_cuts(const int4 *__restrict__ ev, const int64_t *__r
 
 // CM = compile-time channel capacity, 2 * slices <= CM (12 or 16); FACT = the factorised exponentials are compiled in
 // (launches on sparse windows; dense windows run the leaner per-slice form)
+// (waves per SIMD asked of the compiler: 4 = 128 VGPRs, no scratch -- r05b: at 5 the float64 instances carried 44-108 bytes of scratch,
+//  and a launch of tens of thousands of one-wave workgroups pays for scratch per wave: Gen1 88.7 -> 78.9 us, config 3 135.8 -> 129.3)
+#ifndef EVREP_TS_WAVES
+#define EVREP_TS_WAVES 4
+#endif
 template <typename OutT, int CM, bool FACT, bool HOT = false>
-__global__ __launch_bounds__(kWave, HOT ? 4 : 5) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave, HOT ? 4 : EVREP_TS_WAVES) void k_time_surface(BinView bv, const int64_t *__restrict__ off,
                                                        const TsCuts *__restrict__ cuts, int H, int W, int nchunk, UnitCfg uc,
                                                        int S, double tau, int premap, double scale, const double *__restrict__ tf,
                                                        OutT *__restrict__ out) {
@@ -2943,8 +2948,11 @@ struct PolStatParams {
 // the same hint does nothing for EventStack / TORE, which sit at the store ceiling, and hurts k_voxel, r02)
 // SM (r05b): the MAIN launch runs the order-free sweep itself (dense windows: every unit is beyond the record stage and the hot launch
 // is the slower place for bulk work; the host gives this instance a stage that holds the words) -- nothing is deferred, no hot launch
+#ifndef EVREP_PS_WAVES
+#define EVREP_PS_WAVES 6
+#endif
 template <int CM, bool HOT = false, bool SM = false>
-__global__ __launch_bounds__(kWave, (HOT || SM) ? 4 : 6) void k_polstats(BinView bv,
+__global__ __launch_bounds__(kWave, (HOT || SM) ? 4 : EVREP_PS_WAVES) void k_polstats(BinView bv,
                                                    const int64_t *__restrict__ off, const double *__restrict__ tnorm,
                                                    PolStatParams P, int H, int W, int nchunk, UnitCfg uc,
                                                    float *__restrict__ out) {
