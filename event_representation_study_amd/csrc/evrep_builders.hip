@@ -65,7 +65,10 @@ struct UnitCfg {
     // units per row and two multiply-shift reciprocals over (fastdiv_make; exact for ids < 2^31, which evrep_plan_init ensures)
     int nunit;
     uint32_t nunit_m, nunit_sh, h_m, h_sh;
-    int xflags;  // bit 1: builders with a hot-launch split sweep (float32 ERGO-12) hand units beyond the record stage over whole -- set by
+    int xflags;  // bit 2 (value 4): two-chunk units of sparse windows: only units of >= kHotSubMin records are handed over (r05b: a monster unit's
+                 // ordering is the main launch's tail -- 200 us on the 1 Mpx circle -- while the mid-size hot units of a 640x480 window are
+                 // better off ordered beside the store-bound waves);
+                 // bit 1: builders with a hot-launch split sweep (float32 ERGO-12) hand units beyond the record stage over whole -- set by
                  // the host for one-chunk units of windows whose AVERAGE unit fits the stage (hot units are the exception: on dense
                  // windows every unit would go, and the hot launch is the slower place: 8 x 500 000 events 82 -> 134 us, measured);
                  // EVREP_PLAN_X_HANDOVER2 (experiment) also sets it for two-chunk units
@@ -541,18 +544,19 @@ struct NoPre { __device__ inline uint2 operator()(const Rec8 &) const { return m
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge = NoMerge, typename Pre = NoPre, bool SLICEABLE = true>
 struct UnitSplit { static constexpr bool enabled = true; static constexpr bool in_hot = IN_HOT; static constexpr bool sliceable = SLICEABLE;   // (time slices need Merge)
                    Begin begin; F f; Done done; int words_per_px; uint32_t st_lane;
+                   uint32_t min_rec;   // main launch, IN_HOT: only units of at least this many records are handed over (0: every unit beyond the stage)
                    Merge merge;   // merge(mine, unit): a time slice's words of one pixel into the unit's words in global memory (atomics; sub-waves)
                    Pre pre;       // pre(record) -> 8 bytes the builder wants of the record from global memory (its caller-side time): gathered for every
                                   // batch of a round before the first f() -- all in flight together -- and handed to f as `aux`
 };
 template <bool IN_HOT = false, typename Begin, typename F, typename Done>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, NoMerge(), NoPre()}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u, uint32_t min_rec = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, min_rec, NoMerge(), NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, m, NoPre()}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge> unit_split_merge(Begin b, F f, Done d, int words_per_px, Merge m) { return UnitSplit<IN_HOT, Begin, F, Done, Merge>{b, f, d, words_per_px, 0u, 0u, m, NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false> unit_split_whole(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u) { return UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false>{b, f, d, words_per_px, st_lane, NoMerge(), NoPre()}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false> unit_split_whole(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u, uint32_t min_rec = 0u) { return UnitSplit<IN_HOT, Begin, F, Done, NoMerge, NoPre, false>{b, f, d, words_per_px, st_lane, min_rec, NoMerge(), NoPre()}; }
 template <bool IN_HOT, typename Begin, typename F, typename Done, typename Merge, typename Pre>
-__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre> unit_split_full(Begin b, F f, Done d, int words_per_px, Merge m, Pre pr) { return UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre>{b, f, d, words_per_px, 0u, m, pr}; }
+__device__ inline UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre> unit_split_full(Begin b, F f, Done d, int words_per_px, Merge m, Pre pr) { return UnitSplit<IN_HOT, Begin, F, Done, Merge, Pre>{b, f, d, words_per_px, 0u, 0u, m, pr}; }
 #ifndef EVREP_SPLIT_BATCHES
 #define EVREP_SPLIT_BATCHES 8
 #endif
@@ -757,7 +761,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         const uint32_t stw = wave_or(lane < nb ? split.st_lane : 0u);
         // (warm units too -- those that would fit this wave's hot stage: measured, r05b, ordering them here makes the main launch
         //  of a clustered batch 30-40 % longer, which the hot launch they spare does not give back)
-        if (!(stw & kStEscaped) && nrec <= 65535u && dpx == 0) {
+        if (!(stw & kStEscaped) && nrec >= split.min_rec && nrec <= 65535u && dpx == 0) {
             // A unit of >= kHotSubMin records is taken in TIME slices (r05b): S hot waves sweep ~1 000 consecutive records each into
             // their own words, merge them into the unit's words in its spill slot (global atomics: sums, flags, maxima), leave their
             // kept records there, and the last one to finish orders the kept records and emits the unit.  One wave's instruction
@@ -2001,7 +2005,8 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
         // lane k: the status word of the window's block k (meta_prefetch: q2.x), merged by unit_records only when a unit is hot
         u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
                                                   unit_split<true>(never, nof, never, kErgoSplitWords,
-                                                                   (uint32_t)mraw.q2.x | ((uc.xflags & 2) ? 0u : kStEscaped)));
+                                                                   (uint32_t)mraw.q2.x | ((uc.xflags & 6) ? 0u : kStEscaped),
+                                                                   (uc.xflags & 2) ? 0u : kHotSubMin));
         // (two-chunk units -- sparse windows, 640x480 / 1280x720 at 50 000 - 200 000 events -- keep the ordered ways: measured, r05b,
         //  their hot units are few and huge -- 4 000 to 20 000 records, one wave's instruction stream each, 30 to 100 us of sweep --
         //  and the hot launch's tail costs 5-8 % more than it saves; at the reference's Gen1 shape the hand-over takes the
@@ -2713,10 +2718,10 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
                 } else {
                     auto never = []() -> bool { return false; };
                     auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
-                    const bool hand = (uc.xflags & 2) && tf == nullptr && !(m.status & EVREP_ST_UNSORTED);   // wave-uniform
+                    const bool hand = (uc.xflags & 6) && tf == nullptr && !(m.status & EVREP_ST_UNSORTED);   // wave-uniform
                     ur = unit_records<float, HOT, false, NoVisit>(bv, off, b, H * nchunk, row * nchunk + ch_lo, row * nchunk + ch_hi + 1,
                                       row * W + ch_lo * kChunkPx, (ch_hi - ch_lo + 1) * kChunkPx, w, row * W + sc_lo, ch_lo * kChunkPx, uid, npix, part,
-                                      NoVisit(), unit_split_whole<true>(never, nof, never, 2 * K, hand ? 0u : kStEscaped));
+                                      NoVisit(), unit_split_whole<true>(never, nof, never, 2 * K, hand ? 0u : kStEscaped, (uc.xflags & 2) ? 0u : kHotSubMin));
                 }
             } else {
                 const uint32_t *co = bv.chunk_off + ((size_t)b * H + row) * (nchunk + 1);

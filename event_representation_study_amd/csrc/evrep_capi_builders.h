@@ -70,10 +70,19 @@ static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int e
     //  in ~80 pixels -- and its three-part tile sequence costs more than the 48-pixel tail unit it saves: ERGO-12 68 -> 82 us)
     uc.merge = (extra_chunks == 0 && tail != 0 && tail <= kChunkPx / 2 && plan->nchunk >= 2 && (plan->flags & EVREP_PLAN_X_TAIL_MERGE)) ? 1 : 0;
     uc.xflags = ((uc.span == 1 && (per_chunk <= 90.0 || (plan->flags & 2048))) || ((plan->flags & 1024) && uc.span > 1)) ? 2 : 0;   // see UnitCfg::xflags (2048: EVREP_X_HANDOVER_DENSE, experiment)
+    if (uc.span > 1 && !(uc.xflags & 2) && !(plan->flags & 8192)) uc.xflags |= 4;   // monsters only (8192: EVREP_X_NO_MONSTER_HANDOVER, experiment)
     unit_cfg_geometry(uc, plan);
     return uc;
 }
 #define SPAN_GRID(span) dim3(units_per_row(plan->nchunk, (span), uc.merge), plan->H, plan->B)
+// records of the LDS stage of a hot launch whose waves take whole units by an order-free sweep: tile + background + stage have to hold
+// the unit's words (+ `list_bytes` of kept records); never less than the ordinary hot stage (the ordered hot pieces use it)
+static inline int hot_sweep_stage(size_t words_bytes, size_t list_bytes, size_t tile_bytes) {
+    const size_t have = align16(tile_bytes) + align16((size_t)EVREP_MAX_CHANNELS * 8), need = words_bytes + list_bytes;
+    const int st = need > have ? (int)((need - have + 15) / 16) : 0;
+    const int r = (st + 63) & ~63;
+    return r > kHotStage ? r : kHotStage;
+}
 // the hot launch behind a builder launch (run_units): the same unit numbering (span), a stage of kHotStage records, no pacing
 // (only launched after the key-sorted pass: the main launches of the classic passes defer nothing)
 static inline UnitCfg hot_cfg(UnitCfg uc) { uc.stage = kHotStage; uc.hold = 0; return uc; }

@@ -121,7 +121,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
     }                                                                                                               \
     UnitCfg hc = hot_cfg(uc);                                                                                       \
-    if ((uc.xflags & 2) && span == 1) hc.stage = kHotSplitStage;   /* whole units by the order-free sweep: room for their words */ \
+    if (uc.xflags & 6) hc.stage = hot_sweep_stage((size_t)span * kChunkPx * 2 * k * 4, 512, (size_t)kPartPx * 2 * k * 4);   /* whole units by the order-free sweep: room for their words */ \
     /* (none behind the sweeping main launch: it defers nothing -- units with a shifted frame or unsorted timestamps are emitted from their slot by the main wave) */ \
     if (plan->reserved == 2 && !sweep_main) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
@@ -236,7 +236,7 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
         /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \
         UnitCfg hc = hot_cfg(uc);                                                                                     \
-        if (uc.xflags & 2) hc.stage = kHotSplitStage * span;                                                          \
+        if (uc.xflags & 2) hc.stage = hot_sweep_stage((size_t)span * kChunkPx * 14 * 4, 512, (size_t)uc.partpx * C * 4);   \
         if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hc, out);   \
     } while (0)
