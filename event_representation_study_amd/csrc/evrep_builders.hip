@@ -32,6 +32,18 @@ namespace evrep {
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// waves per SIMD asked of the compiler for the main launches (1 = no request).  r05c: EventStack (84-93 -> 73-79 VGPRs) and the voxel
+// grid of <= 8 bins (83 -> 80) fit six waves WITHOUT scratch: Gen1 35.1 -> 33.0 / 60.0 -> 58.0 us, 640x480 x 250 000 events 34.5 -> 32.8 /
+// 65.6 -> 62.6; TORE (93 -> 75) gains nothing from it
+#ifndef EVREP_ES_WAVES
+#define EVREP_ES_WAVES 6
+#endif
+#ifndef EVREP_TORE_WAVES
+#define EVREP_TORE_WAVES 1
+#endif
+#ifndef EVREP_VOXEL_WAVES
+#define EVREP_VOXEL_WAVES 6
+#endif
 #ifndef EVREP_PARTS
 #define EVREP_PARTS 2
 #endif
@@ -2336,7 +2348,7 @@ static __global__ __launch_bounds__(1024) void k_mdes_sbt_windows(const int4 *__
 // A6: EventStack.pre_stack / post_stack (event_stack.py:15-131), last_timestamp = t[-1]
 // --------------------------------------------------------------------------------------------
 template <int CM, bool HOT = false>  // compile-time channel capacity (8, 12 or 16)
-__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_event_stack(BinView bv,
+__global__ __launch_bounds__(kWave, HOT ? 4 : EVREP_ES_WAVES) void k_event_stack(BinView bv,
                                                       const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
                                                       int S, int premap, float scale, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2648,7 +2660,7 @@ constexpr int kMaxToreK = 8;
 // grid (ceil(nchunk/span), H, B) over OUTPUT units / rows, 64 threads.
 // sample_times == nullptr: T = ts[-1] (gen1_transforms.py:63); else DEVICE int32 [B].
 template <int CM, bool HOT = false, bool SM = false>  // compile-time channel capacity, 2 * K <= CM (12 or 16); SM: the main launch sweeps itself (see k_polstats)
-__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 12 ? EVREP_TORE_WAVES : 1)) void k_tore(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                const int32_t *__restrict__ sample_times,
                                                const double *__restrict__ tf, const double *__restrict__ sample_times_f,
                                                int H, int W, int nchunk, UnitCfg uc, int K, int frame_mode, float scale,
@@ -2856,7 +2868,7 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_tore(const int4 *__restr
 // --------------------------------------------------------------------------------------------
 // CM = compile-time channel capacity (8 or 16): the register arrays of a <= 8-bin grid are half the size
 template <int CM, bool HOT = false>
-__global__ __launch_bounds__(kWave, HOT ? 4 : 1) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1)) void k_voxel(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
                                                 int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
                                                 const int64_t *__restrict__ t_range, const double *__restrict__ tnorm,
                                                 double *__restrict__ out) {
