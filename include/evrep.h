@@ -43,7 +43,7 @@ extern "C" {
 /* per-window status bits (evrep_read_status) */
 #define EVREP_ST_EMPTY 1u      /* window has no events (reference: ValueError on t.min()) */
 #define EVREP_ST_OOB 2u        /* some x + y*W outside [0, H*W) (reference: IndexError in put / zero channel in MDES) */
-#define EVREP_ST_UNSORTED 4u   /* timestamps not ascending: evrep_mdes / evrep_optimized work in array order as the reference does; the other builders' tensors are undefined */
+#define EVREP_ST_UNSORTED 4u   /* timestamps not ascending: evrep_mdes / evrep_optimized, evrep_event_stack, evrep_time_surface (premap bit 1) and evrep_tore work in array order as the reference does; the other builders' tensors are undefined */
 #define EVREP_ST_FLAT_TIME 8u  /* t[-1] == t[0] (reference divides by zero) */
 #define EVREP_ST_HOT_OVERFLOW 16u /* a builder could not queue a unit of a clustered window (the workspace's hot list was full): pixels of the window are unwritten */
 
@@ -167,6 +167,8 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
  *               output is a compact (Hbb,Wbb,2k) array at out + b*H*W*2k, bbox via evrep_read_bbox;
  * frame_mode 1: full (H,W) frame, origin-shifted by (xmin,ymin) (n_imagenet .../imagenet.py:1095-1103);
  * frame_mode 2: full (H,W) frame, no shift (x, y used as 0-based pixel coordinates).
+ * Timestamps that are not ascending (EVREP_ST_UNSORTED): array order, each event replacing the (pixel, polarity) k-vector v by the
+ * sorted [dt] + v[:k-1] -- what np.partition yields there on numpy >= 2.0 / AVX2+ hosts (tore.py:22-25).
  * out DEVICE float32. */
 int evrep_tore(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                int32_t k, int32_t frame_mode, const int32_t *sample_times, float scale, float *out, void *stream);
