@@ -18,3 +18,4 @@ python tools/parse_pmc.py $P/pmc_fetch_counter_collection.csv $P/pmc_write_count
 cp profiles/traffic.json $P/traffic.json
 grep -v amdgpu.ids $O/gwd_tile_phases.txt > $P/gwd_tile_phases.txt || true
 for f in phase_times phase_times_dense phase_times_gen1; do grep -v amdgpu.ids $O/$f.txt > $P/$f.txt || true; done
+for f in ks_phases tmpfs_write_floor hot_overflow; do [ -f $O/$f.txt ] && grep -v amdgpu.ids $O/$f.txt > $P/$f.txt || true; done

@@ -40,5 +40,8 @@ timeout 120 tools/microbench/gwd_tile_phases > $O/gwd_tile_phases.txt 2>&1
 EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=640,480,500000,8 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_dense.txt 2>&1
 EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=304,240,50000,32 NBUF=1 timeout 300 python tools/experiments/phase_times.py 0 > $O/phase_times_gen1.txt 2>&1
 EVREP_LIB_PATH=tools/variants/libevrep_timing.so NBUF=2 timeout 300 python tools/experiments/phase_times.py 0 690 > $O/phase_times.txt 2>&1
+timeout 200 python tools/experiments/ks_phases.py > $O/ks_phases.txt 2>&1
+timeout 200 python tools/experiments/tmpfs_write_floor.py > $O/tmpfs_write_floor.txt 2>&1
+timeout 200 python tools/experiments/hot_overflow.py 720 1280 200000 16 > $O/hot_overflow.txt 2>&1
 find $O -name "*.csv" | head -40
 tail -c 900 $O/bench.json
