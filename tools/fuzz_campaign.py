@@ -73,4 +73,17 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
         for b, ev in enumerate(shuf):
             if ev[:, 2].max() != ev[:, 2].min():
                 assert np.array_equal(us[b], oracle.ergo12(ev, H, W), equal_nan=True), (seed, "unsorted ergo12 vs oracle", W, H, len(ev))
+        # r05: TORE in array order on the shuffled windows (every pass, and the oracle), with a few escaped polarity values thrown in
+        for ev in shuf:
+            k = np.random.default_rng(seed + 1).random(len(ev)) < 0.01
+            ev[k, 3] = 5
+        os.environ["EVREP_BIN_KEY_SORTED"] = "1"; tk = eng.EventBatch.from_numpy(shuf, H, W); os.environ.pop("EVREP_BIN_KEY_SORTED")
+        os.environ["EVREP_BIN_CLASSIC"] = "1"; tc = eng.EventBatch.from_numpy(shuf, H, W); os.environ.pop("EVREP_BIN_CLASSIC")
+        ta, tb = tk.tore(6, frame_mode=2).cpu().numpy(), tc.tore(6, frame_mode=2).cpu().numpy()
+        assert np.array_equal(ta, tb), (seed, "unsorted tore: key-sorted vs classic", W, H)
+        e32a, e32b = tk.optimized(dtype=torch.float32).cpu().numpy(), tc.optimized(dtype=torch.float32).cpu().numpy()
+        assert np.array_equal(e32a, e32b, equal_nan=True), (seed, "unsorted / escaped ergo12 f32: key-sorted vs classic", W, H)
+        for b, ev in enumerate(shuf):
+            want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
+            assert np.allclose(ta[b], want, rtol=1e-6, atol=1e-6), (seed, "unsorted tore vs oracle", W, H, len(ev))
 print("fuzz campaign: %d cases ok in %.0f s" % (n, time.time() - t0))
