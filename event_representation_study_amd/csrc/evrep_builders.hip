@@ -1812,11 +1812,18 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 // in front of w3's, so a pixel's kept records are its ch6 records, then its ch1 records: the pixel's ch6 count is all the walk
 // needs to tell them apart.  Words of pixel px (7 px + k):
 //   0: ch0 #(p > 0) | #(p < 0) << 16      1: ch0 #(p == 0) | ch5 n << 16      2: ch3 #(p > 0) | #(p < 0) << 16
-//   3: bit 0 ch2, 1 ch4, 2 ch7, 3 ch11, 4 ch8 present, 5 ch10 present, 6 ch9 present | kept ch6 records << 16
+//   3: bit c: channel c present (ch2, ch4, ch7, ch11: occupancy; ch8, ch9, ch10: a maximum exists) | kept ch6 records << 16
 //   4, 5, 6: max (t - tmin) of ch8, ch9, ch10
 // A record of escaped polarity (p outside {-1, 0, 1}: sum p^2 may leave the integers float64 holds exactly) sends its unit to the
 // ordered paths.
 constexpr int kErgoSplitWords = 7;
+// the ERGO-12 channels of rank window `wnd`, as bits
+constexpr uint32_t ergo_chans_of(int wnd) {
+    uint32_t m = 0;
+    for (int c = 0; c < 12; ++c) if (Ergo12Table::kWin[c] == wnd) m |= 1u << c;
+    return m;
+}
+static_assert(ergo_chans_of(0) == ((1u << 0) | (1u << 9)) && ergo_chans_of(6) == ((1u << 3) | (1u << 5)), "ergo_chans_of");
 template <typename D> struct MdesIsErgo12 { static constexpr bool value = false; };
 template <> struct MdesIsErgo12<StaticDesc<Ergo12Table>> { static constexpr bool value = true; };
 static_assert(Ergo12Table::kWin[0] == 0 && Ergo12Table::kFunc[0] == EVREP_F_POLARITY && Ergo12Table::kAgg[0] == EVREP_A_VARIANCE &&
@@ -1892,7 +1899,9 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
     };
 
     // (cnt, s, s2) of every channel -> the pixel's values
-    auto finish = [&](const int(&cnt)[D::kMaxC], const double(&s)[D::kMaxC], const double(&s2)[D::kMaxC], OutT(&vals)[D::kMaxC]) {
+    // (always inlined: out of line its array arguments live in scratch -- 672 bytes per lane and a 3.5x slower launch, seen in r05c when an
+    //  unrelated change tipped the inliner)
+    auto finish = [&](const int(&cnt)[D::kMaxC], const double(&s)[D::kMaxC], const double(&s2)[D::kMaxC], OutT(&vals)[D::kMaxC]) __attribute__((always_inline)) {
         double rr[D::kMaxC];
 #pragma unroll
         for (int c = 0; c < D::kMaxC; ++c) {
@@ -1947,29 +1956,34 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
         // channel is inactive.
         MdesWindows smw;
         int32_t stmin = 0;
-        uint64_t cmask = 0ull;
+        uint64_t pmask = 0ull;   // bits [16 k, 16 k + 12), k = 0 / 1 / 2 for p < 0 / p == 0 / p > 0: bit c = channel c takes a record of that class
+                                 // (ONE captured scalar: three of them, picked by a select, kept the closure -- and with it the kernel's argument
+                                 //  structs -- in scratch: 672 bytes per lane, the launch 3.5x slower)
+        // the channels of a rank window as bits (compile-time): a record's window membership (7 bits) -> its channels (12 bits) in
+        // seven selects, its polarity class -> one of the three masks above, and every channel's hit test is one bit of their AND
+        // (r05c: twelve window tests and twelve 64-bit shifts per record until then -- the sweep is bound by instruction issue)
         auto sbegin = [&]() -> bool {
             const WindowMeta m = meta_finish(bv, off, b0, mraw);
             stmin = __builtin_amdgcn_readfirstlane(m.tmin);
             smw = mdes_windows(n_win);
             const uint32_t neg_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.neg_flags);
             const uint32_t oob_flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.oob_flags);
-            uint64_t cm = 0ull;
+            uint32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
             for (int c = 0; c < D::kMaxC; ++c) {
                 const int wi = D::win(P, c), f = D::func(P, c);
-                uint64_t cls = 7ull;
+                uint32_t cls = 7u;   // bit k: the channel takes class k (0: p < 0, 1: p == 0, 2: p > 0)
                 int field = 0;
-                if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { cls = 4ull; field = 1; }
+                if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { cls = 4u; field = 1; }
                 if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
                     const bool has_neg = (neg_flags >> wi) & 1u;   // operations.py:59-61,78-80
-                    cls = has_neg ? 1ull : 2ull;
+                    cls = has_neg ? 1u : 2u;
                     field = has_neg ? 2 : 3;
                 }
-                if (n_win <= 0 || ((oob_flags >> (7 * field + wi)) & 1u)) cls = 0ull;
-                cm |= cls << (3 * c);
+                if (n_win <= 0 || ((oob_flags >> (7 * field + wi)) & 1u)) cls = 0u;
+                a0 |= (cls & 1u) << c; a1 |= ((cls >> 1) & 1u) << c; a2 |= ((cls >> 2) & 1u) << c;
             }
-            cmask = cm;
+            pmask = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32);
             return true;
         };
         auto sf = [&](uint32_t px, const Rec8 &q, uint2 &e, const uint2 &) -> bool {
@@ -1979,16 +1993,22 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
             const int p = (int)p2 - 1;
             const uint32_t tt = (uint32_t)((int64_t)(int32_t)q.x - (int64_t)stmin);   // 0 <= t - tmin < 2^32
             uint32_t *wd = words + px * (uint32_t)kErgoSplitWords;
-            const uint32_t inw = mdes_membership(smw, rank);
-            const uint64_t cm = cmask >> p2;
-            auto hit = [&](int c) -> bool { return ((inw >> D::win(P, c)) & 1u) && ((cm >> (3 * c)) & 1ull); };
+            // the record's windows -> its channels: w0 holds every rank, w1..w3 are consecutive thirds [lo1, hi1) [hi1, hi2) [hi2, hi3), w4..w6
+            // run from their start to the window's end (mdes_windows) -- six compares instead of seven range tests and seven selects
+            uint32_t chans = ergo_chans_of(0);
+            chans |= rank < smw.hi[1] ? ergo_chans_of(1) : (rank < smw.hi[2] ? ergo_chans_of(2) : (rank < smw.hi[3] ? ergo_chans_of(3) : 0u));
+            chans |= rank >= smw.lo[4] ? ergo_chans_of(4) : 0u;
+            chans |= rank >= smw.lo[5] ? ergo_chans_of(5) : 0u;
+            chans |= rank >= smw.lo[6] ? ergo_chans_of(6) : 0u;
+            const uint32_t hits = chans & (uint32_t)(pmask >> (16u * p2));
+            auto hit = [&](int c) -> bool { return (hits >> c) & 1u; };
             const uint32_t pinc = p > 0 ? 1u : 0x10000u;
             if (hit(0)) { if (p != 0) atomicAdd(wd + 0, pinc); else atomicAdd(wd + 1, 1u); }
             if (hit(3) && p != 0) atomicAdd(wd + 2, pinc);
             if (hit(5)) atomicAdd(wd + 1, 0x10000u);
             const bool h8 = hit(8), h9 = hit(9), h10 = hit(10), h6 = hit(6), h1 = hit(1);
-            const uint32_t bits = (hit(2) ? 1u : 0u) | (hit(4) ? 2u : 0u) | (hit(7) ? 4u : 0u) | (hit(11) ? 8u : 0u) |
-                                  (h8 ? 16u : 0u) | (h10 ? 32u : 0u) | (h9 ? 64u : 0u);
+            // word 3, low half: presence flags by CHANNEL index (ch2, ch4, ch7, ch11: occupancy; ch8, ch9, ch10: a maximum exists)
+            const uint32_t bits = hits & ((1u << 2) | (1u << 4) | (1u << 7) | (1u << 11) | (1u << 8) | (1u << 9) | (1u << 10));
             if (bits) atomicOr(wd + 3, bits);
             if (h6) atomicAdd(wd + 3, 0x10000u);
             if (h8) atomicMax(wd + 4, tt);
@@ -2176,8 +2196,8 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
                     cn[0] = np0 + nn0 + nz0; s[0] = (double)(np0 - nn0); s2[0] = (double)(np0 + nn0);
                     s[3] = (double)((int)(a2 & 0xffffu) - (int)(a2 >> 16));
                     cn[5] = (int)(a1 >> 16);
-                    cn[2] = (int)(a3 & 1u); cn[4] = (int)((a3 >> 1) & 1u); cn[7] = (int)((a3 >> 2) & 1u); cn[11] = (int)((a3 >> 3) & 1u);
-                    cn[8] = (int)((a3 >> 4) & 1u); cn[10] = (int)((a3 >> 5) & 1u); cn[9] = (int)((a3 >> 6) & 1u);
+                    cn[2] = (int)((a3 >> 2) & 1u); cn[4] = (int)((a3 >> 4) & 1u); cn[7] = (int)((a3 >> 7) & 1u); cn[11] = (int)((a3 >> 11) & 1u);
+                    cn[8] = (int)((a3 >> 8) & 1u); cn[10] = (int)((a3 >> 10) & 1u); cn[9] = (int)((a3 >> 9) & 1u);
                     s[8] = (double)m8 / interval; s[9] = (double)m9 / interval; s[10] = (double)m10 / interval;
                     cn[6] = (int)(mid - st); s[6] = acc6;
                     cn[1] = (int)(en - mid); s[1] = acc1; s2[1] = sq1;
