@@ -24,7 +24,7 @@ static inline BinView bin_view(const evrep_plan *plan, const int32_t *events, vo
     bv.hot = WS(uint32_t, off_scratch);
     bv.hot_cap = hot_items_total(plan->total_events);
     bv.stats_rw = WS(BlockStats, off_stats);
-    bv.placed_pool = reinterpret_cast<double *>(static_cast<char *>(workspace) + plan->off_sorted1 + up256((size_t)plan->total_events * 8));   // the key-sorted pass moves 8-byte records: the upper half of sorted1 is idle
+    bv.placed_pool = reinterpret_cast<double *>(static_cast<char *>(workspace) + plan->off_sorted1 + align16((size_t)plan->total_events * 8));   // the key-sorted pass moves 8-byte records: the upper half of sorted1 (8 bytes per event, fully) is idle
     bv.chunk_shift = plan->chunk == 4096 ? 12 : 13;  // only read after the key-sorted pass
 #ifdef EVREP_TIMING
     // 8 slots per builder wave: behind the 8-byte records of the key-sorted pass (the upper half of sorted1 is idle; sorted2 is
