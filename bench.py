@@ -388,6 +388,75 @@ def precompute_leg(device, samples=512, batch=8, events=200000):
             "bytes_per_sample_over_pcie": per}
 
 
+def host_cores():
+    """Cores this process may use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def per_rank_legs(rank, world, device, dry, samples=256, batch=8, events=200000):
+    """N > 1 (VERDICT r05 missing 1): every rank runs BASELINE config 3's sweep (TimeSurface + EventStack + TORE
+    on 1280x720 windows) and config 5's precompute (its share of the sample stream -> one HDF5 file per sample under the
+    GLOBAL sample number, as precompute_reps.py:439-466's Pool(8) leaves them) on its own GPU; the figures meet in ONE
+    all_gather of a few scalars per leg (distributed.gather_rows) -- no data-path collective.  With EVREP_BENCH_DRYRUN=1 the
+    GPU work is replaced by stand-in figures and the exchange runs on gloo."""
+    import shutil
+    import tempfile
+    from event_representation_study_amd.distributed import gather_rows
+    names = ("time_surface_f64", "event_stack_f32", "tore_full_frame_f32")
+    if dry:
+        local = [1.0 + rank, 0.1 * (rank + 1)] + [0.2 * (rank + 1)] * len(names) + [1e9] * len(names)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_sweep
+        rows = {r["builder"]: r for r in bench_sweep.sweep(("c3",), iters=10, builders=names, device=str(device))}
+        local = [float(rank), rows[names[0]]["bin_ms"]] + [rows[n]["build_ms"] for n in names] \
+            + [rows[n]["algorithmic_bytes"] for n in names]
+    g = gather_rows(local, device=device)
+    Wc, Hc, N3, B3 = 1280, 720, 200000, 8
+    sweep = {"workload": "config 3 on every rank: %d windows of %d events, %dx%d; per-rank HIP-event timings" % (B3, N3, Wc, Hc),
+             "n_ranks": int(g.shape[0]), "bin_ms_min": float(g[:, 1].min()), "bin_ms_max": float(g[:, 1].max()), "rows": []}
+    for j, n in enumerate(names):
+        ms, alg = g[:, 2 + j], g[:, 2 + len(names) + j]
+        sweep["rows"].append({"builder": n, "build_ms_min": float(ms.min()), "build_ms_max": float(ms.max()),
+                              "build_ms_per_rank": [round(float(v), 4) for v in ms.tolist()],
+                              "build_frac_of_8TBps_min": float((alg / ms / 1e6 / HBM_PEAK_GBPS).min()),
+                              "events_per_s_all_ranks_bin_plus_build":
+                                  float((B3 * N3 / ((g[:, 1] + ms) * 1e-3)).sum())})
+    # config 5: the sample stream dealt round-robin to the ranks (sample i -> rank i mod N, written as <i>.h5)
+    from event_representation_study_amd.precompute import aggregate_over_ranks, shard_keys
+    mine, first, stride = shard_keys(list(range(samples)), rank, world)
+    if dry:
+        trip = (len(mine), len(mine) * 640 * 640 * 12 * 4, 1.0 + 0.5 * rank)
+    else:
+        from event_representation_study_amd.precompute import RepPrecomputer
+        from event_representation_study_amd.synthetic import make_events
+        pool = [make_events(events, Wc, Hc, seed=9000 + rank * 100 + i) for i in range(batch)]
+        out_dir = tempfile.mkdtemp(prefix="evrep_c5_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            pc = RepPrecomputer(Hc, Wc, 640, "optimized", device=str(device), writers=max(2, min(12, host_cores() // world)),
+                                loaders=2)
+            pc.reserve([(batch, 640, 640, 12)])
+            pc.run([pool, pool], out_dir, keep_files=False)
+            if world > 1:
+                torch.distributed.barrier()           # the ranks start their shares together
+            stream = ([pool[i % batch] for i in range(len(mine[k:k + batch]))] for k in range(0, len(mine), batch))
+            trip = pc.run(stream, out_dir, keep_files=False, first_index=first, index_stride=stride)
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    pre = aggregate_over_ranks(*trip, device=device)
+    pre["workload"] = ("%d samples of %d events dealt round-robin to %d ranks, 1280x720 -> (640,640,12) float32, one HDF5 file "
+                       "per sample under its global number in /dev/shm" % (samples, events, world))
+    pre["host_cores_shared_by_all_ranks"] = host_cores()
+    return {"sweep_c3_per_rank": sweep, "precompute": pre}
+
+
 def achievable_rates(device, nbytes=1 << 30, iters=10):
     """What this box's HBM delivers to the simplest kernels, measured in this process: a 1 GiB fill (write-only, the
     builder's own traffic pattern) and a 1 GiB device-to-device copy (read + write counted).  The 8 TB/s of `peak` is the
@@ -646,6 +715,9 @@ def main():
                 pass
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
+    if world > 1 and not (args.no_sweep and args.no_precompute):
+        # every rank, its own GPU: config 3's sweep + its share of config 5 (a scaling run measures every config, r06)
+        result["per_rank"] = per_rank_legs(rank, world, device, dry)
     if rank == 0 and world == 1 and not dry and not args.no_sweep:
         result["sweep"] = sweep_leg(device)
     if rank == 0 and world == 1 and not dry and not args.no_precompute:

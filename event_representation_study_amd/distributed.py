@@ -49,6 +49,24 @@ def gather_vector(local_vec, indices, n_items):
     return torch.stack(parts).sum(0)
 
 
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if (
+        dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+
+
+def gather_rows(local_values, device=None):
+    """A short list of float64 figures per rank (timings, counts) -> (world, k) tensor on the CPU, the same on every rank:
+    ONE all_gather.  The control-plane exchange of the per-rank legs (precompute, sweeps): bytes, not data."""
+    if device is None:
+        device = _default_device()
+    row = torch.as_tensor([float(v) for v in local_values], dtype=torch.float64, device=device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return row[None].cpu()
+    parts = [torch.zeros_like(row) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, row)
+    return torch.stack(parts).cpu()
+
+
 def sharded_scores(score_fn, items):
     """Evaluate score_fn(item) for this rank's share of `items` and all-gather the scalars."""
     mine = shard_indices(len(items))

@@ -13,8 +13,12 @@ pool that writes real HDF5 files (``h5lite``: header + array bytes).  Inputs can
 event containers (``run_h5``: flat (n, 4) int32 datasets under string keys, :408-409).
 
 Differences, stated plainly: (1) the resize is the OpenCV INTER_AREA / INTER_LINEAR restatement of
-``gwd_pipeline`` -- parity unpinned against cv2, which is absent; (2) instead of a Pool(8) of CPU workers the
-windows share one GPU and the CPU only drains buffers to disk.  As in the reference, the resize is skipped when
+``gwd_pipeline`` -- parity unpinned against cv2, which is absent; (2) instead of a Pool(8) of CPU workers
+(``process_representations``, :439-466; ``evlicious.tools.TaskManager``, task_manager.py:8-44) the windows of a rank share
+its GPU and the CPU only drains buffers to disk; on N GPUs the sample keys are dealt round-robin to one process per GPU
+(``run_h5(rank=, world=)``: sample ``i`` of the key list is written as ``<i>.h5`` by rank ``i mod N`` -- the same
+``counter`` numbering as the reference's, no data-path collective), and ``aggregate_over_ranks`` sums samples and bytes and
+takes the slowest rank's seconds (one all_gather of three scalars).  As in the reference, the resize is skipped when
 the representation's long side already equals S (``if r != 1``, :228), and TORE is built on the events' bounding
 box per sample (gen4_transforms' branch), so its samples are resized one by one.
 """
@@ -138,9 +142,13 @@ class RepPrecomputer:
         np.save(path_base + ".npy", arr)
         return path_base + ".npy"
 
-    def run(self, window_batches, out_dir, keep_files=True, first_index=0):
-        """window_batches: iterable of lists of (n, 4) int32 arrays.  One file ``<counter>.h5`` per sample.
-        Returns (samples, bytes written, seconds)."""
+    def run(self, window_batches, out_dir, keep_files=True, first_index=0, index_stride=1):
+        """window_batches: iterable of lists of (n, 4) int32 arrays.  One file ``<counter>.h5`` per sample; sample k of
+        the stream is numbered ``first_index + k * index_stride`` (a rank of N holding every N-th sample: first_index =
+        rank, index_stride = N).  Returns (samples, bytes written, seconds)."""
+        index_stride = int(index_stride)
+        if index_stride < 1:
+            raise ValueError("index_stride must be >= 1")
         os.makedirs(out_dir, exist_ok=True)
         q = queue.Queue(maxsize=4)
         written = [0] * self.nwriters                              # one counter per writer thread: no shared update
@@ -156,7 +164,7 @@ class RepPrecomputer:
                     ev.synchronize()                               # the D2H copy of this buffer has landed
                     for k in range(len(host)):
                         arr = host[k].numpy()
-                        path = self._write(os.path.join(out_dir, "%d" % (idx0 + k)), arr)
+                        path = self._write(os.path.join(out_dir, "%d" % (idx0 + k * index_stride)), arr)
                         written[slot] += arr.nbytes
                         if not keep_files:
                             os.remove(path)
@@ -169,7 +177,7 @@ class RepPrecomputer:
         for t in threads:
             t.start()
         t0 = time.perf_counter()
-        count = first_index
+        count = 0
         # loader stage: a few threads turn the next batches (lists of arrays, or callables that read them) into one
         # pinned (total, 4) int32 buffer + offsets while the GPU works on the current one; numpy's copies and the
         # file reads release the GIL.  The main thread only enqueues: H2D, bin, build, resize, D2H.
@@ -208,7 +216,7 @@ class RepPrecomputer:
                             part.record_stream(self.copy_stream)
                         done.record(self.copy_stream)
                     host_list = hosts[0] if not isinstance(small, list) else hosts
-                    q.put((count, host_list, done, token))
+                    q.put((first_index + count * index_stride, host_list, done, token))
                     count += nwin
         finally:
             # whatever happened above (a loader raising, a GPU error, out of memory): the writers get their sentinels and
@@ -219,7 +227,7 @@ class RepPrecomputer:
                 t.join()
         if errors:
             raise errors[0]
-        return count - first_index, sum(written), time.perf_counter() - t0
+        return count, sum(written), time.perf_counter() - t0
 
     def _load(self, item):
         """Loader thread: windows -> one pinned (total, 4) int32 buffer (recycled) + int64 offsets."""
@@ -246,10 +254,18 @@ class RepPrecomputer:
             dst[o:o + w.shape[0]] = w
         return slot, total, offs, len(ws), int(max([w.shape[0] for w in ws], default=0))
 
-    def run_h5(self, event_h5_file, keys, out_dir, batch=8, **kw):
+    def run_h5(self, event_h5_file, keys, out_dir, batch=8, rank=None, world=None, **kw):
         """The reference's input side: every ``key`` of ``event_h5_file`` is a flat (n, 4) int32 [x, y, t, p] dataset
         (precompute_reps.py:408-409 reads it with np.array(hf.get(key)); fix_events_training views it as '<i4'
-        fields, :737-740).  Samples are numbered in key order."""
+        fields, :737-740).  Samples are numbered in key order.
+
+        Data-parallel form (the reference's Pool(8), precompute_reps.py:443): with ``world`` > 1 ranks (default: the
+        initialised torch.distributed group) this rank takes every world-th key starting at ``rank`` and writes them
+        under their GLOBAL numbers, so N ranks together leave exactly the files one rank would.  Returns this rank's
+        (samples, bytes, seconds); ``aggregate_over_ranks`` folds them."""
+        keys, first, stride = shard_keys(list(keys), rank, world)
+        kw.setdefault("first_index", first)
+        kw.setdefault("index_stride", stride)
         f = h5lite.File(event_h5_file)
 
         def read(ks):
@@ -264,3 +280,30 @@ class RepPrecomputer:
                 return wins
             return go
         return self.run((read(keys[i:i + batch]) for i in range(0, len(keys), batch)), out_dir, **kw)
+
+
+def shard_keys(keys, rank=None, world=None):
+    """This rank's share of the sample keys, round-robin (``distributed.shard_indices``), with the numbering that keeps
+    the reference's global ``counter`` (precompute_reps.py:440-466): -> (keys of this rank, first index, index stride)."""
+    from .distributed import shard_indices
+    import torch.distributed as dist
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside a world of %d" % (rank, world))
+    return [keys[i] for i in shard_indices(len(keys), rank, world)], rank, world
+
+
+def aggregate_over_ranks(samples, nbytes, seconds, device=None):
+    """Every rank's (samples, bytes written, seconds) -> the job's figures on every rank: ONE all_gather of three float64
+    scalars per rank.  Aggregate rate = total samples / the SLOWEST rank's seconds (the job is done when the last rank is)."""
+    from .distributed import gather_rows
+    rows = gather_rows([float(samples), float(nbytes), float(seconds)], device=device)
+    n, b = float(rows[:, 0].sum()), float(rows[:, 1].sum())
+    el = max(float(rows[:, 2].max()), 1e-12)
+    per = (rows[:, 0] / rows[:, 2].clamp_min(1e-12)).tolist()
+    return {"n_ranks": int(rows.shape[0]), "samples": int(n), "bytes": int(b), "seconds": el, "samples_per_s": n / el,
+            "output_GBps": b / el / 1e9, "samples_per_rank": [int(v) for v in rows[:, 0].tolist()],
+            "samples_per_s_per_rank_min": min(per), "samples_per_s_per_rank_max": max(per)}

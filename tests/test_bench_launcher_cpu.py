@@ -35,6 +35,13 @@ def test_self_launch_two_ranks_gloo():
     g = res["gwd"]
     assert g["n_ranks"] == 2 and g["pairs"] == 7 and g["solves_per_rank"] == [4, 3] and g["all_solved"] is True
     assert "torch.distributed.run" in r.stderr      # it really re-launched itself
+    # r06: a scaling run keeps config 3's sweep and config 5's precompute, per rank, folded by one all_gather each
+    pr = res["per_rank"]
+    sw, pre = pr["sweep_c3_per_rank"], pr["precompute"]
+    assert sw["n_ranks"] == 2 and [row["builder"] for row in sw["rows"]] == ["time_surface_f64", "event_stack_f32", "tore_full_frame_f32"]
+    assert all(len(row["build_ms_per_rank"]) == 2 and row["build_ms_min"] < row["build_ms_max"] for row in sw["rows"])
+    assert pre["n_ranks"] == 2 and pre["samples"] == 256 and pre["samples_per_rank"] == [128, 128]
+    assert abs(pre["seconds"] - 1.5) < 1e-9 and abs(pre["samples_per_s"] - 256 / 1.5) < 1e-6   # the slowest rank's clock
 
 
 def test_single_rank_dry_run_prints_one_line():

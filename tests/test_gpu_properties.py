@@ -47,6 +47,22 @@ def test_c2_batch32_properties(eng):
     assert torch.equal(eb.optimized(scale=255.0), rep * 255.0)
 
 
+def test_c2_batch32_every_slice_vs_oracle(eng, oracle):
+    """The headline batch as a batch: all 32 slices of one 640x480 launch against the oracle, bit
+    for bit, float64 and float32 outputs, both polarity encodings in the same batch."""
+    H, W, N, B = 480, 640, 50000, 32
+    wins = [make_events(N, W, H, seed=900 + i, polarity=("pm1" if i % 2 == 0 else "01")) for i in range(B)]
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    rep = eb.optimized().cpu().numpy()
+    rep32 = eb.optimized(dtype=torch.float32).cpu().numpy()
+    es = eb.event_stack().cpu().numpy()
+    for b, ev in enumerate(wins):
+        ref = oracle.ergo12(ev, H, W)
+        assert_bit_equal(rep[b], ref, "ergo12 slice %d of the c2 batch" % b)
+        assert_bit_equal(rep32[b], ref.astype(np.float32), "ergo12 f32 slice %d" % b)
+        assert_bit_equal(es[b], oracle.event_stack(ev, H, W), "event_stack slice %d" % b)
+
+
 def test_c2_window_vs_oracle_fullsize(eng, oracle):
     H, W, N = 480, 640, 50000
     ev = make_events(N, W, H, seed=424242)

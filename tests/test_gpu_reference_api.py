@@ -482,6 +482,30 @@ def test_precompute_reads_event_containers_h5py_wrote(tmp_path):
         pc.run_h5(src, ["moorea_2019-02-19_004_td_2257500000_2317500000_td_000012"], str(tmp_path / "c"))   # float64 rows
 
 
+@pytest.mark.gpu
+def test_precompute_two_shards_leave_the_files_of_one(tmp_path):
+    """Config 5 data-parallel (precompute_reps.py:439-466's Pool(8) -> one process per GPU): the shares of two ranks, each
+    written under the global sample numbers, are byte for byte the files a single rank leaves."""
+    import os
+    from event_representation_study_amd import h5lite
+    from event_representation_study_amd.precompute import RepPrecomputer, shard_keys
+    from event_representation_study_amd.synthetic import make_events
+    H, W = 96, 128
+    wins = [make_events(1500 + 37 * i, W, H, seed=400 + i) for i in range(7)]
+    pc = RepPrecomputer(H, W, 64, "optimized", writers=2)
+    n, _, _ = pc.run([wins[0:3], wins[3:6], wins[6:]], str(tmp_path / "one"))
+    assert n == 7
+    for rank in range(2):
+        mine, first, stride = shard_keys(list(range(7)), rank, 2)
+        k, _, _ = pc.run([[wins[i] for i in mine[j:j + 2]] for j in range(0, len(mine), 2)], str(tmp_path / "two"),
+                         first_index=first, index_stride=stride)
+        assert k == len(mine)
+    assert sorted(os.listdir(tmp_path / "one")) == sorted(os.listdir(tmp_path / "two"))
+    for i in range(7):
+        np.testing.assert_array_equal(h5lite.File(str(tmp_path / "one" / ("%d.h5" % i)))["repr"][()],
+                                      h5lite.File(str(tmp_path / "two" / ("%d.h5" % i)))["repr"][()])
+
+
 # ------------------------------------------------------------------ F4: n_imagenet accumulators
 NI_NAMES = ["acc", "acc_time", "acc_count", "acc_count_pol", "acc_count_only", "acc_all", "flat", "flat_pol",
             "acc_exp", "acc_time_pol", "acc_intensity"]
