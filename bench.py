@@ -76,6 +76,8 @@ def parse():
                          "statistics hold the measured steps only (all_us[0] of the probe already predicts it)")
     ap.add_argument("--resident-batches", type=int, default=12,
                     help="distinct resident batches the timed loop rotates over (12 x 25.6 MB of events > the 256 MB Infinity Cache)")
+    ap.add_argument("--no-pipelined-value", action="store_true",
+                    help="skip the second, labelled figure `pipelined` (bin k+1 beside build k, >= 200 steps after the timed region)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the binning pass of step k+1 with the builder of step k on a second HIP stream "
                          "(two resident batches alternate); default: bin + build back to back on one stream")
@@ -713,6 +715,32 @@ def main():
                         % trj[key].get("source")
             except Exception:
                 pass
+    if not dry and pipe is None and world == 1 and not args.no_pipelined_value:
+        # the overlapped counterpart of `value`: the same steps over the same resident batches with
+        # the binning pass of step k+1 on a second HIP stream beside the builder of step k.  A second, LABELLED figure:
+        # `value` stays the back-to-back form on one stream.
+        from event_representation_study_amd.engine import BinBuildPipeline as _BBP
+        p2 = _BBP(device)
+        ksteps = max(200, args.steps)
+
+        def pstep(k):
+            p2.submit(batches[k % nbatch], lambda b: b.optimized(scale=1.0, dtype=dtype, out=outs[0]))
+        for k in range(24):
+            pstep(k)
+        p2.drain()
+        sync()
+        t1 = time.perf_counter()
+        for k in range(ksteps):
+            pstep(k)
+        p2.drain()
+        sync()
+        pel = time.perf_counter() - t1
+        result["pipelined"] = {"what": "bin of step k+1 on a second HIP stream beside the build of step k (engine.BinBuildPipeline), "
+                                       "same resident batches and output tensor; NOT `value`",
+                               "steps": ksteps, "ms_per_step": pel / ksteps * 1e3, "events_per_s": B * N * ksteps / pel,
+                               "algorithmic_GBps_whole_step": alg_bytes * ksteps / pel / 1e9,
+                               "whole_step_frac_of_8TBps": alg_bytes * ksteps / pel / 1e9 / HBM_PEAK_GBPS,
+                               "over_value": (B * N * ksteps / pel) / result["value"]}
     if not args.no_gwd:   # while the GPU is still warm: the CPU baseline below idles it for ~20 s
         result["gwd"] = gwd_leg(rank, world, args.gwd_pairs, device, dry)
     if world > 1 and not (args.no_sweep and args.no_precompute):

@@ -41,11 +41,42 @@ def _obj(src, tag=""):
     return os.path.join(OBJDIR, os.path.splitext(src)[0] + tag + ".o")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _flag_hash(extra_flags=()):
+    import hashlib
+    return hashlib.sha1(" ".join(FLAGS + list(extra_flags)).encode()).hexdigest()[:16]
+
+
+def _stamp(lib):
+    return lib + ".flags"
+
+
+def needs_build(extra_flags=(), lib=LIB):
+    """Out of date if missing, older than a source, or built with OTHER flags (a library left behind by an experiment
+    build with -D switches is not silently kept: its flag hash is recorded beside it)."""
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    try:
+        if open(_stamp(lib)).read().strip() != _flag_hash(extra_flags):
+            return True
+    except OSError:
+        pass        # a library that travelled without its stamp (the GPU box gets the prebuilt .so): trust the mtimes
+    t = os.path.getmtime(lib)
     return any(_mtime(d) > t for src in SOURCES for d in _unit_deps(src))
+
+
+class _BuildLock:
+    """One builder at a time per checkout (pytest workers, one process per GPU): an exclusive flock on _obj/.lock."""
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OBJDIR, exist_ok=True)
+        self.f = open(os.path.join(OBJDIR, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
 
 
 def build(force=False, verbose=True, extra_flags=(), lib=LIB):
@@ -53,25 +84,48 @@ def build(force=False, verbose=True, extra_flags=(), lib=LIB):
     set of extra flags, so experiment builds (tools/variants) do not disturb the library's own objects."""
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
-    if lib == LIB and not force and not needs_build():
-        return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
-    tag = ("-" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]) if extra_flags else ""
-    todo = []
-    for src in SOURCES:
-        o = _obj(src, tag)
-        if force or not os.path.exists(o) or any(_mtime(d) > os.path.getmtime(o) for d in _unit_deps(src)):
-            todo.append([hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c",
-                                                                  os.path.join(CSRC, src), "-o", o])
+    extra_flags = list(extra_flags)
+    if not force and not needs_build(extra_flags, lib):
+        return lib
+    with _BuildLock():
+        if not force and not needs_build(extra_flags, lib):      # another process built it while this one waited
+            return lib
+        tag = ("-" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]) if extra_flags else ""
+        todo = []
+        for src in SOURCES:
+            o = _obj(src, tag)
+            if force or not os.path.exists(o) or any(_mtime(d) > os.path.getmtime(o) for d in _unit_deps(src)):
+                todo.append((o, [hipcc()] + FLAGS + extra_flags + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c",
+                                                                   os.path.join(CSRC, src)]))
 
-    def run(cmd):
-        if verbose:
-            print("[evrep build]", " ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        def run(cmd):
+            if verbose:
+                print("[evrep build]", " ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        list(ex.map(run, todo))
-    run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [_obj(src, tag) for src in SOURCES])
+        def compile_one(job):
+            # into a temporary name, renamed when hipcc succeeded: an interrupted compile never leaves a partial object
+            # that looks up to date
+            o, cmd = job
+            tmp = "%s.tmp%d" % (o, os.getpid())
+            try:
+                run(cmd + ["-o", tmp])
+                os.replace(tmp, o)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+
+        with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+            list(ex.map(compile_one, todo))
+        tmp = "%s.tmp%d" % (lib, os.getpid())
+        try:
+            run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [_obj(src, tag) for src in SOURCES])
+            os.replace(tmp, lib)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        with open(_stamp(lib), "w") as f:
+            f.write(_flag_hash(extra_flags) + "\n")
     return lib
 
 

@@ -1594,6 +1594,7 @@ __device__ inline void emit_warm(const UnitRecs &u, uint32_t nrec, Digest digest
     constexpr int V = 16 / (int)sizeof(OutT);
     for (uint32_t j = (uint32_t)lane; j < nrec; j += kWave) { Rec *q = w.big_at(j); *q = digest(*q); }
     wave_phase();
+    w.mark(2);
     const uint32_t *cnt = reinterpret_cast<const uint32_t *>(w.segs);
     const bool vec = (C % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;   // wave-uniform
     w.pace();
@@ -2896,6 +2897,9 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
     run_units<HOT>(bv, [&](int uid, int part) {
         WaveLds<double, HOT> w(smem, bins, (uc.span + uc.merge) * kChunkPx, uc.stage);
         w.arm(uc.hold);
+#ifdef EVREP_TIMING
+        w.dbg = bv.dbg + 8 * (size_t)uid;
+#endif
         // the window's first / last timestamp: two dependent load levels (extent, then events) issued BEFORE the unit's own two
         // levels (run tables, then records), not behind them (r03: they were a third and fourth step of the wave's latency chain)
         int chunk0;
@@ -2905,7 +2909,9 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
         int tz0 = 0, tz1 = 0;
         if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
         ChunkGeom g;
+        w.mark(6);
         const UnitRecs u = unit_front(bv, off, H, W, nchunk, uc, w, g, uid, part);
+        w.mark(0);
         if (u.deferred) return;
         double *dst = out + (((size_t)g.b * H + g.row) * (size_t)W + g.c0) * bins;
         double t0 = 0.0, den = 1.0;
@@ -2936,16 +2942,27 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
             const double bp = tw ? (double)(bins - 1) * tw[r.y] : bin_pos(r.z);
             return make_int4(r.x, __double2loint(bp), __double2hiint(bp), r.w);
         };
+        // The pixel's `bins` sums live in the lane's own row of an LDS scratch behind the wave's carve (r06), not in a register
+        // array: a register array indexed by a per-lane bin is a select chain -- one float64 add, a compare and four v_cndmask per
+        // BIN and step, ~56 of the ~75 VALU instructions of a step, in walks that are divergent (the wave runs as many steps as its
+        // longest pixel holds records, twice) and in launches that the counters show bound by VALU issue (SIMDs 0.6-0.8 busy on
+        // clustered and dense windows, profiles/r06).  The running sum of the CURRENT bin stays in registers -- a pixel's records
+        // are time-ordered, so its bin changes at most `bins` times per pass -- and moves to / from the row only when the bin
+        // changes (exact: no rounding happens on the way), so every (pixel, bin) sum still adds its terms in the reference's order:
+        // pass 0's in array order, then pass 1's.
+        double *scr = reinterpret_cast<double *>(smem + chunk_lds_bytes(bins, 8, (uc.span + uc.merge) * kChunkPx, uc.stage)) + (size_t)threadIdx.x * bins;
         auto reduce = [&](uint32_t jb, uint32_t je, auto get, double(&vals)[CM]) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) vals[c] = 0.0;
+            for (int c = 0; c < CM; ++c) if (c < bins) scr[c] = 0.0;
             // two np.add.at passes: lower bin for every event, then upper bin for every event
             for (int pass = 0; pass < (mode == 2 ? 1 : 2); ++pass) {
+                int cur = -1;
+                double acc = 0.0;
                 for (uint32_t j = jb; j < je; ++j) {
-                    const Rec e = get(j);
-                    double p = (double)e.w;
-                    if (mode == 1 && e.w == 0) p = -1.0;
-                    const double bpos = __hiloint2double(e.z, e.y);
+                    const Rec ec = get(j);
+                    double p = (double)ec.w;
+                    if (mode == 1 && ec.w == 0) p = -1.0;
+                    const double bpos = __hiloint2double(ec.z, ec.y);
                     // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero
                     // (astype("int32"), utils.py:67), so an event up to one bin before t0_us still lands in bin 0
                     if (!(bpos > (mode == 2 ? -1.0 : -0.0) && bpos < 1.0e9) && !(bpos == 0.0)) continue;
@@ -2957,11 +2974,18 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
                         else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
                         else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
                         const double wp = wgt * p;
-#pragma unroll
-                        for (int c = 0; c < CM; ++c) if (c == blim) vals[c] = vals[c] + wp;
+                        if (blim != cur) {
+                            if (cur >= 0) scr[cur] = acc;
+                            acc = scr[blim];
+                            cur = blim;
+                        }
+                        acc = acc + wp;
                     }
                 }
+                if (cur >= 0) scr[cur] = acc;
             }
+#pragma unroll
+            for (int c = 0; c < CM; ++c) vals[c] = c < bins ? scr[c] : 0.0;
             if (scale != 1.0) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) vals[c] = vals[c] * scale;
@@ -2969,6 +2993,261 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
         };
         emit_chunk<double, CM, HOT>(u, digest, g.row * W + g.c0, g.npix, bins, dst, w, (const double *)nullptr, reduce);
     });
+}
+
+// --------------------------------------------------------------------------------------------
+// A2 (r06), after the key-sorted pass: the voxel grid as a STREAM -- no order by pixel at all.
+// What the reference fixes is the order of the additions into every (pixel, bin) CELL: pass 0's terms (the lower bin of every
+// event) in array order, then pass 1's (the upper bin).  The records of a unit arrive in array order already (the block runs are
+// visited in block order and a run is in arrival order), so the unit's cells -- a (pixels x bins) float64 tile in LDS, in output
+// layout -- are simply bumped in sweep order, 64 records at a time, one sweep per pass.  The only thing to respect inside a
+// batch of 64 is two lanes meeting in one pixel: a leader election per pixel (ds_min of the lane id on a tag word; the lowest
+// pending lane of a pixel goes first, as the array order demands) lets one lane per pixel add per round -- one round for almost
+// every batch of a sparse or uniformly dense window, as many as a pixel holds records of the batch on a hot one.  Against the
+// ordered paths (count sweep, scan, placement with an 8-bit ballot match per batch, digest, divergent walks with one lane per
+// pixel, part tiles): no counting sort, no segment list, no walk, no spill slot, and the tile leaves the wave as one coalesced
+// burst.  Units of up to 64 * RB records keep their digested records in registers between the two sweeps; larger ones are read
+// and digested twice (8 bytes per record from L2).
+// LDS: cells [npixa * bins] float64 | tag [npixa] | head [64 * RB] | srcs [64] | touched [npixa] bytes
+__host__ __device__ inline size_t voxel_stream_lds_bytes(int bins, int npixa, int rb) {
+    return align16((size_t)npixa * bins * 8) + (size_t)npixa * 4 + (size_t)(64 * rb + 64) * 4 + align16((size_t)npixa);
+}
+#ifndef EVREP_VS_WAVES
+#define EVREP_VS_WAVES 6
+#endif
+template <int RB>
+__global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+                                                int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
+                                                const int64_t *__restrict__ t_range, const double *__restrict__ tnorm,
+                                                double *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    int chunk, nch;
+    const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+    const int b = g.b;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    int tz0 = 0, tz1 = 0;
+    if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
+    const int NK = H * nchunk, klo = g.row * nchunk + chunk;
+    uint32_t a = 0, khi_v = 0;
+    if (lane < bv.nblk) {
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+        a = tb[klo];
+        khi_v = tb[klo + nch];
+    }
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    double *acc = reinterpret_cast<double *>(smem);
+    uint32_t *tag = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * bins * 8));
+    uint32_t *head = tag + npixa;
+    uint32_t *srcs = head + 64 * RB;
+    unsigned char *touched = reinterpret_cast<unsigned char *>(srcs + 64);
+    const int ncell = g.npix * bins;
+    {   // zero cells, free tags, nothing touched (overlaps the table loads)
+        uint4 *z = reinterpret_cast<uint4 *>(acc);
+        for (int v = lane; v * 2 < ncell; v += kWave) z[v] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *t4 = reinterpret_cast<uint4 *>(tag);
+        for (int v = lane; v * 4 < npixa; v += kWave) t4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (scale != 1.0) { uint4 *c4 = reinterpret_cast<uint4 *>(touched); for (int v = lane; v * 16 < npixa; v += kWave) c4[v] = make_uint4(0u, 0u, 0u, 0u); }
+    }
+    uint32_t len = khi_v - a;
+    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
+    if (lane >= nb) { a = 0; len = 0; }
+    const uint32_t incl = wave_incl_scan(len);
+    const uint32_t pre = incl - len;
+    const uint32_t nrec = nb > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : 0u;
+    double *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * bins;
+    double t0 = 0.0, den = 1.0;
+    if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
+    if (t_range) { t0 = (double)t_range[2 * b]; den = (double)(t_range[2 * b + 1] - t_range[2 * b]); }
+    const double *tw = tnorm ? tnorm + beg : nullptr;
+    const int4 *evw = ev + beg;
+    const int c0 = g.c0;
+    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+    // the fractional bin position of a record (k_voxel's digest): one float64 division, or the caller's own normalised time
+    auto bin_of = [&](const Rec8 &q) -> double {
+        if (tw) return (double)(bins - 1) * tw[q.y >> 11];
+        const int t = (int)q.x;
+        if (mode == 2) {
+            const int64_t num = (int64_t)(bins - 1) * ((int64_t)t - (int64_t)t0);
+            return (double)num / (den == 0.0 ? 1.0 : den);
+        }
+        if (mode == 0) {
+            const double tn = ((double)t - t0) / den;
+            return (double)(bins - 1) * tn;
+        }
+        const double num = (double)bins * ((double)t - t0);
+        return num / den;
+    };
+    auto pol_of = [&](const Rec8 &q) -> int {
+        const uint32_t p2 = (q.y >> 9) & 3u;
+        int p = (int)p2 - 1;
+        if (p2 == 3u) p = evw[q.y >> 11].w;
+        return p;
+    };
+    auto px_of = [&](const Rec8 &q) -> uint32_t { return ((q.y & 511u) - (uint32_t)c0) & 511u; };
+    const double lowlim = mode == 2 ? -1.0 : -0.0;
+    // one batch of one pass: lane holds (have, pixel, bin position, polarity) of one record; lanes are in array order
+    auto apply = [&](int pass, bool have, uint32_t px, double bpos, int p) {
+        double pd = (double)p;
+        if (mode == 1 && p == 0) pd = -1.0;
+        // flat time span (0/0): the reference yields NaN garbage.  Mode 2 truncates toward zero (astype("int32"), utils.py:67),
+        // so an event up to one bin before t0_us still lands in bin 0
+        bool ok = have && ((bpos > lowlim && bpos < 1.0e9) || bpos == 0.0);
+        const int bi = ok ? (int)bpos : 0;
+        const int blim = bi + pass;
+        ok = ok && blim < bins;
+        double wgt;
+        if (mode == 2) wgt = 1.0;
+        else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
+        else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
+        const double wp = wgt * pd;
+        double *cell = acc + (px * (uint32_t)bins + (uint32_t)blim);
+        bool pend = ok;
+        while (__any(pend)) {
+            if (pend) atomicMin(&tag[px], (uint32_t)lane);
+            wave_phase();
+            const bool win = pend && tag[px] == (uint32_t)lane;
+            wave_phase();
+            if (win) {
+                *cell = *cell + wp;
+                tag[px] = ~0u;
+                pend = false;
+            }
+            wave_phase();
+        }
+    };
+    if (nrec != 0u) {
+        const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+        const int npass = mode == 2 ? 1 : 2;
+        if (nrec <= (uint32_t)(64 * RB)) {
+            // the whole unit in registers: the run of record j by a max-scan over the runs' first positions (unit_records)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
+            srcs[lane] = src;
+            wave_phase();
+            if (lane < nb && len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+            wave_phase();
+            Rec8 q[RB];
+            uint32_t carry = 0u;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                q[i] = make_uint2(0u, 0u);
+                if ((uint32_t)(64 * i) < nrec) {   // uniform
+                    const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+                    const uint32_t j = (uint32_t)(64 * i + lane);
+                    if (j < nrec) q[i] = s8[srcs[k] + j];
+                }
+            }
+            double bp[RB];
+            uint32_t pp[RB];   // pixel | (polarity + bias) is not needed: the polarity is kept whole in its own bits
+            int pol[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                bp[i] = 0.0; pp[i] = 0u; pol[i] = 0;
+                if ((uint32_t)(64 * i + lane) < nrec) { pp[i] = px_of(q[i]); pol[i] = pol_of(q[i]); bp[i] = bin_of(q[i]); }
+            }
+            if (scale != 1.0) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) if ((uint32_t)(64 * i + lane) < nrec) touched[pp[i]] = 1;
+            }
+            for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if ((uint32_t)(64 * i) < nrec) apply(pass, (uint32_t)(64 * i + lane) < nrec, pp[i], bp[i], pol[i]);
+            }
+        } else {
+            // a larger unit: swept once per pass, four batches in flight; run by run when the runs are long enough to fill
+            // batches, else 64 consecutive records of the unit with the run found per record (unit_records)
+            constexpr int G = 4;
+            const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+            const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
+            uint32_t *runs2 = head;   // [2][64]
+            if (!by_run && nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
+            wave_phase();
+            auto src_of = [&](uint32_t j) -> uint32_t {
+                if (nb <= kBsChainBlocks) {
+                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+                    uint32_t prev = sx;
+                    for (int k = 1; k < nb; ++k) {
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                        sx += (j >= pk) ? sk - prev : 0u;
+                        prev = sk;
+                    }
+                    return sx + j;
+                }
+                uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+                for (int step = 0; step < 6; ++step) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool go = hi - lo > 1 && runs2[mid] <= j;
+                    if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+                }
+                return runs2[64 + lo] + j;
+            };
+            for (int pass = 0; pass < npass; ++pass) {
+                int rk_ = 0;
+                uint32_t ro_ = 0;
+                bool more = true;
+                while (more) {
+                    Rec8 q[G];
+                    uint32_t bcnt[G];
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        bcnt[sl] = 0u;
+                        uint32_t addr = 0u;
+                        if (by_run) {
+                            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                            if (rk_ < nb) {
+                                addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                                bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                                ro_ += kWave;
+                            }
+                        } else {
+                            const uint32_t j0 = ro_;
+                            if (j0 < nrec) {
+                                bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
+                                if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
+                                ro_ += kWave;
+                            }
+                        }
+                        q[sl] = make_uint2(0u, 0u);
+                        if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
+                    }
+                    if (by_run) {
+                        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                        more = rk_ < nb;
+                    } else {
+                        more = ro_ < nrec;
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        if (bcnt[sl] == 0u) break;   // uniform
+                        const bool have = (uint32_t)lane < bcnt[sl];
+                        uint32_t px = 0u; int pol = 0; double bp = 0.0;
+                        if (have) { px = px_of(q[sl]); pol = pol_of(q[sl]); bp = bin_of(q[sl]); }
+                        if (pass == 0 && scale != 1.0 && have) touched[px] = 1;
+                        apply(pass, have, px, bp, pol);
+                    }
+                }
+            }
+        }
+    }
+    wave_phase();
+    if (scale != 1.0) {   // the pixels that hold records are scaled, bin by bin (k_voxel's reduce); empty ones stay +0
+        const uint32_t inv = (65536u + (uint32_t)bins - 1u) / (uint32_t)bins;   // v / bins == (v * inv) >> 16 for v < 4096
+        for (int v = lane; v < ncell; v += kWave) {
+            const uint32_t px = ((uint32_t)v * inv) >> 16;
+            if (touched[px]) acc[v] = acc[v] * scale;
+        }
+        wave_phase();
+    }
+    tile_store(acc, ncell, dst);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -121,7 +121,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
         plan->H, plan->W, plan->nchunk, uc, k, frame_mode, scale, out);                                             \
     }                                                                                                               \
     UnitCfg hc = hot_cfg(uc);                                                                                       \
-    if (uc.xflags & 6) hc.stage = hot_sweep_stage((size_t)span * kChunkPx * 2 * k * 4, 512, (size_t)kPartPx * 2 * k * 4);   /* whole units by the order-free sweep: room for their words */ \
+    if (uc.xflags & 6) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 2 * k * 4, 512, (size_t)kPartPx * 2 * k * 4);   /* whole units by the order-free sweep: room for their words */ \
     /* (none behind the sweeping main launch: it defers nothing -- units with a shifted frame or unsorted timestamps are emitted from their slot by the main wave) */ \
     if (plan->reserved == 2 && !sweep_main) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
@@ -159,14 +159,28 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
     if (bins <= 0 || bins > EVREP_MAX_CHANNELS || mode < 0 || mode > 2 || !out) return EVREP_EINVAL;
     if (t_range && mode != 2) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (plan->reserved == 2 && !(plan->flags & EVREP_PLAN_X_VOXEL_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass: the streaming form (k_voxel_stream) -- one launch, every unit, no hot list
+        UnitCfg us = unit_cfg(plan, (size_t)bins * 8);
+        us.span = 1; us.merge = 0; us.hold = 0;
+        unit_cfg_geometry(us, plan);
+        const UnitCfg &uc = us;
+        constexpr int kRB = 4;
+        k_voxel_stream<kRB><<<SPAN_GRID(1), kWave, voxel_stream_lds_bytes(bins, kChunkPx, kRB), stream>>>(
+            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us,
+            bins, mode, scale, t_range, tnorm, out);
+        LAUNCH_CHECK("k_voxel_stream");
+        return EVREP_OK;
+    }
     const UnitCfg uc = unit_cfg(plan, (size_t)bins * 8);
     const int span = uc.span;
 #define VOXEL_LAUNCH(CM)                                                                                         \
     do {                                                                                                         \
-    k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(              \
+    /* + the lanes' own rows of running sums: 64 x bins float64 behind the carve (k_voxel's reduce) */              \
+    k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, uc.stage) + (size_t)kWave * bins * 8, stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
         bins, mode, scale, t_range, tnorm, out);                                                                 \
-    if (plan->reserved == 2) k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(         \
+    if (plan->reserved == 2) k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage) + (size_t)kWave * bins * 8, stream>>>(         \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
         hot_cfg(uc), bins, mode, scale, t_range, tnorm, out);                                                    \
     } while (0)
@@ -236,7 +250,7 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, uc, out);            \
         /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \
         UnitCfg hc = hot_cfg(uc);                                                                                     \
-        if (uc.xflags & 2) hc.stage = hot_sweep_stage((size_t)span * kChunkPx * 14 * 4, 512, (size_t)uc.partpx * C * 4);   \
+        if (uc.xflags & 2) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 14 * 4, 512, (size_t)uc.partpx * C * 4);   \
         if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hc, out);   \
     } while (0)

@@ -52,7 +52,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
            hands hot units to its hot launch whole (Split, IN_HOT): a stage of kHotSplitStage records there */                   \
         const bool hot_launch = plan->reserved == 2 && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                             \
         UnitCfg hc = hot_cfg(uc);                                                                                             \
-        if (MdesIsErgo12<DESC>::value) hc.stage = hot_sweep_stage((size_t)span * kChunkPx * 7 * 4, 4096, (size_t)uc.partpx * C * sizeof(T));                                                             \
+        if (MdesIsErgo12<DESC>::value) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 7 * 4, 4096, (size_t)uc.partpx * C * sizeof(T));                                                             \
         if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(  \
             bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hc, scale, static_cast<T *>(out)); \
     } while (0)

@@ -106,6 +106,17 @@ class EventBatch:
                                              st.ctypes.data_as(ctypes.c_void_p), _stream_ptr()), "evrep_read_status")
         return st
 
+    def check_built(self, what="builder"):
+        """After a builder call (one synchronisation): raise if a builder kernel set EVREP_ST_HOT_OVERFLOW -- the
+        workspace's hot-unit list filled up and a unit was left unwritten.  The builders are asynchronous and the flag is
+        raised BY the builder launch, so it can only be seen after it; the per-sample wrappers (`finish`) read it with the
+        result, batched callers call this where they synchronise anyway.  Returns the status words."""
+        from ._lib import EvrepError, ST_HOT_OVERFLOW
+        st = self.status()
+        if any(int(v) & ST_HOT_OVERFLOW for v in st):
+            raise EvrepError("%s: the workspace's hot-unit list overflowed (EVREP_ST_HOT_OVERFLOW): the tensor is incomplete" % what)
+        return st
+
     def bbox(self):
         self.bin()
         bb = np.zeros((self.B, 4), dtype=np.int32)

@@ -29,7 +29,10 @@ from ..synthetic import from_structured, narrow_to_int32
 
 RESULT_POOL_DEPTH = int(os.environ.get("EVREP_RESULT_POOL", os.environ.get("EVREP_RESULT_RING", "8")))
 _CONTEXTS = {}            # insertion-ordered: least recently used first (_context)
-MAX_CONTEXTS = 32         # (a context a caller still holds results of stays alive through their references)
+# how many (process, thread, device, stream, H, W, size bucket, flags, pacing) contexts stay cached: EVREP_MAX_CONTEXTS
+# (a context a caller still holds results of stays alive through their references)
+MAX_CONTEXTS = max(1, int(os.environ.get("EVREP_MAX_CONTEXTS", "64")))
+_EVICTION_LOGGED = [False]
 _CONTEXTS_LOCK = threading.Lock()
 
 
@@ -112,10 +115,20 @@ def _context(height, width, n):
             # that makes a thread or a stream per sample would otherwise pin cap x 16 B and hold 29.5 MB of device output each
             if len(_CONTEXTS) > MAX_CONTEXTS:
                 alive = {t.ident for t in threading.enumerate()}
-                for k in [k for k in _CONTEXTS if k[0] == os.getpid() and k[1] not in alive]:
+                for k in [k for k in _CONTEXTS if k[0] != os.getpid() or k[1] not in alive]:    # dead threads, forked-away parents
                     del _CONTEXTS[k]
+                # only then live ones, least recently used first -- and never silently: every miss after this re-allocates
+                # pinned staging, a workspace and a plan (milliseconds), so a feed that cycles through more shapes / size
+                # buckets than the limit should raise EVREP_MAX_CONTEXTS
                 while len(_CONTEXTS) > MAX_CONTEXTS:
-                    del _CONTEXTS[next(iter(_CONTEXTS))]
+                    victim = next(k for k in _CONTEXTS if k != key)
+                    del _CONTEXTS[victim]
+                    if not _EVICTION_LOGGED[0]:
+                        _EVICTION_LOGGED[0] = True
+                        import warnings
+                        warnings.warn("evrep: more than %d live per-sample contexts (threads x streams x sensor sizes x size "
+                                      "buckets); the least recently used one was evicted -- set EVREP_MAX_CONTEXTS higher if "
+                                      "this feed cycles through that many" % MAX_CONTEXTS, RuntimeWarning, stacklevel=3)
     return ctx
 
 

@@ -54,6 +54,7 @@ class ToTimesurface:
         for s0 in range(0, live, 8):                                  # up to 8 surfaces per launch
             chunk = indices[s0:min(s0 + 8, live)]
             rep = batch.time_surface(slices=len(chunk), tau=float(self.tau), premap=2 if unsorted else 0, indices=chunk, times_f64=tf_dev)
+            batch.check_built("ToTimesurface")                        # the hot-list flag is raised BY the builder
             rep = rep[0].cpu().numpy().reshape(H, W, len(chunk), 2)    # channel c = 2*s + p
             out[s0:s0 + len(chunk)] = rep.transpose(2, 3, 0, 1)
         return out

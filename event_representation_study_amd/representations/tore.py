@@ -51,4 +51,5 @@ def events2ToreFeature(x, y, ts, pol, sampleTimes, k, frameSize):
         batch = EventBatch.from_numpy(ev, Hf, Wf)
         raise_for_status(batch, what="events2ToreFeature", allow_unsorted=True)   # array order, as the reference (r05)
         rep = batch.tore(k=int(k), frame_mode=2, scale=1.0, sample_times=[int(st)])
+    batch.check_built("events2ToreFeature")      # the hot-list flag is raised BY the builder: read it after the build
     return rep[0].cpu().numpy()

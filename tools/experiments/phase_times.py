@@ -22,7 +22,18 @@ DIST = os.environ.get("DIST", "uniform")   # uniform | circle | edges (synthetic
 eb = EventBatch.from_numpy([GENERATORS[DIST](N, W, H, seed=i) for i in range(B)], H, W)
 eb.bin()
 DT = torch.float32 if os.environ.get("DTYPE") == "f32" else torch.float64   # DTYPE=f32: the float32 ERGO-12 instance
-outs = [torch.empty((B, H, W, 12), dtype=DT, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
+BUILDER = os.environ.get("BUILDER", "optimized")                              # BUILDER=voxel: k_voxel's marks (r06)
+CH = 5 if BUILDER == "voxel" else 12
+
+
+def build(o):
+    if BUILDER == "voxel":
+        eb.voxel(5, out=o)
+    else:
+        eb.optimized(out=o, dtype=DT)
+
+
+outs = [torch.empty((B, H, W, CH), dtype=DT, device="cuda:0") for _ in range(int(os.environ.get("NBUF", "4")))]
 holds = [int(v) for v in sys.argv[1:]] or [0, 600, 670]
 nunit = B * H * ((W + 127) // 128)
 assert nunit * 64 <= (eb.total + 1) * 8, "the idle half of the record stream is too small for the marks"
@@ -32,13 +43,13 @@ for o in outs:
     for h in holds:
         check(eb.lib.evrep_plan_set_pacing(ctypes.byref(eb.plan), h), "pacing")
         for _ in range(3):
-            eb.optimized(out=o, dtype=DT)
+            build(o)
         torch.cuda.synchronize()
         dbg.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
-            eb.optimized(out=o, dtype=DT)
+            build(o)
         b.record()
         torch.cuda.synchronize()
         d = dbg.cpu().numpy().astype(float) / 100.0

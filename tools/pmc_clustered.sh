@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
 for tag in "$@"; do
   d=$O/${tag/@/_}; mkdir -p $d
-  for set in sq fetch write; do
+  for set in ${PMC_SETS:-sq fetch write}; do
     case $set in sq) C="$SQ";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
     timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d/$set -o p -- python $R/tools/pmc_builders_workload.py $tag $PMC_BUILDERS > $d/$set.log 2>&1
     f=$(find $d/$set -name "*counter_collection.csv" | head -1)
