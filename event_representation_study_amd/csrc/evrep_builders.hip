@@ -2881,6 +2881,235 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 12 ? EVREP_TORE_WAVES : 1))
 }
 
 // --------------------------------------------------------------------------------------------
+// A8 (r06), after the key-sorted pass: TORE as a STREAM -- the unit's tile in LDS IS the K-deep FIFOs.
+// A FIFO slot's value depends on its event alone (one sample time per window) and is a non-increasing function of the event's
+// time, so "the K most recent events of a pixel and polarity, most recent first" = "the K SMALLEST finished values, ascending":
+// the tile (pixels x 2 K float32, output layout) starts as the empty-FIFO value everywhere and every record pushes its value --
+// the digest: one logf per record and lane, all lanes at once -- down a K-deep cascade of LDS atomicMin on the value's bits (values
+// are >= +0: their bit patterns order as unsigned integers); slot k ends up with the (k + 1)-th smallest whatever the order of
+// arrival, hot pixels are serialised by the LDS atomic unit and not by rounds of the wave, and a cascade stops as soon as what it
+// carries is the empty value (a sparse pixel's first record: one atomic).  No grouping, no order, no walk, no per-slot logarithm,
+// no hot launch: the tile leaves as one burst.  Any frame (bounding box, shifted, full): the unit's records are those of the
+// sensor keys its output columns cover, a record's output pixel is its column minus the frame's offset.
+// Windows whose timestamps are not ascending keep the reference's array-order semantics (np.partition on the k-vector, see
+// k_tore's reduce): there one record per (pixel, polarity) and round inserts into its FIFO -- an election as in k_voxel_stream.
+// LDS: tile [npixa * 2 K] u32 | tag [2 * npixa] | head [64 * RB] | srcs [64] / run table [128]
+__host__ __device__ inline size_t tore_stream_lds_bytes(int K, int npixa, int rb) {
+    return align16((size_t)npixa * 2 * K * 4) + (size_t)2 * npixa * 4 + (size_t)(64 * rb) * 4 + 128 * 4;
+}
+#ifndef EVREP_TST_WAVES
+#define EVREP_TST_WAVES 6
+#endif
+template <int RB>
+__global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+                                               const int32_t *__restrict__ sample_times, int H, int W, int nchunk, UnitCfg uc,
+                                               int K, int frame_mode, float scale, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int C = 2 * K;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    const int nunit = uc.nunit;
+    const uint32_t urow = fastdiv((uint32_t)uid, uc.nunit_m, uc.nunit_sh);
+    const int b = (int)fastdiv(urow, uc.h_m, uc.h_sh), orow = (int)urow - b * H, oc0 = (uid - (int)urow * nunit) * uc.span * kChunkPx;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const bool empty = n_win <= 0;
+    if (empty && frame_mode == 0) return;   // no bounding box: nothing to write (k_tore)
+    const MetaRaw mraw = meta_prefetch(bv, b);
+    int Tl = 0;
+    if (!empty) Tl = sample_times ? sample_times[b] : ev[beg + n_win - 1].z;
+    const WindowMeta m = meta_finish(bv, off, b, mraw);
+    int x0 = 0, y0 = 0, Hf = H, Wf = W;
+    if (!empty && (frame_mode == 0 || frame_mode == 1)) { x0 = m.xmin; y0 = m.ymin; }
+    if (frame_mode == 0) { Hf = m.ymax - m.ymin + 1; Wf = m.xmax - m.xmin + 1; }
+    if (orow >= Hf || oc0 >= Wf) return;
+    const int npix = min(uc.span * kChunkPx, Wf - oc0);
+    const int row = orow + y0;
+    const int T = Tl;
+    const int sc_lo = oc0 + x0, sc_hi = sc_lo + npix;   // the sensor columns behind the unit's output columns
+    const int npixa = uc.span * kChunkPx;
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *tag = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * C * 4));
+    uint32_t *head = tag + 2 * npixa;
+    uint32_t *srcs = head + 64 * RB;
+    const double log_min = log(151.0);
+    const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
+    const uint32_t bgb = __float_as_uint(bgv);
+    const bool unsorted = (m.status & EVREP_ST_UNSORTED) != 0u;   // wave-uniform
+    {
+        uint4 *t4 = reinterpret_cast<uint4 *>(tile);
+        const int nvec = (npix * C + 3) / 4;
+        for (int v = lane; v < nvec; v += kWave) t4[v] = make_uint4(bgb, bgb, bgb, bgb);
+        if (unsorted) { uint4 *g4 = reinterpret_cast<uint4 *>(tag); for (int v = lane; v * 4 < 2 * npixa; v += kWave) g4[v] = make_uint4(~0u, ~0u, ~0u, ~0u); }
+    }
+    float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
+    uint32_t nrec = 0u, a = 0u, len = 0u, pre = 0u;
+    int nb = 0, c0 = 0;
+    if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
+        const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
+        const int NK = H * nchunk, klo = row * nchunk + ch_lo, khi = row * nchunk + ch_hi + 1;
+        c0 = ch_lo * kChunkPx;
+        uint32_t khi_v = 0;
+        if (lane < bv.nblk) {
+            const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+            a = tb[klo];
+            khi_v = tb[khi];
+        }
+        len = khi_v - a;
+        nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
+        if (lane >= nb) { a = 0; len = 0; }
+        const uint32_t incl = wave_incl_scan(len);
+        pre = incl - len;
+        nrec = nb > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : 0u;
+    }
+    const int4 *evw = ev + beg;
+    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+    const int pxoff = sc_lo - c0;   // output pixel = (column inside the gathered chunks) - pxoff
+    // one batch: a record's finished value down its FIFO
+    auto push = [&](bool have, const Rec8 &q) {
+        const int32_t t = (int32_t)q.x;
+        const int px = (int)(((q.y & 511u) - (uint32_t)c0) & 511u) - pxoff;
+        const bool ok = have && t < T && px >= 0 && px < npix;   // events at the sample time are dropped (tore.py:17)
+        const uint32_t p2 = (q.y >> 9) & 3u;
+        int p = (int)p2 - 1;
+        if (ok && p2 == 3u) p = evw[q.y >> 11].w;
+        float v = (float)(double)((int64_t)T - (int64_t)t);
+        v = fminf(v, 500e6f);
+        v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
+        uint32_t *wd = tile + (uint32_t)(ok ? px : 0) * (uint32_t)C + (p > 0 ? 0u : (uint32_t)K);
+        if (!unsorted) {
+            uint32_t vb = __float_as_uint(v);
+            if (ok) {
+                for (int k = 0; k < K && vb < bgb; ++k) { const uint32_t old = atomicMin(wd + k, vb); vb = max(old, vb); }
+            }
+        } else {
+            // array order (k_tore's reduce, unsorted): insert v into the ascending k - 1 smallest kept so far; the largest of
+            // the k is only dropped by the NEXT event of the FIFO.  One record per FIFO and round.
+            uint32_t *tg = tag + 2u * (uint32_t)(ok ? px : 0) + (p > 0 ? 0u : 1u);
+            bool pend = ok;
+            while (__any(pend)) {
+                if (pend) atomicMin(tg, (uint32_t)lane);
+                wave_phase();
+                const bool win = pend && *tg == (uint32_t)lane;
+                wave_phase();
+                if (win) {
+                    float *fa = reinterpret_cast<float *>(wd);
+                    float prev = v;   // a'[q - 1] of the OLD list (q > 0), v for q == 0
+                    for (int q2 = 0; q2 < K; ++q2) {
+                        const float aq = fa[q2];
+                        const float hi = q2 > 0 ? (prev > v ? prev : v) : v;
+                        const bool last = q2 >= K - 1;
+                        fa[q2] = (last || hi < aq) ? hi : aq;
+                        prev = aq;
+                    }
+                    *tg = ~0u;
+                    pend = false;
+                }
+                wave_phase();
+            }
+        }
+    };
+    if (nrec != 0u) {
+        const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+        if (nrec <= (uint32_t)(64 * RB)) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
+            srcs[lane] = src;
+            wave_phase();
+            if (lane < nb && len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+            wave_phase();
+            Rec8 q[RB];
+            uint32_t carry = 0u;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                q[i] = make_uint2(0u, 0u);
+                if ((uint32_t)(64 * i) < nrec) {   // uniform
+                    const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+                    const uint32_t j = (uint32_t)(64 * i + lane);
+                    if (j < nrec) q[i] = s8[srcs[k] + j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if ((uint32_t)(64 * i) < nrec) push((uint32_t)(64 * i + lane) < nrec, q[i]);
+        } else {
+            constexpr int G = 4;
+            const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+            const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
+            uint32_t *rt = srcs;   // [2][64]
+            if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
+            wave_phase();
+            auto src_of = [&](uint32_t j) -> uint32_t {
+                if (nb <= kBsChainBlocks) {
+                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+                    uint32_t prev = sx;
+                    for (int k = 1; k < nb; ++k) {
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                        sx += (j >= pk) ? sk - prev : 0u;
+                        prev = sk;
+                    }
+                    return sx + j;
+                }
+                uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+                for (int step = 0; step < 6; ++step) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool go = hi - lo > 1 && rt[mid] <= j;
+                    if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+                }
+                return rt[64 + lo] + j;
+            };
+            int rk_ = 0;
+            uint32_t ro_ = 0;
+            bool more = true;
+            while (more) {
+                Rec8 q[G];
+                uint32_t bcnt[G];
+#pragma unroll
+                for (int sl = 0; sl < G; ++sl) {
+                    bcnt[sl] = 0u;
+                    uint32_t addr = 0u;
+                    if (by_run) {
+                        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                        if (rk_ < nb) {
+                            addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                            bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                            ro_ += kWave;
+                        }
+                    } else {
+                        const uint32_t j0 = ro_;
+                        if (j0 < nrec) {
+                            bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
+                            if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
+                            ro_ += kWave;
+                        }
+                    }
+                    q[sl] = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
+                }
+                if (by_run) {
+                    uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                    while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                    more = rk_ < nb;
+                } else {
+                    more = ro_ < nrec;
+                }
+#pragma unroll
+                for (int sl = 0; sl < G; ++sl) {
+                    if (bcnt[sl] == 0u) break;   // uniform
+                    push((uint32_t)lane < bcnt[sl], q[sl]);
+                }
+            }
+        }
+    }
+    wave_phase();
+    tile_store(reinterpret_cast<const float *>(tile), npix * C, dst);
+}
+
+// --------------------------------------------------------------------------------------------
 // A2: compute_repr (representation_search/gromov_wasserstein.py:72-82), t normalised as :96.
 // mode 1: tonic.transforms.ToVoxelGrid as consumed at gen1_transforms.py:22-25 (parity unpinned).
 // mode 2: ev-licious events_to_voxel_grid, integer-pixel path (ev-licious/src/evlicious/tools/utils.py:

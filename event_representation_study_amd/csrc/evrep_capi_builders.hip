@@ -98,6 +98,19 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     if (k <= 0 || k > kMaxToreK || frame_mode < 0 || frame_mode > 2 || !out) return EVREP_EINVAL;
     if (sample_times_f && !tf) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (plan->reserved == 2 && tf == nullptr && scale >= 0.0f && !(plan->flags & EVREP_PLAN_X_TORE_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass, integer times: the streaming form (k_tore_stream) -- one launch, every unit and frame, no hot list
+        UnitCfg us = unit_cfg(plan, (size_t)2 * k * 4, 1);
+        us.span = 1; us.merge = 0; us.hold = 0;
+        unit_cfg_geometry(us, plan);
+        const UnitCfg &uc = us;
+        constexpr int kRB = 4;
+        k_tore_stream<kRB><<<SPAN_GRID(1), kWave, tore_stream_lds_bytes(k, kChunkPx, kRB), stream>>>(
+            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, plan->H, plan->W,
+            plan->nchunk, us, k, frame_mode, scale, out);
+        LAUNCH_CHECK("k_tore_stream");
+        return EVREP_OK;
+    }
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
     const int span = uc.span;
     // dense windows: the main launch runs the order-free cascade itself (k_tore, SM), as k_polstats does
