@@ -2881,6 +2881,206 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 12 ? EVREP_TORE_WAVES : 1))
 }
 
 // --------------------------------------------------------------------------------------------
+// r06: the STREAM front end shared by the order-free builders after the key-sorted pass.
+// Every record of the sensor keys [klo, khi) of window b (consecutive 128-pixel chunks of one row), 64 at a time, in array
+// order: `pre(q)` (optional per-record gather from global memory, issued for every batch of a group before the first `f`) and
+// `f(have, q, aux)`.  Units of up to 64 * RB records: every record load in flight at once, a record's run found by a max-scan over
+// the runs' first positions; larger ones four batches at a time, run by run when the runs fill batches.  No order by pixel, no
+// segment list: what a builder keeps per pixel it keeps by LDS atomics (or elections) on its own tile.
+// head: [64 * RB] words of LDS, srcs: [128].  Returns the unit's record count.
+struct StreamNoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
+template <int RB, typename Pre, typename F>
+__device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
+                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f) {
+    const int lane = threadIdx.x;
+    uint32_t a = 0, khi_v = 0;
+    if (lane < bv.nblk) {
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+        a = tb[klo];
+        khi_v = tb[khi];
+    }
+    uint32_t len = khi_v - a;
+    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
+    if (nb <= 0) return 0u;
+    if (lane >= nb) { a = 0; len = 0; }
+    const uint32_t incl = wave_incl_scan(len);
+    const uint32_t pre = incl - len;
+    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (nrec == 0u) return 0u;
+    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+    const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+    if (nrec <= (uint32_t)(64 * RB)) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
+        srcs[lane] = src;
+        wave_phase();
+        if (len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+        wave_phase();
+        Rec8 q[RB];
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            q[i] = make_uint2(0u, 0u);
+            if ((uint32_t)(64 * i) < nrec) {   // uniform
+                const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+                const uint32_t j = (uint32_t)(64 * i + lane);
+                if (j < nrec) q[i] = s8[srcs[k] + j];
+            }
+        }
+        uint2 aux[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            aux[i] = make_uint2(0u, 0u);
+            if ((uint32_t)(64 * i + lane) < nrec) aux[i] = pre_f(q[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
+        return nrec;
+    }
+    constexpr int G = 4;
+    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+    const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
+    uint32_t *rt = srcs;   // [2][64]
+    if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
+    wave_phase();
+    auto src_of = [&](uint32_t j) -> uint32_t {
+        if (nb <= kBsChainBlocks) {
+            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t prev = sx;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                sx += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return sx + j;
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && rt[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return rt[64 + lo] + j;
+    };
+    int rk_ = 0;
+    uint32_t ro_ = 0;
+    bool more = true;
+    while (more) {
+        Rec8 q[G];
+        uint32_t bcnt[G];
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            bcnt[sl] = 0u;
+            uint32_t addr = 0u;
+            if (by_run) {
+                uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                if (rk_ < nb) {
+                    addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                    bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                    ro_ += kWave;
+                }
+            } else {
+                const uint32_t j0 = ro_;
+                if (j0 < nrec) {
+                    bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
+                    if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
+                    ro_ += kWave;
+                }
+            }
+            q[sl] = make_uint2(0u, 0u);
+            if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
+        }
+        if (by_run) {
+            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+            more = rk_ < nb;
+        } else {
+            more = ro_ < nrec;
+        }
+        uint2 aux[G];
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            aux[sl] = make_uint2(0u, 0u);
+            if ((uint32_t)lane < bcnt[sl]) aux[sl] = pre_f(q[sl]);
+        }
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            if (bcnt[sl] == 0u) break;   // uniform
+            f((uint32_t)lane < bcnt[sl], q[sl], aux[sl]);
+        }
+    }
+    return nrec;
+}
+
+// --------------------------------------------------------------------------------------------
+// A6 (r06), after the key-sorted pass: EventStack as a STREAM.  A pixel's levels only depend on its LAST record in array order
+// (ndarray.put is last-write-wins, event_stack.py:125): one word per pixel of the unit, ((rank + 1) << 2 | polarity code) under LDS
+// atomicMax, in ONE sweep of the unit's records whatever it holds; then a lane per pixel forms the pixel's S levels into the unit's
+// tile and the tile leaves as one coalesced burst.  No grouping, no stage, no hot launch.
+// LDS: tile [npixa * S] f32 | last [npixa] u32 | head [64 * RB] | srcs [128]
+__host__ __device__ inline size_t event_stack_stream_lds_bytes(int S, int npixa, int rb) {
+    return align16((size_t)npixa * S * 4) + (size_t)npixa * 4 + (size_t)(64 * rb) * 4 + 128 * 4;
+}
+template <int CM, int RB>
+__global__ __launch_bounds__(kWave, 6) void k_event_stack_stream(BinView bv, const int64_t *__restrict__ off, int H, int W, int nchunk,
+                                                             UnitCfg uc, int S, int premap, float scale, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    int chunk, nch;
+    const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+    const int b = g.b;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    float *tile = reinterpret_cast<float *>(smem);
+    uint32_t *last = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * S * 4));
+    uint32_t *head = last + npixa;
+    uint32_t *srcs = head + 64 * RB;
+    for (int v = lane; v * 4 < npixa; v += kWave) reinterpret_cast<uint4 *>(last)[v] = make_uint4(0u, 0u, 0u, 0u);
+    const int4 *evw = bv.ev + beg;
+    const int c0 = g.c0;
+    wave_phase();
+    stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, g.row * nchunk + chunk, g.row * nchunk + chunk + nch, head, srcs, StreamNoPre(),
+        [&](bool have, const Rec8 &q, const uint2 &) {
+            if (have) atomicMax(&last[((q.y & 511u) - (uint32_t)c0) & 511u], (((q.y >> 11) + 1u) << 2) | ((q.y >> 9) & 3u));
+        });
+    wave_phase();
+    // level k keeps events[off_k:], off_k = sum_{j=1..k} N // 2^j  (event_stack.py:70-82)
+    int offk[CM];
+    {
+        int cur = (int)n_win, o = 0;
+#pragma unroll
+        for (int k = 0; k < CM; ++k) { offk[k] = o; cur /= 2; o += cur; }
+    }
+    for (int pt = 0; pt * kWave < g.npix; ++pt) {
+        const int px = pt * kWave + lane;
+        if (px < g.npix) {
+            const uint32_t wv = last[px];
+            const int rank = (int)(wv >> 2) - 1;
+            float v = 0.0f;
+            if (wv) {
+                const uint32_t p2 = wv & 3u;
+                int p = p2 == 3u ? evw[rank].w : (int)p2 - 1;
+                if (premap == 1) p = (p + 1) >> 1;                   // (p + 1) // 2   (gen1_transforms.py:34)
+                v = (float)(int8_t)(premap == 2 ? p : 2 * p - 1) * scale;   // 2*p - 1 as int8 (event_stack.py:18)
+            }
+            float *mine = tile + (size_t)px * S;
+#pragma unroll
+            for (int l = 0; l < CM; ++l) if (l < S) mine[l] = (wv && rank >= offk[l]) ? v : 0.0f;
+        }
+    }
+    wave_phase();
+    float *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * S;
+    tile_store(tile, g.npix * S, dst);
+}
+
+// --------------------------------------------------------------------------------------------
 // A8 (r06), after the key-sorted pass: TORE as a STREAM -- the unit's tile in LDS IS the K-deep FIFOs.
 // A FIFO slot's value depends on its event alone (one sample time per window) and is a non-increasing function of the event's
 // time, so "the K most recent events of a pixel and polarity, most recent first" = "the K SMALLEST finished values, ascending":
@@ -3658,6 +3858,162 @@ __global__ __launch_bounds__(kWave, (HOT || SM) ? 4 : EVREP_PS_WAVES) void k_pol
         };
         emit_chunk<float, CM, HOT>(u, digest, g.row * W + g.c0, g.npix, C, dst, w, bg, reduce);
     });
+}
+
+// --------------------------------------------------------------------------------------------
+// F4 (r06), after the key-sorted pass: the n_imagenet accumulators as a STREAM.  Every statistic is order-free (counts, maxima and
+// minima of the caller's per-event time per polarity class): sixteen words per pixel of the unit in LDS (three full-width counts,
+// six 64-bit extremes as order-preserving keys: k_polstats' words), bumped by LDS atomics in ONE sweep of the unit's records --
+// whatever it holds -- then every pixel's C values are formed from its words, 64 pixels at a time, and written over the words
+// already consumed (C * 4 <= 64 bytes per pixel: a batch's values end in front of the next batch's words), so that the unit leaves
+// as one coalesced burst.  No grouping, no stage, no hot launch.
+// LDS: words [npixa * 16 (K32: 9)] u32 (then the tile) | head [64 * RB] | srcs [128]
+// K32 (no EXP channel, C <= 8): the extremes as 32-bit keys of the time ROUNDED to float32 -- the outputs are (float) max / (float) min
+// of the float64 times, and the rounding is monotone, so the maximum of the rounded times is the rounded maximum: nine words per
+// pixel instead of sixteen, 32-bit LDS atomics, a three-instruction decode per extreme (sparse 640x480 windows: 102 -> us, the
+// kernel is bound by its instruction count there).
+__host__ __device__ inline int polstats_stream_words(bool k32) { return k32 ? 9 : 16; }   // #(p > 0), #(p < 0), #(p == 0), [pad,] per class max key(t_n), max ~key(t_n)
+__host__ __device__ inline size_t polstats_stream_lds_bytes(int npixa, int rb, bool k32) {
+    return align16((size_t)npixa * polstats_stream_words(k32) * 4) + (size_t)(64 * rb) * 4 + 128 * 4;
+}
+template <int CM, int RB, bool K32>
+__global__ __launch_bounds__(kWave, 6) void k_polstats_stream(BinView bv, const int64_t *__restrict__ off, const double *__restrict__ tnorm,
+                                                          PolStatParams P, int H, int W, int nchunk, UnitCfg uc, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = K32 ? 9 : 16;
+    const int lane = threadIdx.x;
+    const int C = P.C;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    int chunk, nch;
+    const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+    const int b = g.b;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    uint32_t *words = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *head = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * NW * 4));
+    uint32_t *srcs = head + 64 * RB;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(words);
+        const int nvec = (g.npix * NW + 3) / 4;
+        for (int v = lane; v < nvec; v += kWave) z[v] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const double *tw0 = tnorm + beg;
+    const int4 *evw0 = bv.ev + beg;
+    const int c0 = g.c0;
+    auto dkey = [](double v) -> unsigned long long {
+        const unsigned long long bts = (unsigned long long)__double_as_longlong(v);
+        return (bts >> 63) ? ~bts : (bts | 0x8000000000000000ull);
+    };
+    auto dval = [](unsigned long long k) -> double {
+        const unsigned long long bts = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        return __longlong_as_double((long long)bts);
+    };
+    auto fkey = [](float v) -> uint32_t { const uint32_t bts = __float_as_uint(v); return (bts >> 31) ? ~bts : (bts | 0x80000000u); };
+    auto fval = [](uint32_t k) -> float { return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); };
+    wave_phase();
+    stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, g.row * nchunk + chunk, g.row * nchunk + chunk + nch, head, srcs,
+        [&](const Rec8 &q) -> uint2 {   // the record's time from the caller's array: every gather of a group in flight together
+            const double tn = tw0[q.y >> 11];
+            if constexpr (K32) return make_uint2(__float_as_uint((float)tn), 0u);
+            return make_uint2((uint32_t)__double2loint(tn), (uint32_t)__double2hiint(tn));
+        },
+        [&](bool have, const Rec8 &q, const uint2 &aux) {
+            if (!have) return;
+            const uint32_t px = ((q.y & 511u) - (uint32_t)c0) & 511u;
+            const uint32_t p2 = (q.y >> 9) & 3u;
+            int p = (int)p2 - 1;
+            if (p2 == 3u) p = evw0[q.y >> 11].w;   // an escaped polarity value: only its sign counts
+            const int cls = p > 0 ? 0 : (p < 0 ? 1 : 2);
+            uint32_t *wd = words + px * (uint32_t)NW;
+            atomicAdd(wd + cls, 1u);
+            if constexpr (K32) {
+                const uint32_t k = fkey(__uint_as_float(aux.x));
+                atomicMax(wd + 3 + 2 * cls, k);
+                atomicMax(wd + 4 + 2 * cls, ~k);
+            } else {
+                const unsigned long long k = dkey(__hiloint2double((int)aux.y, (int)aux.x));
+                unsigned long long *w64 = reinterpret_cast<unsigned long long *>(wd + 4 + 4 * cls);
+                atomicMax(w64, k);
+                atomicMax(w64 + 1, ~k);
+            }
+        });
+    wave_phase();
+    float *tile = reinterpret_cast<float *>(smem);
+    for (int pt = 0; pt * kWave < g.npix; ++pt) {
+        const int px = pt * kWave + lane;
+        float vals[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) vals[c] = 0.0f;
+        if (px < g.npix) {
+            const uint32_t *wd = words + (uint32_t)px * (uint32_t)NW;
+            const int n_pos = (int)wd[0], n_neg = (int)wd[1], n_zero = (int)wd[2];
+            const int n_any = n_pos + n_neg + n_zero;
+            if constexpr (K32) {
+                // (float32 extremes: no EXP channel reads them)
+                const float mxp = n_pos ? fval(wd[3]) : 0.0f, mnp = n_pos ? fval(~wd[4]) : 0.0f;
+                const float mxn = n_neg ? fval(wd[5]) : 0.0f, mnn = n_neg ? fval(~wd[6]) : 0.0f;
+                const float mxz = n_zero ? fval(wd[7]) : 0.0f, mnz = n_zero ? fval(~wd[8]) : 0.0f;
+                float mxa = 0.0f, mna = 0.0f;
+                bool hv = false;
+                if (n_pos) { mxa = mxp; mna = mnp; hv = true; }
+                if (n_neg) { mxa = hv ? fmaxf(mxa, mxn) : mxn; mna = hv ? fminf(mna, mnn) : mnn; hv = true; }
+                if (n_zero) { mxa = hv ? fmaxf(mxa, mxz) : mxz; mna = hv ? fminf(mna, mnz) : mnz; }
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    float v = 0.0f;
+                    if (c < C) {
+                        const int k = P.pol[c], st = P.stat[c];
+                        const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
+                        const float mx = k == EVREP_PS_POS ? mxp : (k == EVREP_PS_NEG ? mxn : mxa);
+                        const float mn = k == EVREP_PS_POS ? mnp : (k == EVREP_PS_NEG ? mnn : mna);
+                        if (st == EVREP_PS_COUNT) v = (float)n;
+                        else if (st == EVREP_PS_TMAX) v = n ? mx : 0.0f;
+                        else if (st == EVREP_PS_TMIN) v = n ? mn : 0.0f;
+                        else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
+                        else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+                    }
+                    vals[c] = v;
+                }
+            } else {
+                const unsigned long long *w64 = reinterpret_cast<const unsigned long long *>(wd + 4);
+                const double mxp = n_pos ? dval(w64[0]) : 0.0, mnp = n_pos ? dval(~w64[1]) : 0.0;
+                const double mxn = n_neg ? dval(w64[2]) : 0.0, mnn = n_neg ? dval(~w64[3]) : 0.0;
+                const double mxz = n_zero ? dval(w64[4]) : 0.0, mnz = n_zero ? dval(~w64[5]) : 0.0;
+                double mxa = 0.0, mna = 0.0;
+                bool hv = false;
+                if (n_pos) { mxa = mxp; mna = mnp; hv = true; }
+                if (n_neg) { mxa = hv ? fmax(mxa, mxn) : mxn; mna = hv ? fmin(mna, mnn) : mnn; hv = true; }
+                if (n_zero) { mxa = hv ? fmax(mxa, mxz) : mxz; mna = hv ? fmin(mna, mnz) : mnz; }
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    float v = 0.0f;
+                    if (c < C) {
+                        const int k = P.pol[c], st = P.stat[c];
+                        const int n = k == EVREP_PS_POS ? n_pos : (k == EVREP_PS_NEG ? n_neg : n_any);
+                        const double mx = k == EVREP_PS_POS ? mxp : (k == EVREP_PS_NEG ? mxn : mxa);
+                        const double mn = k == EVREP_PS_POS ? mnp : (k == EVREP_PS_NEG ? mnn : mna);
+                        if (st == EVREP_PS_COUNT) v = (float)n;
+                        else if (st == EVREP_PS_TMAX) v = n ? (float)mx : 0.0f;
+                        else if (st == EVREP_PS_TMIN) v = n ? (float)mn : 0.0f;
+                        else if (st == EVREP_PS_FLAG) v = n ? 1.0f : 0.0f;
+                        else if (st == EVREP_PS_EXP) v = (float)exp_neg_range(-(1.0 - (n ? mx : 0.0)) / P.tau);
+                        else if (st == EVREP_PS_SIGNED) v = (float)n_pos - (float)n_neg;
+                    }
+                    vals[c] = v;
+                }
+            }
+        }
+        wave_phase();   // the batch's words are in registers: its values may take their place
+        if (px < g.npix) {
+            float *mine = tile + (size_t)px * C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) if (c < C) mine[c] = vals[c];
+        }
+        wave_phase();
+    }
+    float *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * C;
+    tile_store(tile, g.npix * C, dst);
 }
 
 // --------------------------------------------------------------------------------------------

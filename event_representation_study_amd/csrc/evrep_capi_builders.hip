@@ -11,6 +11,20 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     if (rc) return rc;
     if (stack_size <= 0 || stack_size > EVREP_MAX_CHANNELS || !out) return EVREP_EINVAL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (plan->reserved == 2 && !(plan->flags & EVREP_PLAN_X_ESTACK_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass: the streaming form (k_event_stack_stream) -- one launch, every unit, no hot list
+        UnitCfg us = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);
+        us.span = 1; us.merge = 0; us.hold = 0;
+        unit_cfg_geometry(us, plan);
+        const UnitCfg &uc = us;
+        constexpr int kRB = 4;
+#define ESS_LAUNCH(CM) k_event_stack_stream<CM, kRB><<<SPAN_GRID(1), kWave, event_stack_stream_lds_bytes(stack_size, kChunkPx, kRB), stream>>>( \
+            bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, stack_size, premap, scale, out)
+        if (stack_size <= 8) ESS_LAUNCH(8); else if (stack_size <= 12) ESS_LAUNCH(12); else ESS_LAUNCH(16);
+#undef ESS_LAUNCH
+        LAUNCH_CHECK("k_event_stack_stream");
+        return EVREP_OK;
+    }
     const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
     // EventStack reads the last record of a pixel only: a unit beyond the record stage keeps one (rank, polarity) word per pixel
@@ -243,6 +257,23 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
     // circle windows 230 -> 129 us, the other clustered streams within 3 % (TORE, whose sweep is heavier and cannot be sliced: 124
     // -> 142 us on the config 2 circle, so its two-chunk units stay)
     if (span == 2) uc.xflags |= 2;
+    if (plan->reserved == 2 && !(plan->flags & EVREP_PLAN_X_POLSTATS_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass: the streaming form (k_polstats_stream) -- one launch, every unit, no hot list
+        UnitCfg us = uc;
+        us.span = 1; us.merge = 0; us.hold = 0;
+        unit_cfg_geometry(us, plan);
+        const UnitCfg &uc = us;
+        constexpr int kRB = 4;
+        bool any_exp = false;
+        for (int c = 0; c < C; ++c) any_exp = any_exp || stat[c] == EVREP_PS_EXP;
+        const bool k32 = !any_exp && C <= 8;   // float32 extremes: exact for every statistic but EXP (k_polstats_stream)
+#define PSS_LAUNCH(CM, K32) k_polstats_stream<CM, kRB, K32><<<SPAN_GRID(1), kWave, polstats_stream_lds_bytes(kChunkPx, kRB, K32), stream>>>( \
+                bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, us, out)
+        if (k32) PSS_LAUNCH(8, true); else if (C <= 8) PSS_LAUNCH(8, false); else PSS_LAUNCH(16, false);
+#undef PSS_LAUNCH
+        LAUNCH_CHECK("k_polstats_stream");
+        return EVREP_OK;
+    }
     // dense windows (every unit beyond the record stage): the main launch sweeps order-free itself (k_polstats, SM) with a stage
     // that holds the unit's fourteen words per pixel; nothing is deferred and there is no hot launch
     const double per_chunk_ps = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);

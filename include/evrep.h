@@ -84,6 +84,8 @@ typedef struct evrep_plan {
 #define EVREP_PLAN_NO_FUSED_SCATTER 16u /* three-kernel pass: separate scan and scatter kernels */
 #define EVREP_PLAN_X_SPAN2 64u          /* experiment: float64 MDES units of two 128-pixel chunks (NOTES.md 8) */
 #define EVREP_PLAN_X_TAIL_MERGE 256u    /* experiment: a row's last unit also takes a short tail chunk (NOTES.md r04: slower) */
+#define EVREP_PLAN_X_POLSTATS_ORDERED 65536u /* A/B: the n_imagenet accumulators by k_polstats also where r06 streams them (k_polstats_stream) */
+#define EVREP_PLAN_X_ESTACK_ORDERED 131072u /* A/B: EventStack by k_event_stack also where r06 streams it (k_event_stack_stream) */
 #define EVREP_PLAN_X_TORE_ORDERED 32768u  /* A/B: TORE by the ordered / handed-over paths (k_tore) also where r06 streams it (k_tore_stream) */
 #define EVREP_PLAN_X_VOXEL_ORDERED 16384u /* A/B: the voxel grid by the ordered paths (k_voxel) also after the key-sorted pass,
                                              where r06 streams it (k_voxel_stream); same tensors bit for bit */
