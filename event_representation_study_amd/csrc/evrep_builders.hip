@@ -1748,6 +1748,143 @@ __device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, 
 }
 
 // --------------------------------------------------------------------------------------------
+// r06: the STREAM front end shared by the order-free builders after the key-sorted pass.
+// Every record of the sensor keys [klo, khi) of window b (consecutive 128-pixel chunks of one row), 64 at a time, in array
+// order: `pre(q)` (optional per-record gather from global memory, issued for every batch of a group before the first `f`) and
+// `f(have, q, aux)`.  Units of up to 64 * RB records: every record load in flight at once, a record's run found by a max-scan over
+// the runs' first positions; larger ones four batches at a time, run by run when the runs fill batches.  No order by pixel, no
+// segment list: what a builder keeps per pixel it keeps by LDS atomics (or elections) on its own tile.
+// head: [64 * RB] words of LDS, srcs: [128].  Returns the unit's record count.
+struct StreamNoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
+template <int RB, typename Pre, typename F>
+__device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
+                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f) {
+    const int lane = threadIdx.x;
+    uint32_t a = 0, khi_v = 0;
+    if (lane < bv.nblk) {
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+        a = tb[klo];
+        khi_v = tb[khi];
+    }
+    uint32_t len = khi_v - a;
+    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
+    if (nb <= 0) return 0u;
+    if (lane >= nb) { a = 0; len = 0; }
+    const uint32_t incl = wave_incl_scan(len);
+    const uint32_t pre = incl - len;
+    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (nrec == 0u) return 0u;
+    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+    const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+    if (nrec <= (uint32_t)(64 * RB)) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
+        srcs[lane] = src;
+        wave_phase();
+        if (len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+        wave_phase();
+        Rec8 q[RB];
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            q[i] = make_uint2(0u, 0u);
+            if ((uint32_t)(64 * i) < nrec) {   // uniform
+                const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+                const uint32_t j = (uint32_t)(64 * i + lane);
+                if (j < nrec) q[i] = s8[srcs[k] + j];
+            }
+        }
+        uint2 aux[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            aux[i] = make_uint2(0u, 0u);
+            if ((uint32_t)(64 * i + lane) < nrec) aux[i] = pre_f(q[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
+        return nrec;
+    }
+    constexpr int G = 4;
+    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+    const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
+    uint32_t *rt = srcs;   // [2][64]
+    if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
+    wave_phase();
+    auto src_of = [&](uint32_t j) -> uint32_t {
+        if (nb <= kBsChainBlocks) {
+            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t prev = sx;
+            for (int k = 1; k < nb; ++k) {
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                sx += (j >= pk) ? sk - prev : 0u;
+                prev = sk;
+            }
+            return sx + j;
+        }
+        uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1 && rt[mid] <= j;
+            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+        }
+        return rt[64 + lo] + j;
+    };
+    int rk_ = 0;
+    uint32_t ro_ = 0;
+    bool more = true;
+    while (more) {
+        Rec8 q[G];
+        uint32_t bcnt[G];
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            bcnt[sl] = 0u;
+            uint32_t addr = 0u;
+            if (by_run) {
+                uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                if (rk_ < nb) {
+                    addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                    bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                    ro_ += kWave;
+                }
+            } else {
+                const uint32_t j0 = ro_;
+                if (j0 < nrec) {
+                    bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
+                    if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
+                    ro_ += kWave;
+                }
+            }
+            q[sl] = make_uint2(0u, 0u);
+            if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
+        }
+        if (by_run) {
+            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
+            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+            more = rk_ < nb;
+        } else {
+            more = ro_ < nrec;
+        }
+        uint2 aux[G];
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            aux[sl] = make_uint2(0u, 0u);
+            if ((uint32_t)lane < bcnt[sl]) aux[sl] = pre_f(q[sl]);
+        }
+#pragma unroll
+        for (int sl = 0; sl < G; ++sl) {
+            if (bcnt[sl] == 0u) break;   // uniform
+            f((uint32_t)lane < bcnt[sl], q[sl], aux[sl]);
+        }
+    }
+    return nrec;
+}
+
+// --------------------------------------------------------------------------------------------
 // A3/A4/A5: MixedDensityEventStack.stack + Operations
 // (representation_search/mixed_density_event_stack.py:25-151, operations.py:15-89)
 // --------------------------------------------------------------------------------------------
@@ -2284,6 +2421,234 @@ __global__ __launch_bounds__(kWave, HOT ? ((MdesIsErgo12<D>::value && sizeof(Out
     });
 }
 
+
+// --------------------------------------------------------------------------------------------
+// A5 (r06), after the key-sorted pass: ERGO-12 as a STREAM (optimized_representation.py:87-115 over mixed_density_event_stack.py /
+// operations.py, as mdes_unit's split path reads them).  Ten of the twelve channels are order-free and live as integer words per pixel
+// of the unit, bumped by LDS atomics in ONE sweep of the unit's records in array order (no grouping, no stage, no spill slot, no hot
+// launch); the two float64 sums that have to run in array order -- ch6 (w2, timestamp_pos, mean) and ch1 (w3, timestamp_neg,
+// variance), a sixth of the records each -- are added by the record's own lane after a leader election per pixel and batch (the
+// lowest pending lane of a pixel goes first: k_voxel_stream's rounds), the normalised timestamp's division formed one record per
+// lane.  A window that holds polarity values outside {-1, 0, 1} (escaped in its 8-byte records) cannot keep ch0 / ch3 as integer
+// counts (the sums of p and p^2 may leave the integers float64 holds exactly): there EVERY record goes through the election and
+// those sums run in array order too.  Then a lane per pixel forms the twelve values (mdes_unit's finish) over the pixel's own
+// state and the unit leaves as one coalesced burst.
+// State of pixel px, 20 words:  0 ch0 #(p > 0), 1 ch0 #(p < 0), 2 ch0 #(p == 0), 3 ch5 n, 4 ch3 #(p > 0), 5 ch3 #(p < 0), 6 presence
+// bits by channel, 7-9 max (t - tmin) of ch8 / ch9 / ch10, 10 n6, 11 n1, 12-13 sum6, 14-15 sum1, 16-17 sumsq1, 18-19 (escaped) sumsq0;
+// escaped windows: 0-1 sum0 (float64), 2 n0, 4-5 sum3 (float64).
+// LDS: state [npixa * 20] u32, overlaid by the tile [npixa * 12] OutT (float64: written from the last pixel batch down) | tag [npixa] |
+// head [64 * RB] | srcs [128]
+constexpr int kErgoStreamWords = 20;
+__host__ __device__ inline size_t mdes_stream_lds_bytes(int npixa, size_t elem, int rb) {
+    const size_t st = (size_t)npixa * kErgoStreamWords * 4, tl = (size_t)npixa * 12 * elem;
+    return align16(st > tl ? st : tl) + (size_t)npixa * 4 + (size_t)(64 * rb) * 4 + 128 * 4;
+}
+#ifndef EVREP_MS_WAVES
+#define EVREP_MS_WAVES 4
+#endif
+template <typename OutT, int RB>
+__global__ __launch_bounds__(kWave, EVREP_MS_WAVES) void k_mdes_stream(BinView bv, const int64_t *__restrict__ off, int H, int W, int nchunk,
+                                                                    UnitCfg uc, double scale, OutT *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    using T = Ergo12Table;
+    constexpr int C = 12, NWD = kErgoStreamWords;
+    const int lane = threadIdx.x;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    int chunk, nch;
+    const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+    const int b = g.b;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const MetaRaw mraw = meta_prefetch(bv, b);
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    const size_t st_bytes = (size_t)npixa * NWD * 4, tl_bytes = (size_t)npixa * C * sizeof(OutT);
+    uint32_t *words = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *tag = reinterpret_cast<uint32_t *>(smem + align16(st_bytes > tl_bytes ? st_bytes : tl_bytes));
+    uint32_t *head = tag + npixa;
+    uint32_t *srcs = head + 64 * RB;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(words);
+        const int nvec = (g.npix * NWD + 3) / 4;
+        for (int v = lane; v < nvec; v += kWave) z[v] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *t4 = reinterpret_cast<uint4 *>(tag);
+        for (int v = lane; v * 4 < npixa; v += kWave) t4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    const WindowMeta m = meta_finish(bv, off, b, mraw);
+    const int32_t tmin = m.tmin;
+    const double interval = (double)((int64_t)m.tmax - (int64_t)tmin);   // t_s = (t - t.min()) / (t.max() - t.min())  (:33,112-114)
+    const MdesWindows mw = mdes_windows(n_win);
+    const bool escaped = (m.status & kStEscaped) != 0u;   // wave-uniform
+    // per polarity class k = 0 / 1 / 2 (p == -1 / 0 / +1) the channels that take a record of the class; `many`: the channels that take
+    // every record (the only ones an escaped polarity value can hit).  mdes_unit's set-up: an out-of-range index inside a channel's rows
+    // raises in torch_scatter -> zero channel (no hits); timestamp_neg / count_neg fall back to p == 0 when the window has no p == -1.
+    uint32_t a0 = 0, a1 = 0, a2 = 0, many = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int wi = T::kWin[c], f = T::kFunc[c];
+        uint32_t cls = 7u;
+        int field = 0;
+        if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { cls = 4u; field = 1; }
+        if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
+            const bool has_neg = (m.neg_flags >> wi) & 1u;   // operations.py:59-61,78-80
+            cls = has_neg ? 1u : 2u;
+            field = has_neg ? 2 : 3;
+        }
+        if (n_win <= 0 || ((m.oob_flags >> (7 * field + wi)) & 1u)) cls = 0u;
+        a0 |= (cls & 1u) << c; a1 |= ((cls >> 1) & 1u) << c; a2 |= ((cls >> 2) & 1u) << c;
+        if (cls == 7u) many |= 1u << c;
+    }
+    const uint64_t pmask = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32);
+    const int4 *evw = bv.ev + beg;
+    const int c0 = g.c0;
+    wave_phase();
+    stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, g.row * nchunk + chunk, g.row * nchunk + chunk + nch, head, srcs, StreamNoPre(),
+        [&](bool have, const Rec8 &q, const uint2 &) {
+            const uint32_t px = have ? ((q.y & 511u) - (uint32_t)c0) & 511u : 0u;
+            const int rank = (int)(q.y >> 11);
+            const uint32_t p2 = (q.y >> 9) & 3u;
+            int p = (int)p2 - 1;
+            if (have && p2 == 3u) p = evw[rank].w;
+            const uint32_t tt = (uint32_t)((int64_t)(int32_t)q.x - (int64_t)tmin);   // 0 <= t - tmin < 2^32
+            uint32_t *wd = words + px * (uint32_t)NWD;
+            // the record's rank windows -> its channels (mdes_unit's sweep: w0 every rank, w1..w3 consecutive thirds, w4..w6 run to the end)
+            uint32_t chans = ergo_chans_of(0);
+            chans |= rank < mw.hi[1] ? ergo_chans_of(1) : (rank < mw.hi[2] ? ergo_chans_of(2) : (rank < mw.hi[3] ? ergo_chans_of(3) : 0u));
+            chans |= rank >= mw.lo[4] ? ergo_chans_of(4) : 0u;
+            chans |= rank >= mw.lo[5] ? ergo_chans_of(5) : 0u;
+            chans |= rank >= mw.lo[6] ? ergo_chans_of(6) : 0u;
+            const uint32_t cmask = p2 == 3u ? many : (uint32_t)(pmask >> (16u * p2));
+            const uint32_t hits = have ? (chans & cmask) : 0u;
+            auto hit = [&](int c) -> bool { return (hits >> c) & 1u; };
+            if (!escaped) {
+                if (hit(0)) atomicAdd(wd + (p > 0 ? 0 : (p < 0 ? 1 : 2)), 1u);
+                if (hit(3) && p != 0) atomicAdd(wd + (p > 0 ? 4 : 5), 1u);
+            }
+            if (hit(5)) atomicAdd(wd + 3, 1u);
+            // presence bits by channel; bit 31: the pixel holds a record at all (an EMPTY pixel is +0 unscaled, as the ordered paths leave it)
+            const uint32_t bits = hits & ((1u << 2) | (1u << 4) | (1u << 7) | (1u << 11) | (1u << 8) | (1u << 9) | (1u << 10));
+            if (have) atomicOr(wd + 6, bits | 0x80000000u);
+            if (hit(8)) atomicMax(wd + 7, tt);
+            if (hit(9)) atomicMax(wd + 8, tt);
+            if (hit(10)) atomicMax(wd + 9, tt);
+            // the ordered part: in array order per pixel
+            const bool h6 = hit(6), h1 = hit(1);
+            const bool h0 = escaped && hit(0), h3 = escaped && hit(3);
+            bool pend = h6 || h1 || h0 || h3;
+            if (__any(pend)) {
+                const double ts = (double)tt / interval;   // the digest: one division per record and lane (mixed_density_event_stack.py:112-114)
+                const double pv = (double)p;
+                while (__any(pend)) {
+                    if (pend) atomicMin(&tag[px], (uint32_t)lane);
+                    wave_phase();
+                    const bool win = pend && tag[px] == (uint32_t)lane;
+                    wave_phase();
+                    if (win) {
+                        double *dd = reinterpret_cast<double *>(wd);
+                        if (h6) { dd[6] = dd[6] + ts; wd[10] = wd[10] + 1u; }
+                        if (h1) { dd[7] = dd[7] + ts; const double vv = ts * ts; dd[8] = dd[8] + vv; wd[11] = wd[11] + 1u; }
+                        if (h0) { dd[0] = dd[0] + pv; const double vv = pv * pv; dd[9] = dd[9] + vv; wd[2] = wd[2] + 1u; }
+                        if (h3) { dd[2] = dd[2] + pv; }
+                        tag[px] = ~0u;
+                        pend = false;
+                    }
+                    wave_phase();
+                }
+            }
+        });
+    wave_phase();
+    // A lane per NON-EMPTY pixel: the twelve values from the pixel's state (mdes_unit's finish, channel by channel).  The non-empty
+    // pixels of the unit are listed first (sparse windows: a sixth of the pixels), every round's values wait in registers until all
+    // states are read, then the tile -- which overlays the states -- is zero-filled and patched.  Float64 divisions (~35 instructions
+    // each for the whole wave) are only entered when some pixel of the wave needs them: x / 1.0 == x.
+    OutT *tile = reinterpret_cast<OutT *>(smem);
+    unsigned char *nelist = reinterpret_cast<unsigned char *>(head);   // [npixa] pixel indices (npixa <= 256)
+    int nne = 0;
+    for (int pt = 0; pt * kWave < g.npix; ++pt) {
+        const int px = pt * kWave + lane;
+        const bool ne = px < g.npix && (words[(uint32_t)px * (uint32_t)NWD + 6] >> 31);
+        const uint64_t mne = __ballot(ne);
+        if (ne) nelist[nne + __popcll(mne & ((1ull << lane) - 1ull))] = (unsigned char)px;
+        nne += __popcll(mne);
+    }
+    wave_phase();
+    constexpr int kRounds = 2;   // npixa = 128: at most two rounds of 64 non-empty pixels
+    OutT rv[kRounds][C];
+    int rpx[kRounds];
+#pragma unroll
+    for (int rd = 0; rd < kRounds; ++rd) {
+        rpx[rd] = -1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) rv[rd][c] = (OutT)0;
+        if (rd * kWave < nne) {   // uniform
+            const bool own = rd * kWave + lane < nne;
+            const int px = own ? (int)nelist[rd * kWave + lane] : 0;
+            const uint32_t *wd = words + (uint32_t)px * (uint32_t)NWD;
+            const double *dd = reinterpret_cast<const double *>(wd);
+            double r[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) r[c] = 0.0;
+            const uint32_t fl = own ? wd[6] : 0u;
+            // ch0 (w0, polarity, variance): n, sum p, sum p^2
+            int n0 = 0; double s0 = 0.0, q0 = 0.0;
+            if (own) {
+                if (!escaped) { const int np0 = (int)wd[0], nn0 = (int)wd[1], nz0 = (int)wd[2]; n0 = np0 + nn0 + nz0; s0 = (double)(np0 - nn0); q0 = (double)(np0 + nn0); }
+                else { n0 = (int)wd[2]; s0 = dd[0]; q0 = dd[9]; }
+            }
+            {
+                double mean = s0, mean2 = q0;
+                if (__any(n0 > 1)) { const double d = (double)(n0 < 1 ? 1 : n0); mean = n0 > 1 ? s0 / d : s0; mean2 = n0 > 1 ? q0 / d : q0; }
+                const double mm = mean * mean;
+                r[0] = mean2 - mm;
+            }
+            // ch1 (w3, timestamp_neg, variance)
+            {
+                const int n1 = own ? (int)wd[11] : 0;
+                const double s1 = own ? dd[7] : 0.0, q1 = own ? dd[8] : 0.0;
+                double mean = s1, mean2 = q1;
+                if (__any(n1 > 1)) { const double d = (double)(n1 < 1 ? 1 : n1); mean = n1 > 1 ? s1 / d : s1; mean2 = n1 > 1 ? q1 / d : q1; }
+                const double mm = mean * mean;
+                r[1] = mean2 - mm;
+            }
+            r[2] = (fl >> 2) & 1u ? 1.0 : 0.0;                                        // (w2, count_neg, mean)
+            if (own) r[3] = escaped ? dd[2] : (double)((int)wd[4] - (int)wd[5]);       // (w6, polarity, sum)
+            r[4] = (fl >> 4) & 1u ? 1.0 : 0.0;                                        // (w5, count_pos, mean)
+            if (own) r[5] = (double)(int)wd[3];                                        // (w6, count, sum)
+            {                                                                          // (w2, timestamp_pos, mean)
+                const int n6 = own ? (int)wd[10] : 0;
+                const double s6 = own ? dd[6] : 0.0;
+                r[6] = s6;
+                if (__any(n6 > 1)) r[6] = n6 > 1 ? s6 / (double)n6 : s6;
+            }
+            r[7] = (fl >> 7) & 1u ? 1.0 : 0.0;                                        // (w5, count_neg, mean)
+            // (w1, timestamp_neg, max), (w0, timestamp_pos, max), (w4, timestamp, max): the quotient of the maximum
+            if (__any((fl >> 8) & 1u)) r[8] = (fl >> 8) & 1u ? (double)wd[7] / interval : 0.0;
+            if (__any((fl >> 9) & 1u)) r[9] = (fl >> 9) & 1u ? (double)wd[8] / interval : 0.0;
+            if (__any((fl >> 10) & 1u)) r[10] = (fl >> 10) & 1u ? (double)wd[9] / interval : 0.0;
+            r[11] = (fl >> 11) & 1u ? 1.0 : 0.0;                                      // (w1, count, mean)
+            if (scale != 1.0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) r[c] = r[c] * scale;
+            }
+            if (own) rpx[rd] = px;
+#pragma unroll
+            for (int c = 0; c < C; ++c) rv[rd][c] = (OutT)r[c];
+        }
+    }
+    wave_phase();   // every state is read: the tile may take the states' place
+    tile_fill(tile, g.npix, C, (const OutT *)nullptr);
+    wave_phase();
+#pragma unroll
+    for (int rd = 0; rd < kRounds; ++rd) {
+        if (rpx[rd] >= 0) {
+            OutT *mine = tile + (size_t)rpx[rd] * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) mine[c] = rv[rd][c];
+        }
+    }
+    wave_phase();
+    OutT *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * C;
+    tile_store(tile, g.npix * C, dst);
+}
 
 // "SBT" stacking (mixed_density_event_stack.py:76-107): eight windows cut by the normalised time t_s = (t - tmin) / (tmax -
 // tmin) -- w0 all, w1..w3 i/3 <= t_s <= (i+1)/3 (both ends inclusive), w4..w7 t_s <= 1/2, 1/4, 1/8, 1/16.  On ascending
@@ -2878,143 +3243,6 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 12 ? EVREP_TORE_WAVES : 1))
         };
         emit_chunk<float, CM, HOT>(ur, digest, row * W + sc_lo, npix, C, dst, w, (const float *)w.bg, reduce);
     });
-}
-
-// --------------------------------------------------------------------------------------------
-// r06: the STREAM front end shared by the order-free builders after the key-sorted pass.
-// Every record of the sensor keys [klo, khi) of window b (consecutive 128-pixel chunks of one row), 64 at a time, in array
-// order: `pre(q)` (optional per-record gather from global memory, issued for every batch of a group before the first `f`) and
-// `f(have, q, aux)`.  Units of up to 64 * RB records: every record load in flight at once, a record's run found by a max-scan over
-// the runs' first positions; larger ones four batches at a time, run by run when the runs fill batches.  No order by pixel, no
-// segment list: what a builder keeps per pixel it keeps by LDS atomics (or elections) on its own tile.
-// head: [64 * RB] words of LDS, srcs: [128].  Returns the unit's record count.
-struct StreamNoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
-template <int RB, typename Pre, typename F>
-__device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
-                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f) {
-    const int lane = threadIdx.x;
-    uint32_t a = 0, khi_v = 0;
-    if (lane < bv.nblk) {
-        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
-        a = tb[klo];
-        khi_v = tb[khi];
-    }
-    uint32_t len = khi_v - a;
-    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
-    if (nb <= 0) return 0u;
-    if (lane >= nb) { a = 0; len = 0; }
-    const uint32_t incl = wave_incl_scan(len);
-    const uint32_t pre = incl - len;
-    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (nrec == 0u) return 0u;
-    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
-    const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
-    if (nrec <= (uint32_t)(64 * RB)) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
-        srcs[lane] = src;
-        wave_phase();
-        if (len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
-        wave_phase();
-        Rec8 q[RB];
-        uint32_t carry = 0u;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            q[i] = make_uint2(0u, 0u);
-            if ((uint32_t)(64 * i) < nrec) {   // uniform
-                const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
-                const uint32_t j = (uint32_t)(64 * i + lane);
-                if (j < nrec) q[i] = s8[srcs[k] + j];
-            }
-        }
-        uint2 aux[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            aux[i] = make_uint2(0u, 0u);
-            if ((uint32_t)(64 * i + lane) < nrec) aux[i] = pre_f(q[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
-        return nrec;
-    }
-    constexpr int G = 4;
-    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
-    const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
-    uint32_t *rt = srcs;   // [2][64]
-    if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
-    wave_phase();
-    auto src_of = [&](uint32_t j) -> uint32_t {
-        if (nb <= kBsChainBlocks) {
-            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
-            uint32_t prev = sx;
-            for (int k = 1; k < nb; ++k) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
-                sx += (j >= pk) ? sk - prev : 0u;
-                prev = sk;
-            }
-            return sx + j;
-        }
-        uint32_t lo = 0, hi = (uint32_t)nb;
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const bool go = hi - lo > 1 && rt[mid] <= j;
-            if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
-        }
-        return rt[64 + lo] + j;
-    };
-    int rk_ = 0;
-    uint32_t ro_ = 0;
-    bool more = true;
-    while (more) {
-        Rec8 q[G];
-        uint32_t bcnt[G];
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) {
-            bcnt[sl] = 0u;
-            uint32_t addr = 0u;
-            if (by_run) {
-                uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-                if (rk_ < nb) {
-                    addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
-                    bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
-                    ro_ += kWave;
-                }
-            } else {
-                const uint32_t j0 = ro_;
-                if (j0 < nrec) {
-                    bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
-                    if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
-                    ro_ += kWave;
-                }
-            }
-            q[sl] = make_uint2(0u, 0u);
-            if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
-        }
-        if (by_run) {
-            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-            more = rk_ < nb;
-        } else {
-            more = ro_ < nrec;
-        }
-        uint2 aux[G];
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) {
-            aux[sl] = make_uint2(0u, 0u);
-            if ((uint32_t)lane < bcnt[sl]) aux[sl] = pre_f(q[sl]);
-        }
-#pragma unroll
-        for (int sl = 0; sl < G; ++sl) {
-            if (bcnt[sl] == 0u) break;   // uniform
-            f((uint32_t)lane < bcnt[sl], q[sl], aux[sl]);
-        }
-    }
-    return nrec;
 }
 
 // --------------------------------------------------------------------------------------------

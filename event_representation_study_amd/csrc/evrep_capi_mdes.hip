@@ -1,5 +1,6 @@
 // evrep_capi_mdes.hip -- the extern "C" surface, part 2: MixedDensityEventStack / Operations / ERGO-12 (k_mdes).
 #define EVREP_TU_MDES 1
+#include <cstdlib>
 #include "evrep_capi_builders.h"
 
 extern "C" {
@@ -38,6 +39,32 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
     bool ergo = C == Ergo12Table::kC && bounds == nullptr;
     for (int c = 0; ergo && c < C; ++c)
         ergo = window[c] == Ergo12Table::kWin[c] && func[c] == Ergo12Table::kFunc[c] && agg[c] == Ergo12Table::kAgg[c];
+    if (ergo && plan->reserved == 2 && !(plan->flags & EVREP_PLAN_X_MDES_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass: ERGO-12 as a stream (k_mdes_stream) -- one launch, every unit, no hot list -- where it wins
+        // (measured, r06, build launch(es) in us, ordered / stream; the stream's fixed cost per wave -- 10 KB of state to zero,
+        // twelve values per non-empty pixel from scratch, 12-14 KB of LDS = 11-13 waves per CU -- loses on sparse uniform windows,
+        // where the ordered builder's sparse emit is at the store roof):
+        //   float32: Gen1 shape 55.6 / 56.5 uniform, 78 / 78 circle, 97 / 67 edges; 8 x 500 000 events 82 / 71;
+        //            640x480 x 50 000 (21 records per unit) 82 / 147, 1 Mpx x 200 000 77 / 116 (circle 222 / 129)
+        //   float64: Gen1 shape 64.8 / 67.5, circle 73 / 86, edges 86 / 77; 8 x 500 000 events 99 / 85; 640x480 x 50 000 152 / 188
+        const double per_chunk_ms = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+        const bool use = out_dtype == EVREP_F32 ? per_chunk_ms > 28.0 : per_chunk_ms > 100.0;
+        if (use) {
+            UnitCfg us = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
+            us.span = 1; us.merge = 0; us.hold = 0;
+            unit_cfg_geometry(us, plan);
+            const UnitCfg &uc = us;
+            constexpr int kRB = 4;
+            if (out_dtype == EVREP_F64)
+                k_mdes_stream<double, kRB><<<SPAN_GRID(1), kWave, mdes_stream_lds_bytes(kChunkPx, 8, kRB), stream>>>(
+                    bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<double *>(out));
+            else
+                k_mdes_stream<float, kRB><<<SPAN_GRID(1), kWave, mdes_stream_lds_bytes(kChunkPx, 4, kRB), stream>>>(
+                    bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<float *>(out));
+            LAUNCH_CHECK("k_mdes_stream");
+            return EVREP_OK;
+        }
+    }
     UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
     if ((plan->flags & EVREP_PLAN_X_SPAN2) && plan->nchunk >= 2) { uc.span = 2; uc.stage = 128; unit_cfg_geometry(uc, plan); }
     const int span = uc.span;
