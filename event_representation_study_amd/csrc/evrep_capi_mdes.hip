@@ -48,7 +48,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
         //            640x480 x 50 000 (21 records per unit) 82 / 147, 1 Mpx x 200 000 77 / 116 (circle 222 / 129)
         //   float64: Gen1 shape 64.8 / 67.5, circle 73 / 86, edges 86 / 77; 8 x 500 000 events 99 / 85; 640x480 x 50 000 152 / 188
         const double per_chunk_ms = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
-        const bool use = out_dtype == EVREP_F32 ? per_chunk_ms > 28.0 : per_chunk_ms > 100.0;
+        const bool use = (plan->flags & EVREP_PLAN_X_MDES_STREAM) || (out_dtype == EVREP_F32 ? per_chunk_ms > 28.0 : per_chunk_ms > 100.0);
         if (use) {
             UnitCfg us = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
             us.span = 1; us.merge = 0; us.hold = 0;

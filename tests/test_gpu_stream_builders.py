@@ -1,0 +1,103 @@
+"""-m gpu: the STREAM builders of round 6 (k_voxel_stream, k_tore_stream, k_event_stack_stream, k_polstats_stream,
+k_mdes_stream) against the oracle AND against the ordered kernels they replace after the key-sorted pass (the
+EVREP_X_*_ORDERED plan flags switch those back on): same tensors bit for bit, on uniform, clustered and degenerate
+windows, both polarity encodings, escaped polarity values, unsorted timestamps, empty and one-event windows."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bit_equal
+
+from event_representation_study_amd.synthetic import GENERATORS, make_events
+
+pytestmark = pytest.mark.gpu
+
+ORDERED = ("EVREP_X_VOXEL_ORDERED", "EVREP_X_TORE_ORDERED", "EVREP_X_POLSTATS_ORDERED", "EVREP_X_ESTACK_ORDERED", "EVREP_X_MDES_ORDERED")
+
+
+def _windows(kind, W, H):
+    rng = np.random.default_rng(17)
+    if kind == "uniform":
+        return [make_events(n, W, H, seed=50 + i, polarity=("pm1" if i % 2 else "01")) for i, n in enumerate((3001, 2, 9000))]
+    if kind == "clustered":
+        wins = [GENERATORS["circle"](12000, W, H, seed=3), GENERATORS["edges"](12000, W, H, seed=4)]
+        hot = make_events(6000, W, H, seed=5)                   # one pixel holds 40 % of the window, in bursts
+        idx = np.sort(rng.choice(6000, 2400, replace=False))
+        hot[idx, 0], hot[idx, 1] = W // 3, H // 2
+        return wins + [hot]
+    if kind == "escaped":                                       # arbitrary integer polarity values (operations.py takes them as they come)
+        ev = make_events(5000, W, H, seed=8)
+        ev[:, 3] = rng.integers(-3, 6, size=5000)
+        return [ev, make_events(4000, W, H, seed=9)]
+    if kind == "dense":
+        return [make_events(40000, W, H, seed=11), make_events(40001, W, H, seed=12, polarity="01")]
+    raise ValueError(kind)
+
+
+def _build_all(eng, wins, H, W, monkeypatch, ordered):
+    for name in ORDERED:
+        if ordered:
+            monkeypatch.setenv(name, "1")
+        else:
+            monkeypatch.delenv(name, raising=False)
+    if ordered:
+        monkeypatch.delenv("EVREP_X_MDES_STREAM", raising=False)
+    else:
+        monkeypatch.setenv("EVREP_X_MDES_STREAM", "1")           # the stream at every density (its default gate is by density)
+    eb = eng.EventBatch.from_numpy(wins, H, W)
+    tn = torch.rand(eb.total, dtype=torch.float64, device=eb.device, generator=torch.Generator(device=eb.device).manual_seed(3))
+    out = {"ergo64": eb.optimized(), "ergo32": eb.optimized(dtype=torch.float32), "ergo_x255": eb.optimized(scale=255.0),
+           "es": eb.event_stack(), "tore": eb.tore(6, frame_mode=2), "tore_scaled": eb.tore(6, frame_mode=2, scale=255.0),
+           "voxel": eb.voxel(5), "voxel12": eb.voxel(12, mode=1, scale=255.0), "evl": eb.voxel(9, mode=2),
+           "acc_all": eb.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2]),
+           "acc_exp": eb.polstats(tn, [0, 1, 2, 0], [4, 4, 0, 5], tau=0.3)}
+    bbox = eb.tore(6, frame_mode=0)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items()}
+    res["tore_bbox"] = [t.cpu().numpy() for t in bbox]
+    eb.check_built("stream builders")
+    return res
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "escaped", "dense"])
+def test_stream_builders_equal_ordered_builders_and_oracle(kind, monkeypatch, oracle):
+    from event_representation_study_amd import engine as eng
+    H, W = (60, 200) if kind != "dense" else (48, 160)
+    wins = _windows(kind, W, H)
+    got = _build_all(eng, wins, H, W, monkeypatch, ordered=False)
+    ref = _build_all(eng, wins, H, W, monkeypatch, ordered=True)
+    for k in got:
+        if k == "tore_bbox":
+            for a, b in zip(got[k], ref[k]):
+                assert_bit_equal(a, b, "tore bbox stream vs ordered (%s)" % kind)
+        else:
+            assert_bit_equal(got[k], ref[k], "%s stream vs ordered (%s)" % (k, kind))
+    for b, ev in enumerate(wins):
+        if ev.shape[0] == 0:
+            assert not got["ergo64"][b].any() and not got["es"][b].any()
+            continue
+        assert_bit_equal(got["ergo64"][b], oracle.ergo12(ev, H, W), "ergo12 stream vs oracle (%s, window %d)" % (kind, b))
+        assert_bit_equal(got["es"][b], oracle.event_stack(ev, H, W), "event_stack stream vs oracle (%s, window %d)" % (kind, b))
+        want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
+        np.testing.assert_allclose(got["tore"][b], want, rtol=1e-6, atol=1e-6)
+
+
+def test_stream_builders_on_unsorted_windows(monkeypatch, oracle):
+    """Array order whatever the timestamps are: ERGO-12 (MDES works by index), EventStack (put is last-write-wins), TORE (the
+    reference's np.partition on its k-vector): the streams against the ordered kernels, bit for bit."""
+    from event_representation_study_amd import engine as eng
+    H, W = 60, 200
+    rng = np.random.default_rng(23)
+    wins = []
+    for s in (1, 2):
+        ev = make_events(7000, W, H, seed=70 + s)
+        ev = ev[rng.permutation(ev.shape[0])]
+        wins.append(np.ascontiguousarray(ev))
+    got = _build_all(eng, wins, H, W, monkeypatch, ordered=False)
+    ref = _build_all(eng, wins, H, W, monkeypatch, ordered=True)
+    for k in ("ergo64", "ergo32", "es", "tore", "tore_scaled", "acc_all", "acc_exp"):
+        assert_bit_equal(got[k], ref[k], "%s stream vs ordered on unsorted windows" % k)
+    for a, b in zip(got["tore_bbox"], ref["tore_bbox"]):
+        assert_bit_equal(a, b, "tore bbox stream vs ordered on unsorted windows")
+    for b, ev in enumerate(wins):
+        assert_bit_equal(got["ergo64"][b], oracle.ergo12(ev, H, W), "ergo12 stream vs oracle, unsorted window %d" % b)
