@@ -3039,6 +3039,151 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : EVREP_TS_WAVES) void k_time_surfac
 }
 
 // --------------------------------------------------------------------------------------------
+// A7 (r06), after the key-sorted pass: the time surface as a STREAM.  Slice s of a (pixel, polarity) entry reads ONE event: the last
+// one in array order at or before the slice's cut.  Every record goes, by ONE 64-bit LDS atomicMax, into the word of the FIRST live
+// slice whose cut lies at or behind it (the live cuts ascend strictly); a running maximum over the slices then hands every slice the
+// last event it saw.  What the word holds is a KEY that grows with the event's place in the window:
+//   * ascending integer timestamps, a window of up to 600 tau (every window the dispatcher hands over): the bits of
+//     E = exp((t - tref) / tau) -- ONE exponential per EVENT, one record per lane, all lanes at once -- and a slice's value is
+//     E * fac[s], k_ts_cuts' exp((tref - t_cut) / tau) * scale: k_time_surface's factorised form, now for units of every size
+//     (the ordered builder takes it for fully staged units only: twelve exponentials per touched pixel are what bound it on dense
+//     windows -- 8 x 500 000 events 124 us -- and the two forms differ by an ulp or two, far inside the 1e-5 budget);
+//   * else (a longer window, timestamps that are not ascending): the event's rank; its time is gathered by the rank from the
+//     caller's events and the exponential of (t_event - t_cut) / tau taken per slice and polarity for 64 pixels at a time.
+// No grouping, no stage, no walk, no hot launch, any unit size.  (Float64 timestamps and the caller's array-order flag stay with
+// k_time_surface: the host decides.)
+// LDS: words [npixa * 2 * S] u64, overlaid by the tile [npixa * 2 S] OutT | head | srcs
+__host__ __device__ inline size_t time_surface_stream_lds_bytes(int S, int npixa, size_t elem, int rb) {
+    (void)elem;   // (the words are as wide as a float64 value: the tile always fits their room)
+    return align16((size_t)npixa * 2 * S * 8) + (size_t)(64 * rb) * 4 + 128 * 4;
+}
+template <typename OutT, int CM, int RB>
+__global__ __launch_bounds__(kWave, 4) void k_time_surface_stream(BinView bv, const int64_t *__restrict__ off, const TsCuts *__restrict__ cuts,
+                                                              int H, int W, int nchunk, UnitCfg uc, int S, double tau, int premap,
+                                                              double scale, OutT *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int SM = CM / 2;
+    const int lane = threadIdx.x;
+    const int C = 2 * S;
+    const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+    int chunk, nch;
+    const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+    const int b = g.b;
+    const int64_t beg = off[b];
+    const int64_t n_win = off[b + 1] - beg;
+    const TsCuts *cp = cuts + b;
+    int idx[SM], live[SM];
+#pragma unroll
+    for (int q = 0; q < SM; ++q) { idx[q] = cp->idx[q]; live[q] = cp->live[q]; }
+    const int tref = cp->tref;
+    const MetaRaw mraw = meta_prefetch(bv, b);
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(smem);
+    uint32_t *head = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * C * 8));
+    uint32_t *srcs = head + 64 * RB;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(words);
+        const int nvec = (g.npix * C + 1) / 2;
+        for (int v = lane; v < nvec; v += kWave) z[v] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    int nlive = 0;   // the live slices are a prefix (k_ts_cuts)
+#pragma unroll
+    for (int q = 0; q < SM; ++q) nlive += (q < S && live[q]) ? 1 : 0;
+    const WindowMeta m = meta_finish(bv, off, b, mraw);
+    const bool byrank = cp->direct != 0 || (m.status & EVREP_ST_UNSORTED) != 0u;   // wave-uniform
+    const double inv_tau = 1.0 / tau;
+    const int4 *evw = bv.ev + beg;
+    const int c0 = g.c0;
+    wave_phase();
+    stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, g.row * nchunk + chunk, g.row * nchunk + chunk + nch, head, srcs, StreamNoPre(),
+        [&](bool have, const Rec8 &q8, const uint2 &) {
+            const uint32_t px = have ? ((q8.y & 511u) - (uint32_t)c0) & 511u : 0u;
+            const uint32_t rank = q8.y >> 11, p2 = (q8.y >> 9) & 3u;
+            int p = (have && p2 == 3u) ? evw[rank].w : (int)p2 - 1;
+            if (premap & 1) p = (int)(int8_t)(int)((double)(p + 1) / 2.0);   // ((p + 1) / 2).astype(int8)  (gen1_transforms.py:70-72)
+            int q0 = 0;   // the live slices whose cut lies strictly before the event
+#pragma unroll
+            for (int q = 0; q < SM; ++q) q0 += (q < nlive && idx[q] < (int)rank) ? 1 : 0;
+            unsigned long long key = (unsigned long long)rank + 1ull;
+            if (!byrank) {   // one exponential per event: E > 0, and E grows with t, so its bits order as the events do
+                const double E = exp_neg_range(((double)(int32_t)q8.x - (double)tref) * inv_tau);
+                key = (unsigned long long)__double_as_longlong(E) + 1ull;   // (+ 1: an E that underflowed to +0 still marks the entry as touched)
+            }
+            if (have && q0 < nlive) atomicMax(words + (px * 2u + (uint32_t)(p & 1)) * (uint32_t)S + (uint32_t)q0, key);
+        });
+    wave_phase();
+    OutT *tile = reinterpret_cast<OutT *>(smem);
+    const int nbatch = (g.npix + kWave - 1) / kWave;
+    for (int pt = 0; pt < nbatch; ++pt) {   // (a value is never wider than its word: a batch's values end in front of the next batch's words)
+        const int px = pt * kWave + lane;
+        const bool own = px < g.npix;
+        unsigned long long last[2][SM];   // the last event each slice saw: a running maximum over the slices
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            unsigned long long run = 0ull;
+#pragma unroll
+            for (int q = 0; q < SM; ++q) {
+                if (q < S && own) { const unsigned long long wv = words[((uint32_t)px * 2u + (uint32_t)pl) * (uint32_t)S + (uint32_t)q]; run = wv > run ? wv : run; }
+                last[pl][q] = (q < nlive) ? run : 0ull;
+            }
+        }
+        OutT vals[CM];
+        if (!byrank) {
+#pragma unroll
+            for (int q = 0; q < SM; ++q) {
+                OutT v0 = (OutT)0, v1 = (OutT)0;
+                if (q < S) {
+                    const double fq = gload_f64(&cp->fac[q]);
+                    v0 = last[0][q] ? (OutT)(__longlong_as_double((long long)(last[0][q] - 1ull)) * fq) : (OutT)gload_f64(&cp->bg[2 * q]);
+                    v1 = last[1][q] ? (OutT)(__longlong_as_double((long long)(last[1][q] - 1ull)) * fq) : (OutT)gload_f64(&cp->bg[2 * q + 1]);
+                }
+                vals[2 * q] = v0;
+                vals[2 * q + 1] = v1;
+            }
+        } else {
+            double tm[2][SM];   // the events' times, by rank (every gather in flight together)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int q = 0; q < SM; ++q) {
+                    tm[pl][q] = 0.0;
+                    if (last[pl][q]) tm[pl][q] = (double)evw[(uint32_t)last[pl][q] - 1u].z;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SM; ++q) {
+                OutT v0 = (OutT)0, v1 = (OutT)0;
+                if (q < S) {
+                    v0 = (OutT)gload_f64(&cp->bg[2 * q]); v1 = (OutT)gload_f64(&cp->bg[2 * q + 1]);
+                    if (q < nlive) {
+                        const double tc = gload_f64(&cp->tcutf[q]);
+                        if (__any(last[0][q] != 0ull)) {
+                            const double e0 = exp_neg_range((tm[0][q] - tc) * inv_tau) * scale;
+                            if (last[0][q]) v0 = (OutT)e0;
+                        }
+                        if (__any(last[1][q] != 0ull)) {
+                            const double e1 = exp_neg_range((tm[1][q] - tc) * inv_tau) * scale;
+                            if (last[1][q]) v1 = (OutT)e1;
+                        }
+                    }
+                }
+                vals[2 * q] = v0;
+                vals[2 * q + 1] = v1;
+            }
+        }
+        wave_phase();   // the batch's words are in registers: its values may take their place
+        if (own) {
+            OutT *mine = tile + (size_t)px * C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) if (c < C) mine[c] = vals[c];
+        }
+        wave_phase();
+    }
+    OutT *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * C;
+    tile_store(tile, g.npix * C, dst);
+}
+
+// --------------------------------------------------------------------------------------------
 // A8: events2ToreFeature (tore.py:6-83), one sample time per window
 // --------------------------------------------------------------------------------------------
 constexpr int kMaxToreK = 8;

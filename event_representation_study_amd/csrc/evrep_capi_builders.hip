@@ -1,6 +1,7 @@
 // evrep_capi_builders.hip -- the extern "C" surface, part 3: EventStack, TimeSurface, TORE, the voxel grids, the n_imagenet
 // accumulators, EST, the resize taps and the store probe.
 #define EVREP_TU_BUILDERS 1
+#include <cstdlib>
 #include "evrep_capi_builders.h"
 
 extern "C" {
@@ -46,6 +47,16 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     return EVREP_OK;
 }
 
+// where the time surface's stream beats its ordered builder (measured, r06, float64, build launch in us, ordered / stream): Gen1
+// shape 79.8 / 67.1 (circle 75.8 / 73.8, edges 97.3 / 70.0), 8 x 500 000 events at 640x480 124.0 / 79.3; sparse windows lose --
+// 640x480 x 50 000 events (21 records per unit) 177 / 218, 1 Mpx x 200 000 141 / 167 (12 KB of 64-bit words to zero and to scan
+// per unit, 11 waves per CU), so they keep k_time_surface, which is near the store roof there
+static bool ts_stream_wins(const evrep_plan *plan, int32_t out_dtype) {
+    const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    (void)out_dtype;
+    return per_chunk > 28.0;
+}
+
 int evrep_time_surface(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
                        int32_t slices, const int32_t *indices, double tau, int32_t premap, double scale,
                        int32_t out_dtype, void *out, void *stream_) {
@@ -64,6 +75,21 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
     TsCuts *cuts = WS(TsCuts, off_cuts);
     k_ts_cuts<<<plan->B, 64, 0, stream>>>(reinterpret_cast<const int4 *>(events), offsets, slices, indices, tau, scale, cuts, tf);
     LAUNCH_CHECK("k_ts_cuts");
+    if (plan->reserved == 2 && tf == nullptr && !(premap & 2) && ((plan->flags & EVREP_PLAN_X_TS_STREAM) || ts_stream_wins(plan, out_dtype)) && !(plan->flags & EVREP_PLAN_X_TS_ORDERED) && plan->W <= 512 * 8) {
+        // after the key-sorted pass: the streaming form (k_time_surface_stream) -- one launch, every unit, no hot list
+        UnitCfg us = unit_cfg(plan, (size_t)1 << 20, 0, false, false);
+        us.span = 1; us.merge = 0; us.hold = 0;
+        unit_cfg_geometry(us, plan);
+        const UnitCfg &uc = us;
+        constexpr int kRB = 4;
+#define TSS_LAUNCH(T, CM) k_time_surface_stream<T, CM, kRB><<<SPAN_GRID(1), kWave, time_surface_stream_lds_bytes(slices, kChunkPx, sizeof(T), kRB), stream>>>( \
+            bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, us, slices, tau, premap, scale, static_cast<T *>(out))
+        if (out_dtype == EVREP_F64) { if (slices <= 6) TSS_LAUNCH(double, 12); else TSS_LAUNCH(double, 16); }
+        else { if (slices <= 6) TSS_LAUNCH(float, 12); else TSS_LAUNCH(float, 16); }
+#undef TSS_LAUNCH
+        LAUNCH_CHECK("k_time_surface_stream");
+        return EVREP_OK;
+    }
     // windows whose units are practically all fully staged (<= 128 records: everything the key-sorted pass is chosen for, r03;
     // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
     // when ITS unit is fully staged, whatever the binning pass (Gen1 shape 88 -> 80 us)

@@ -95,4 +95,9 @@ def test_order_free_units_with_odd_polarities_and_small_stacks():
         "surface float32 (ordered paths)": lambda eb: eb.time_surface(dtype=torch.float32),
         "surface, raw polarity": lambda eb: eb.time_surface(premap=False),
     }.items():
-        assert_bit_equal(fn(ks).cpu().numpy(), fn(cl).cpu().numpy(), tag)
+        a, b = fn(ks).cpu().numpy(), fn(cl).cpu().numpy()
+        if tag.startswith("surface"):   # r06: the stream's per-event exponentials vs the ordered builder's per-slice ones: an ulp or two
+            np.testing.assert_allclose(a, b, rtol=1e-6 if a.dtype == np.float32 else 1e-13, atol=0, err_msg=tag)
+            assert np.array_equal(a == 0, b == 0), tag
+        else:
+            assert_bit_equal(a, b, tag)

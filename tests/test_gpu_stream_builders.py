@@ -12,7 +12,9 @@ from event_representation_study_amd.synthetic import GENERATORS, make_events
 
 pytestmark = pytest.mark.gpu
 
-ORDERED = ("EVREP_X_VOXEL_ORDERED", "EVREP_X_TORE_ORDERED", "EVREP_X_POLSTATS_ORDERED", "EVREP_X_ESTACK_ORDERED", "EVREP_X_MDES_ORDERED")
+ORDERED = ("EVREP_X_VOXEL_ORDERED", "EVREP_X_TORE_ORDERED", "EVREP_X_POLSTATS_ORDERED", "EVREP_X_ESTACK_ORDERED", "EVREP_X_MDES_ORDERED",
+           "EVREP_X_TS_ORDERED")
+CLOSE = ("ts64", "ts32", "ts_scaled")     # float exponentials: 1e-12 relative between the two forms (budget 1e-5)
 
 
 def _windows(kind, W, H):
@@ -40,14 +42,16 @@ def _build_all(eng, wins, H, W, monkeypatch, ordered):
             monkeypatch.setenv(name, "1")
         else:
             monkeypatch.delenv(name, raising=False)
-    if ordered:
-        monkeypatch.delenv("EVREP_X_MDES_STREAM", raising=False)
-    else:
-        monkeypatch.setenv("EVREP_X_MDES_STREAM", "1")           # the stream at every density (its default gate is by density)
+    for name in ("EVREP_X_MDES_STREAM", "EVREP_X_TS_STREAM"):    # the streams at every density (their default gates are by density)
+        if ordered:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, "1")
     eb = eng.EventBatch.from_numpy(wins, H, W)
     tn = torch.rand(eb.total, dtype=torch.float64, device=eb.device, generator=torch.Generator(device=eb.device).manual_seed(3))
     out = {"ergo64": eb.optimized(), "ergo32": eb.optimized(dtype=torch.float32), "ergo_x255": eb.optimized(scale=255.0),
            "es": eb.event_stack(), "tore": eb.tore(6, frame_mode=2), "tore_scaled": eb.tore(6, frame_mode=2, scale=255.0),
+           "ts64": eb.time_surface(), "ts32": eb.time_surface(dtype=torch.float32), "ts_scaled": eb.time_surface(premap=1, scale=255.0),
            "voxel": eb.voxel(5), "voxel12": eb.voxel(12, mode=1, scale=255.0), "evl": eb.voxel(9, mode=2),
            "acc_all": eb.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2]),
            "acc_exp": eb.polstats(tn, [0, 1, 2, 0], [4, 4, 0, 5], tau=0.3)}
@@ -70,6 +74,9 @@ def test_stream_builders_equal_ordered_builders_and_oracle(kind, monkeypatch, or
         if k == "tore_bbox":
             for a, b in zip(got[k], ref[k]):
                 assert_bit_equal(a, b, "tore bbox stream vs ordered (%s)" % kind)
+        elif k in CLOSE:
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-6 if k == "ts32" else 1e-12, atol=0, err_msg="%s stream vs ordered (%s)" % (k, kind))
+            assert np.array_equal(got[k] == 0, ref[k] == 0)          # dead slices stay exactly 0
         else:
             assert_bit_equal(got[k], ref[k], "%s stream vs ordered (%s)" % (k, kind))
     for b, ev in enumerate(wins):
@@ -80,6 +87,8 @@ def test_stream_builders_equal_ordered_builders_and_oracle(kind, monkeypatch, or
         assert_bit_equal(got["es"][b], oracle.event_stack(ev, H, W), "event_stack stream vs oracle (%s, window %d)" % (kind, b))
         want = oracle.tore(ev[:, 0] + 1, ev[:, 1] + 1, ev[:, 2], ev[:, 3], ev[-1, 2], 6, (H, W))
         np.testing.assert_allclose(got["tore"][b], want, rtol=1e-6, atol=1e-6)
+        if kind != "escaped":      # (the time surface reads p & 1 of whatever the dispatcher mapped: the oracle takes {0, 1} / {-1, +1} streams)
+            np.testing.assert_allclose(got["ts64"][b], oracle.time_surface(ev, H, W), rtol=1e-12)
 
 
 def test_stream_builders_on_unsorted_windows(monkeypatch, oracle):
