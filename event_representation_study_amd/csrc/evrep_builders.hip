@@ -1232,7 +1232,20 @@ __device__ inline WindowMeta meta_finish(const BinView &bv, const int64_t *__res
     // timestamp is block 0's minimum, its last one the last block's maximum -- two readlanes instead of two DPP reductions
     // on every builder wave's critical path.  A window the status word reports as unsorted takes the reductions (below).
     m.tmin = nb > 0 ? __builtin_amdgcn_readlane(st.tmin, 0) : INT32_MAX;
-    m.tmax = nb > 0 ? __builtin_amdgcn_readlane(st.tmax, nb - 1) : INT32_MIN;
+    m.tmax = nb > 0 ? __builtin_amdgcn_readlane(st.tmax, min(nb, kWave) - 1) : INT32_MIN;
+    if (nb > kWave) {   // wave-uniform (r06: windows of up to 128 block runs, stream builders only): blocks 64 .. nb - 1, one per lane, merged in
+        BlockStats s2;
+        stats_identity(s2);
+        if (kWave + lane < nb) {
+            const int4 *sp = reinterpret_cast<const int4 *>(bv.stats + (size_t)b * bv.nblk + kWave + lane);
+            const int4 a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            s2.tmin = a0.x; s2.tmax = a0.y; s2.xmin = a0.z; s2.xmax = a0.w;
+            s2.ymin = a1.x; s2.ymax = a1.y; s2.neg_flags = (uint32_t)a1.z; s2.oob_flags = (uint32_t)a1.w;
+            s2.status = (uint32_t)a2.x; s2.n_valid = a2.y;
+        }
+        m.tmax = __builtin_amdgcn_readlane(s2.tmax, nb - kWave - 1);
+        stats_merge(st, s2);
+    }
     m.xmin = wave_min(st.xmin); m.xmax = wave_max(st.xmax);
     m.ymin = wave_min(st.ymin); m.ymax = wave_max(st.ymax);
     m.neg_flags = wave_or(st.neg_flags); m.oob_flags = wave_or(st.oob_flags);
@@ -1756,32 +1769,67 @@ __device__ inline void emit_chunk(const UnitRecs &u, int key0, int npix, int C, 
 // segment list: what a builder keeps per pixel it keeps by LDS atomics (or elections) on its own tile.
 // head: [64 * RB] words of LDS, srcs: [128].  Returns the unit's record count.
 struct StreamNoPre { __device__ inline uint2 operator()(const Rec8 &) const { return make_uint2(0u, 0u); } };
+// The run tables of a unit's keys, up to 128 block runs: lane l holds run l and, in windows of more than 64 runs, run 64 + l.
+struct StreamRuns {
+    uint32_t a0, len0, pre0, a1, len1, pre1, nrec;
+    int nb;
+    // of run k (wave-uniform k): its length / the address of its first record of the unit, given the lane-wise values v0 (runs 0..63), v1 (64..127)
+    __device__ inline uint32_t pick(uint32_t v0, uint32_t v1, int k) const {
+        return k < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)v0, k) : (uint32_t)__builtin_amdgcn_readlane((int)v1, k - kWave);
+    }
+};
+__device__ inline StreamRuns stream_runs(const BinView &bv, int b, int64_t n_win, int NK, int klo, int khi) {
+    const int lane = threadIdx.x;
+    StreamRuns r;
+    r.a0 = 0; r.a1 = 0; r.len0 = 0; r.len1 = 0; r.pre0 = 0; r.pre1 = 0; r.nrec = 0;
+    uint32_t k0v = 0, k1v = 0;
+    if (lane < bv.nblk) {
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
+        r.a0 = tb[klo];
+        k0v = tb[khi];
+    }
+    if (kWave + lane < bv.nblk) {   // (only windows of more than 64 runs)
+        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + kWave + lane) * ((size_t)NK + 1);
+        r.a1 = tb[klo];
+        k1v = tb[khi];
+    }
+    r.nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
+    if (r.nb <= 0) return r;
+    r.len0 = k0v - r.a0; r.len1 = k1v - r.a1;
+    if (lane >= r.nb) { r.a0 = 0; r.len0 = 0; }
+    if (kWave + lane >= r.nb) { r.a1 = 0; r.len1 = 0; }
+    const uint32_t i0 = wave_incl_scan(r.len0);
+    r.pre0 = i0 - r.len0;
+    r.nrec = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+    if (r.nb > kWave) {   // wave-uniform
+        const uint32_t i1 = wave_incl_scan(r.len1);
+        r.pre1 = r.nrec + i1 - r.len1;
+        r.nrec += (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+    }
+    return r;
+}
 template <int RB, typename Pre, typename F>
 __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
                                                uint32_t *head, uint32_t *srcs, Pre pre_f, F f) {
+    static_assert(RB >= 4, "head[] doubles as the 2 x 128-word run table of the LDS search");
     const int lane = threadIdx.x;
-    uint32_t a = 0, khi_v = 0;
-    if (lane < bv.nblk) {
-        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
-        a = tb[klo];
-        khi_v = tb[khi];
-    }
-    uint32_t len = khi_v - a;
-    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
-    if (nb <= 0) return 0u;
-    if (lane >= nb) { a = 0; len = 0; }
-    const uint32_t incl = wave_incl_scan(len);
-    const uint32_t pre = incl - len;
-    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (nrec == 0u) return 0u;
+    const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, khi);
+    const int nb = R.nb;
+    const uint32_t nrec = R.nrec;
+    if (nb <= 0 || nrec == 0u) return 0u;
+    const bool wide = nb > kWave;   // wave-uniform
     const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
-    const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+    // record j of the unit, if in run `lane` / run 64 + lane: src + j
+    const uint32_t src0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0 - R.pre0;
+    const uint32_t src1 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1 - R.pre1;
     if (nrec <= (uint32_t)(64 * RB)) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
-        srcs[lane] = src;
+        srcs[lane] = src0;
+        if (wide) srcs[kWave + lane] = src1;
         wave_phase();
-        if (len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+        if (R.len0 > 0u && R.pre0 < (uint32_t)(64 * RB)) head[R.pre0] = (uint32_t)lane;
+        if (wide && R.len1 > 0u && R.pre1 < (uint32_t)(64 * RB)) head[R.pre1] = (uint32_t)(kWave + lane);
         wave_phase();
         Rec8 q[RB];
         uint32_t carry = 0u;
@@ -1808,17 +1856,21 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
     }
     constexpr int G = 4;
     const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
-    const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
-    uint32_t *rt = srcs;   // [2][64]
-    if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
+    const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
+    const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
+    uint32_t *rt = head;   // [2][128]: the runs' first records of the unit (pre) and their addresses (src)
+    if (!by_run && nb > kBsChainBlocks) {
+        rt[lane] = R.pre0; rt[128 + lane] = src0;
+        if (wide) { rt[kWave + lane] = R.pre1; rt[128 + kWave + lane] = src1; }
+    }
     wave_phase();
     auto src_of = [&](uint32_t j) -> uint32_t {
         if (nb <= kBsChainBlocks) {
-            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+            uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
             uint32_t prev = sx;
             for (int k = 1; k < nb; ++k) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)R.pre0, k);
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src0, k);
                 sx += (j >= pk) ? sk - prev : 0u;
                 prev = sk;
             }
@@ -1826,12 +1878,12 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         }
         uint32_t lo = 0, hi = (uint32_t)nb;
 #pragma unroll
-        for (int step = 0; step < 6; ++step) {
+        for (int step = 0; step < 7; ++step) {
             const uint32_t mid = (lo + hi) >> 1;
             const bool go = hi - lo > 1 && rt[mid] <= j;
             if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
         }
-        return rt[64 + lo] + j;
+        return rt[128 + lo] + j;
     };
     int rk_ = 0;
     uint32_t ro_ = 0;
@@ -1844,10 +1896,10 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
             bcnt[sl] = 0u;
             uint32_t addr = 0u;
             if (by_run) {
-                uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
+                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
                 if (rk_ < nb) {
-                    addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                    addr = R.pick(run00, run01, rk_) + ro_ + (uint32_t)lane;
                     bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
                     ro_ += kWave;
                 }
@@ -1863,8 +1915,8 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
             if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
         }
         if (by_run) {
-            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+            uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
+            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
             more = rk_ < nb;
         } else {
             more = ro_ < nrec;
@@ -3516,27 +3568,14 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
         if (unsorted) { uint4 *g4 = reinterpret_cast<uint4 *>(tag); for (int v = lane; v * 4 < 2 * npixa; v += kWave) g4[v] = make_uint4(~0u, ~0u, ~0u, ~0u); }
     }
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
-    uint32_t nrec = 0u, a = 0u, len = 0u, pre = 0u;
-    int nb = 0, c0 = 0;
-    if (!empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W) {
+    int c0 = 0, klo = 0, khi = 0;
+    const bool has = !empty && row >= 0 && row < H && sc_hi > 0 && sc_lo < W;   // wave-uniform: sensor keys lie behind the unit
+    if (has) {
         const int ch_lo = max(sc_lo, 0) / kChunkPx, ch_hi = (min(sc_hi, W) - 1) / kChunkPx;
-        const int NK = H * nchunk, klo = row * nchunk + ch_lo, khi = row * nchunk + ch_hi + 1;
+        klo = row * nchunk + ch_lo; khi = row * nchunk + ch_hi + 1;
         c0 = ch_lo * kChunkPx;
-        uint32_t khi_v = 0;
-        if (lane < bv.nblk) {
-            const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
-            a = tb[klo];
-            khi_v = tb[khi];
-        }
-        len = khi_v - a;
-        nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
-        if (lane >= nb) { a = 0; len = 0; }
-        const uint32_t incl = wave_incl_scan(len);
-        pre = incl - len;
-        nrec = nb > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : 0u;
     }
     const int4 *evw = ev + beg;
-    const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
     const int pxoff = sc_lo - c0;   // output pixel = (column inside the gathered chunks) - pxoff
     // one batch: a record's finished value down its FIFO
     auto push = [&](bool have, const Rec8 &q) {
@@ -3582,102 +3621,10 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
             }
         }
     };
-    if (nrec != 0u) {
-        const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
-        if (nrec <= (uint32_t)(64 * RB)) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
-            srcs[lane] = src;
-            wave_phase();
-            if (lane < nb && len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
-            wave_phase();
-            Rec8 q[RB];
-            uint32_t carry = 0u;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                q[i] = make_uint2(0u, 0u);
-                if ((uint32_t)(64 * i) < nrec) {   // uniform
-                    const uint32_t k = max(carry, wave_incl_max_scan(head[lane + 64 * i]));
-                    carry = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
-                    const uint32_t j = (uint32_t)(64 * i + lane);
-                    if (j < nrec) q[i] = s8[srcs[k] + j];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-                if ((uint32_t)(64 * i) < nrec) push((uint32_t)(64 * i + lane) < nrec, q[i]);
-        } else {
-            constexpr int G = 4;
-            const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
-            const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
-            uint32_t *rt = srcs;   // [2][64]
-            if (!by_run && nb > kBsChainBlocks) { rt[lane] = pre; rt[64 + lane] = src; }
-            wave_phase();
-            auto src_of = [&](uint32_t j) -> uint32_t {
-                if (nb <= kBsChainBlocks) {
-                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
-                    uint32_t prev = sx;
-                    for (int k = 1; k < nb; ++k) {
-                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
-                        sx += (j >= pk) ? sk - prev : 0u;
-                        prev = sk;
-                    }
-                    return sx + j;
-                }
-                uint32_t lo = 0, hi = (uint32_t)nb;
-#pragma unroll
-                for (int step = 0; step < 6; ++step) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const bool go = hi - lo > 1 && rt[mid] <= j;
-                    if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
-                }
-                return rt[64 + lo] + j;
-            };
-            int rk_ = 0;
-            uint32_t ro_ = 0;
-            bool more = true;
-            while (more) {
-                Rec8 q[G];
-                uint32_t bcnt[G];
-#pragma unroll
-                for (int sl = 0; sl < G; ++sl) {
-                    bcnt[sl] = 0u;
-                    uint32_t addr = 0u;
-                    if (by_run) {
-                        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-                        if (rk_ < nb) {
-                            addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
-                            bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
-                            ro_ += kWave;
-                        }
-                    } else {
-                        const uint32_t j0 = ro_;
-                        if (j0 < nrec) {
-                            bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
-                            if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
-                            ro_ += kWave;
-                        }
-                    }
-                    q[sl] = make_uint2(0u, 0u);
-                    if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
-                }
-                if (by_run) {
-                    uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                    while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
-                    more = rk_ < nb;
-                } else {
-                    more = ro_ < nrec;
-                }
-#pragma unroll
-                for (int sl = 0; sl < G; ++sl) {
-                    if (bcnt[sl] == 0u) break;   // uniform
-                    push((uint32_t)lane < bcnt[sl], q[sl]);
-                }
-            }
-        }
-    }
+    wave_phase();
+    if (has)
+        stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, klo, khi, head, srcs, StreamNoPre(),
+                                [&](bool have, const Rec8 &q, const uint2 &) { push(have, q); });
     wave_phase();
     tile_store(reinterpret_cast<const float *>(tile), npix * C, dst);
 }
@@ -3810,9 +3757,9 @@ __global__ __launch_bounds__(kWave, HOT ? 4 : (CM <= 8 ? EVREP_VOXEL_WAVES : 1))
 // pixel, part tiles): no counting sort, no segment list, no walk, no spill slot, and the tile leaves the wave as one coalesced
 // burst.  Units of up to 64 * RB records keep their digested records in registers between the two sweeps; larger ones are read
 // and digested twice (8 bytes per record from L2).
-// LDS: cells [npixa * bins] float64 | tag [npixa] | head [64 * RB] | srcs [64] | touched [npixa] bytes
+// LDS: cells [npixa * bins] float64 | tag [npixa] | head [64 * RB] | srcs [128] | touched [npixa] bytes
 __host__ __device__ inline size_t voxel_stream_lds_bytes(int bins, int npixa, int rb) {
-    return align16((size_t)npixa * bins * 8) + (size_t)npixa * 4 + (size_t)(64 * rb + 64) * 4 + align16((size_t)npixa);
+    return align16((size_t)npixa * bins * 8) + (size_t)npixa * 4 + (size_t)(64 * rb + 128) * 4 + align16((size_t)npixa);
 }
 #ifndef EVREP_VS_WAVES
 #define EVREP_VS_WAVES 6
@@ -3833,18 +3780,13 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
     int tz0 = 0, tz1 = 0;
     if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
     const int NK = H * nchunk, klo = g.row * nchunk + chunk;
-    uint32_t a = 0, khi_v = 0;
-    if (lane < bv.nblk) {
-        const uint32_t *tb = bv.table + ((size_t)b * bv.nblk + lane) * ((size_t)NK + 1);
-        a = tb[klo];
-        khi_v = tb[klo + nch];
-    }
+    const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, klo + nch);   // (up to 128 block runs: two per lane)
     const int npixa = (uc.span + uc.merge) * kChunkPx;
     double *acc = reinterpret_cast<double *>(smem);
     uint32_t *tag = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * bins * 8));
     uint32_t *head = tag + npixa;
     uint32_t *srcs = head + 64 * RB;
-    unsigned char *touched = reinterpret_cast<unsigned char *>(srcs + 64);
+    unsigned char *touched = reinterpret_cast<unsigned char *>(srcs + 128);
     const int ncell = g.npix * bins;
     {   // zero cells, free tags, nothing touched (overlaps the table loads)
         uint4 *z = reinterpret_cast<uint4 *>(acc);
@@ -3853,12 +3795,9 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
         for (int v = lane; v * 4 < npixa; v += kWave) t4[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
         if (scale != 1.0) { uint4 *c4 = reinterpret_cast<uint4 *>(touched); for (int v = lane; v * 16 < npixa; v += kWave) c4[v] = make_uint4(0u, 0u, 0u, 0u); }
     }
-    uint32_t len = khi_v - a;
-    const int nb = min((int)(((uint32_t)n_win + (1u << bv.chunk_shift) - 1u) >> bv.chunk_shift), bv.nblk);
-    if (lane >= nb) { a = 0; len = 0; }
-    const uint32_t incl = wave_incl_scan(len);
-    const uint32_t pre = incl - len;
-    const uint32_t nrec = nb > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : 0u;
+    const int nb = R.nb;
+    const uint32_t nrec = nb > 0 ? R.nrec : 0u;
+    const bool wide = nb > kWave;   // wave-uniform
     double *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * bins;
     double t0 = 0.0, den = 1.0;
     if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
@@ -3921,15 +3860,19 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
         }
     };
     if (nrec != 0u) {
-        const uint32_t src = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a - pre;   // record j of the unit, if in run `lane`: src + j
+        // record j of the unit, if in run `lane` / run 64 + lane: src + j
+        const uint32_t src0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0 - R.pre0;
+        const uint32_t src1 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1 - R.pre1;
         const int npass = mode == 2 ? 1 : 2;
         if (nrec <= (uint32_t)(64 * RB)) {
             // the whole unit in registers: the run of record j by a max-scan over the runs' first positions (unit_records)
 #pragma unroll
             for (int i = 0; i < RB; ++i) head[lane + 64 * i] = 0u;
-            srcs[lane] = src;
+            srcs[lane] = src0;
+            if (wide) srcs[kWave + lane] = src1;
             wave_phase();
-            if (lane < nb && len > 0u && pre < (uint32_t)(64 * RB)) head[pre] = (uint32_t)lane;
+            if (R.len0 > 0u && R.pre0 < (uint32_t)(64 * RB)) head[R.pre0] = (uint32_t)lane;
+            if (wide && R.len1 > 0u && R.pre1 < (uint32_t)(64 * RB)) head[R.pre1] = (uint32_t)(kWave + lane);
             wave_phase();
             Rec8 q[RB];
             uint32_t carry = 0u;
@@ -3965,17 +3908,21 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
             // batches, else 64 consecutive records of the unit with the run found per record (unit_records)
             constexpr int G = 4;
             const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
-            const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;
-            uint32_t *runs2 = head;   // [2][64]
-            if (!by_run && nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
+            const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
+            const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
+            uint32_t *runs2 = head;   // [2][128]
+            if (!by_run && nb > kBsChainBlocks) {
+                runs2[lane] = R.pre0; runs2[128 + lane] = src0;
+                if (wide) { runs2[kWave + lane] = R.pre1; runs2[128 + kWave + lane] = src1; }
+            }
             wave_phase();
             auto src_of = [&](uint32_t j) -> uint32_t {
                 if (nb <= kBsChainBlocks) {
-                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src, 0);
+                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
                     uint32_t prev = sx;
                     for (int k = 1; k < nb; ++k) {
-                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pre, k);
-                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src, k);
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)R.pre0, k);
+                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src0, k);
                         sx += (j >= pk) ? sk - prev : 0u;
                         prev = sk;
                     }
@@ -3983,12 +3930,12 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                 }
                 uint32_t lo = 0, hi = (uint32_t)nb;
 #pragma unroll
-                for (int step = 0; step < 6; ++step) {
+                for (int step = 0; step < 7; ++step) {
                     const uint32_t mid = (lo + hi) >> 1;
                     const bool go = hi - lo > 1 && runs2[mid] <= j;
                     if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
                 }
-                return runs2[64 + lo] + j;
+                return runs2[128 + lo] + j;
             };
             for (int pass = 0; pass < npass; ++pass) {
                 int rk_ = 0;
@@ -4002,10 +3949,10 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                         bcnt[sl] = 0u;
                         uint32_t addr = 0u;
                         if (by_run) {
-                            uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                            uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
+                            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
                             if (rk_ < nb) {
-                                addr = (uint32_t)__builtin_amdgcn_readlane((int)run0, rk_) + ro_ + (uint32_t)lane;
+                                addr = R.pick(run00, run01, rk_) + ro_ + (uint32_t)lane;
                                 bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
                                 ro_ += kWave;
                             }
@@ -4021,8 +3968,8 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                         if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
                     }
                     if (by_run) {
-                        uint32_t lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u;
-                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? (uint32_t)__builtin_amdgcn_readlane((int)len, rk_) : 0u; }
+                        uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
+                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
                         more = rk_ < nb;
                     } else {
                         more = ro_ < nrec;

@@ -91,7 +91,9 @@ int evrep_plan_init_ex(evrep_plan *plan, int32_t B, int32_t H, int32_t W, int64_
     // windows, every builder + 8-11 us, bin + build 15-27 % shorter; 640x480 x 150 000 / 250 000 events likewise,
     // profiles/r03/sweep_mid_density.txt); beyond, the units spill and the per-key column sort (pass 3) wins
     const int64_t NK = (int64_t)H * plan->nchunk;
-    const bool key_sorted = two_kernel && max_events_per_window <= (int64_t)kBsMaxBlocks * kBsChunk && NK < 65535 &&
+    // (r06: up to kCsMaxRuns = 128 block runs -- windows of up to 1 048 576 events: the STREAM builders gather two runs per lane;
+    //  the ordered builders, one run per lane, take such a window through the per-key column sort, on demand: ensure_pixel_stream)
+    const bool key_sorted = two_kernel && max_events_per_window <= (int64_t)kCsMaxRuns * kBsChunk && NK < 65535 &&
                             block_keysort_lds_bytes((int)NK, 4096, kBsChunk) + 1024 <= 160 * 1024 &&
                             ((double)max_events_per_window <= kKeySortedMaxPerUnit * (double)NK || f_force_ks) && !f_classic && !f_three;
     // dense windows on the same sensors: k_block_keysort + the column sort run per KEY (k_col_sort_runs, by_key),
@@ -154,7 +156,7 @@ int evrep_bin_events(const evrep_plan *plan, const int32_t *events, const int64_
         if (rc2) return rc2;
     }
     if (plan->reserved == 2 || plan->reserved == 3) {
-        if ((chunk != kBsChunk && chunk != 4096) || nblk > (plan->reserved == 2 ? kBsMaxBlocks : kCsMaxRuns)) return EVREP_EINVAL;
+        if ((chunk != kBsChunk && chunk != 4096) || nblk > kCsMaxRuns) return EVREP_EINVAL;
         const int NK = H * plan->nchunk;
         // > 64 KB of dynamic LDS has to be opted into per (function, device): renewed on every launch that needs it (no
         // process-wide "already done" flag: a plan may run on any device, from any host thread)

@@ -9,11 +9,17 @@ using namespace evrep;
 
 #define BUILDER_GRID dim3(plan->nchunk, plan->H, plan->B)
 
-// what the builders read of the binning pass (see BinView in evrep_builders.hip)
-static inline BinView bin_view(const evrep_plan *plan, const int32_t *events, void *workspace) {
+// The key-sorted pass leaves block RUNS (plan->reserved == 2).  The ORDERED builders gather a unit's records with one lane per run:
+// up to kBsMaxBlocks = 64 runs (ks_pass); the STREAM builders (r06) take two runs per lane: up to kCsMaxRuns = 128 -- windows of up
+// to 1 048 576 events.  A window of more than 64 runs reaches an ordered builder through the per-key column sort, run on demand in
+// front of that builder's launch (ensure_pixel_stream): the builder then reads the pixel-sorted stream as after the classic passes.
+static inline bool ks_pass(const evrep_plan *plan) { return plan->reserved == 2 && plan->nblk <= kBsMaxBlocks; }
+
+// what the builders read of the binning pass (see BinView in evrep_builders.hip); runs: the view of a stream builder
+static inline BinView bin_view(const evrep_plan *plan, const int32_t *events, void *workspace, bool runs = false) {
     BinView bv;
     bv.ev = reinterpret_cast<const int4 *>(events);
-    bv.fused = plan->reserved == 2 ? 1 : 0;
+    bv.fused = (runs ? plan->reserved == 2 : ks_pass(plan)) ? 1 : 0;
     bv.sorted = bv.fused ? CWS(Rec, off_sorted1) : CWS(Rec, off_sorted2);
     bv.chunk_off = CWS(uint32_t, off_chunkoff);
     bv.table = CWS(uint32_t, off_table);
@@ -41,6 +47,11 @@ static inline int ensure_column_sorted(const evrep_plan *plan, const int32_t *ev
     if (plan->reserved != 2) return EVREP_OK;
     return evrep_host::column_sort_keys(plan, events, offsets, workspace, stream);
 }
+// in front of an ORDERED builder's launches: a key-sorted window of more than 64 runs gets its pixel-sorted stream now
+static inline int ensure_pixel_stream(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace, hipStream_t stream) {
+    if (plan->reserved != 2 || ks_pass(plan)) return EVREP_OK;
+    return evrep_host::column_sort_keys(plan, events, offsets, workspace, stream);
+}
 
 // The unit of one builder wave.  span = 128-pixel chunks it takes: 2 for small pixels (float32 x 12, float64 x 5 ...) on
 // sparse windows (<= 30 records per chunk on average, so a 256-pixel unit still fits the one-lane-per-non-empty-pixel
@@ -59,8 +70,8 @@ static inline UnitCfg unit_cfg(const evrep_plan *plan, size_t pixel_bytes, int e
     // denser units (the reference's own Gen1 shape, 304x240 x 50 000 events: ~69 records per unit) are ordered inside LDS
     // in two register batches: a 128-record stage; the dense windows of the classic passes stage 256 (stage_classic)
     // (deep_stage = false: EventStack only reads a segment's last records, TimeSurface measured slower with it)
-    uc.stage = (deep_stage && plan->reserved != 2 && per_chunk > kDeepStageMinPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
-    if ((plan->flags & 512) && plan->reserved == 2 && uc.span == 1) uc.stage = 64;   // experiment (EVREP_X_STAGE64): units of > 64 records leave the two-batch path
+    uc.stage = (deep_stage && !ks_pass(plan) && per_chunk > kDeepStageMinPerUnit) ? 256 : ((uc.span + extra_chunks > 1 || per_chunk > 28.0 || (plan->flags & 128)) ? 128 : 64);
+    if ((plan->flags & 512) && ks_pass(plan) && uc.span == 1) uc.stage = 64;   // experiment (EVREP_X_STAGE64): units of > 64 records leave the two-batch path
     uc.partpx = (wide_part && per_chunk <= 30.0) ? 2 * kPartPx : kPartPx;  // sparse windows only: dense ones lose 5 % with it
     uc.hold = plan->pacing > 0 ? plan->pacing : 0;  // automatic pacing is decided per launch (auto_hold)
     // a short tail chunk (<= 64 of 128 pixels: Gen1's 304-pixel rows end in 48) rides with the row's last unit (UnitCfg::merge);

@@ -20,12 +20,13 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
 #define ESS_LAUNCH(CM) k_event_stack_stream<CM, kRB><<<SPAN_GRID(1), kWave, event_stack_stream_lds_bytes(stack_size, kChunkPx, kRB), stream>>>( \
-            bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, stack_size, premap, scale, out)
+            bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us, stack_size, premap, scale, out)
         if (stack_size <= 8) ESS_LAUNCH(8); else if (stack_size <= 12) ESS_LAUNCH(12); else ESS_LAUNCH(16);
 #undef ESS_LAUNCH
         LAUNCH_CHECK("k_event_stack_stream");
         return EVREP_OK;
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     const UnitCfg uc = unit_cfg(plan, (size_t)stack_size * 4, 0, true, false);  // float32 pixels of <= 64 B: 128-pixel part tiles (see UnitCfg)
     const int span = uc.span;
     // EventStack reads the last record of a pixel only: a unit beyond the record stage keeps one (rank, polarity) word per pixel
@@ -33,7 +34,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
     // launch (and no flip of the hot lists: the current one stays empty)
     const bool last_fits = (size_t)(span + uc.merge) * kChunkPx * sizeof(Rec) <=
                            align16((size_t)uc.partpx * stack_size * 4) + (size_t)uc.stage * sizeof(Rec);
-    const bool hot_launch = plan->reserved == 2 && !last_fits;
+    const bool hot_launch = ks_pass(plan) && !last_fits;
 #define ES_LAUNCH(CM)                                                                                              \
     do {                                                                                                           \
     k_event_stack<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(stack_size, 4, (span + uc.merge) * kChunkPx, uc.stage, uc.partpx), stream>>>(   \
@@ -83,13 +84,14 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
 #define TSS_LAUNCH(T, CM) k_time_surface_stream<T, CM, kRB><<<SPAN_GRID(1), kWave, time_surface_stream_lds_bytes(slices, kChunkPx, sizeof(T), kRB), stream>>>( \
-            bin_view(plan, events, workspace), offsets, cuts, plan->H, plan->W, plan->nchunk, us, slices, tau, premap, scale, static_cast<T *>(out))
+            bin_view(plan, events, workspace, true), offsets, cuts, plan->H, plan->W, plan->nchunk, us, slices, tau, premap, scale, static_cast<T *>(out))
         if (out_dtype == EVREP_F64) { if (slices <= 6) TSS_LAUNCH(double, 12); else TSS_LAUNCH(double, 16); }
         else { if (slices <= 6) TSS_LAUNCH(float, 12); else TSS_LAUNCH(float, 16); }
 #undef TSS_LAUNCH
         LAUNCH_CHECK("k_time_surface_stream");
         return EVREP_OK;
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     // windows whose units are practically all fully staged (<= 128 records: everything the key-sorted pass is chosen for, r03;
     // r02: <= 30 records per unit on average): the kernel with the factorised exponentials compiled in -- a wave uses them
     // when ITS unit is fully staged, whatever the binning pass (Gen1 shape 88 -> 80 us)
@@ -106,7 +108,7 @@ int evrep_time_surface_ftime(const evrep_plan *plan, const int32_t *events, cons
     // 2 * slices words per pixel of the unit fit the part tile -- unit_records, Visit: the float64 surfaces)
 #define TS_LAUNCH(T, CM, GRID, SEG)                                                                                  \
     do {                                                                                                             \
-        hot_launch = plan->reserved == 2 &&                                                                          \
+        hot_launch = ks_pass(plan) &&                                                                                \
                      (size_t)(SEG) * 2 * slices * 4 > align16((size_t)kPartPx * 2 * slices * sizeof(T));                          \
         if (ts_fact) TS_LAUNCH_F(T, CM, true, GRID, SEG); else TS_LAUNCH_F(T, CM, false, GRID, SEG);                  \
         if (hot_launch) k_time_surface<T, CM, false, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * slices, sizeof(T), SEG, kHotStage), stream>>>( \
@@ -146,16 +148,17 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
         k_tore_stream<kRB><<<SPAN_GRID(1), kWave, tore_stream_lds_bytes(k, kChunkPx, kRB), stream>>>(
-            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, plan->H, plan->W,
+            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, sample_times, plan->H, plan->W,
             plan->nchunk, us, k, frame_mode, scale, out);
         LAUNCH_CHECK("k_tore_stream");
         return EVREP_OK;
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * k * 4, 1);   // the shifted frame straddles one more chunk
     const int span = uc.span;
     // dense windows: the main launch runs the order-free cascade itself (k_tore, SM), as k_polstats does
     const double per_chunk_t = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
-    const bool sweep_main = plan->reserved == 2 && span == 1 && per_chunk_t > 150.0 && !(plan->flags & 4096) && tf == nullptr;
+    const bool sweep_main = ks_pass(plan) && span == 1 && per_chunk_t > 150.0 && !(plan->flags & 4096) && tf == nullptr;
     UnitCfg um = uc;
     if (sweep_main) {
         const size_t need = (size_t)kChunkPx * 2 * k * 4 + 1024, have = align16((size_t)kPartPx * 2 * k * 4) + align16((size_t)EVREP_MAX_CHANNELS * 4);
@@ -176,7 +179,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
     UnitCfg hc = hot_cfg(uc);                                                                                       \
     if (uc.xflags & 6) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 2 * k * 4, 512, (size_t)kPartPx * 2 * k * 4);   /* whole units by the order-free sweep: room for their words */ \
     /* (none behind the sweeping main launch: it defers nothing -- units with a shifted frame or unsorted timestamps are emitted from their slot by the main wave) */ \
-    if (plan->reserved == 2 && !sweep_main) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
+    if (ks_pass(plan) && !sweep_main) k_tore<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(2 * k, 4, (span + 1) * kChunkPx, hc.stage), stream>>>(     \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, sample_times, tf, sample_times_f,    \
         plan->H, plan->W, plan->nchunk, hc, k, frame_mode, scale, out);                                    \
     } while (0)
@@ -220,11 +223,12 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
         k_voxel_stream<kRB><<<SPAN_GRID(1), kWave, voxel_stream_lds_bytes(bins, kChunkPx, kRB), stream>>>(
-            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us,
+            reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us,
             bins, mode, scale, t_range, tnorm, out);
         LAUNCH_CHECK("k_voxel_stream");
         return EVREP_OK;
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     const UnitCfg uc = unit_cfg(plan, (size_t)bins * 8);
     const int span = uc.span;
 #define VOXEL_LAUNCH(CM)                                                                                         \
@@ -233,7 +237,7 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
     k_voxel<CM><<<SPAN_GRID(span), kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, uc.stage) + (size_t)kWave * bins * 8, stream>>>(              \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, \
         bins, mode, scale, t_range, tnorm, out);                                                                 \
-    if (plan->reserved == 2) k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage) + (size_t)kWave * bins * 8, stream>>>(         \
+    if (ks_pass(plan)) k_voxel<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(bins, 8, (span + uc.merge) * kChunkPx, kHotStage) + (size_t)kWave * bins * 8, stream>>>(         \
         reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk,   \
         hot_cfg(uc), bins, mode, scale, t_range, tnorm, out);                                                    \
     } while (0)
@@ -294,16 +298,17 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
         for (int c = 0; c < C; ++c) any_exp = any_exp || stat[c] == EVREP_PS_EXP;
         const bool k32 = !any_exp && C <= 8;   // float32 extremes: exact for every statistic but EXP (k_polstats_stream)
 #define PSS_LAUNCH(CM, K32) k_polstats_stream<CM, kRB, K32><<<SPAN_GRID(1), kWave, polstats_stream_lds_bytes(kChunkPx, kRB, K32), stream>>>( \
-                bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, us, out)
+                bin_view(plan, events, workspace, true), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, us, out)
         if (k32) PSS_LAUNCH(8, true); else if (C <= 8) PSS_LAUNCH(8, false); else PSS_LAUNCH(16, false);
 #undef PSS_LAUNCH
         LAUNCH_CHECK("k_polstats_stream");
         return EVREP_OK;
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     // dense windows (every unit beyond the record stage): the main launch sweeps order-free itself (k_polstats, SM) with a stage
     // that holds the unit's fourteen words per pixel; nothing is deferred and there is no hot launch
     const double per_chunk_ps = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
-    const bool sweep_main = plan->reserved == 2 && span == 1 && per_chunk_ps > 150.0 && !(plan->flags & 4096);   // (measured: 8 x 500 000 events at 640x480 74 -> 63 us; at 250 000 -- 104 per unit, most of them inside the stage -- 52 -> 58: the instance's budget is the sweep's); 4096: EVREP_X_NO_SWEEP_MAIN
+    const bool sweep_main = ks_pass(plan) && span == 1 && per_chunk_ps > 150.0 && !(plan->flags & 4096);   // (measured: 8 x 500 000 events at 640x480 74 -> 63 us; at 250 000 -- 104 per unit, most of them inside the stage -- 52 -> 58: the instance's budget is the sweep's); 4096: EVREP_X_NO_SWEEP_MAIN
     if (sweep_main) {
         const size_t need = (size_t)kChunkPx * 14 * 4 + 1024, have = align16((size_t)uc.partpx * C * 4) + align16((size_t)EVREP_MAX_CHANNELS * 4);
         const int st = (int)((need > have ? need - have : 0) + 15) / 16;
@@ -321,7 +326,7 @@ int evrep_polstats(const evrep_plan *plan, const int32_t *events, const int64_t 
         /* one-chunk units of sparse windows go to the hot launch whole (order-free sweep there): a larger stage for their words */ \
         UnitCfg hc = hot_cfg(uc);                                                                                     \
         if (uc.xflags & 2) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 14 * 4, 512, (size_t)uc.partpx * C * 4);   \
-        if (plan->reserved == 2) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
+        if (ks_pass(plan)) k_polstats<CM, true><<<kHotGrid, kWave, chunk_lds_bytes(C, 4, (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(   \
             bin_view(plan, events, workspace), offsets, tnorm, P, plan->H, plan->W, plan->nchunk, hc, out);   \
     } while (0)
     if (C <= 8) PS_LAUNCH(8); else PS_LAUNCH(16);
@@ -343,12 +348,13 @@ int evrep_est_voxel(const evrep_plan *plan, const int32_t *events, const int64_t
     P.lo = lo; P.inv_width = (double)nbucket / (hi - lo);
     for (int i = 0; i < C; ++i) P.shift[i] = (float)((double)i / (double)(C - 1));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     const UnitCfg uc = unit_cfg(plan, (size_t)2 * C * 4);
     const int span = uc.span;
     k_est<false><<<SPAN_GRID(span), kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, uc.stage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, uc, out);
-    if (plan->reserved == 2) k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(
+    if (ks_pass(plan)) k_est<true><<<kHotGrid, kWave, chunk_lds_bytes(2 * C, 4, (span + uc.merge) * kChunkPx, kHotStage), stream>>>(
         bin_view(plan, events, workspace), offsets, tnorm, segments, buckets, P, plan->H, plan->W,
         plan->nchunk, hot_cfg(uc), out);
     LAUNCH_CHECK("k_est");

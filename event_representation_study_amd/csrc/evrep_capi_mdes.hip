@@ -57,14 +57,15 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
             constexpr int kRB = 4;
             if (out_dtype == EVREP_F64)
                 k_mdes_stream<double, kRB><<<SPAN_GRID(1), kWave, mdes_stream_lds_bytes(kChunkPx, 8, kRB), stream>>>(
-                    bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<double *>(out));
+                    bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<double *>(out));
             else
                 k_mdes_stream<float, kRB><<<SPAN_GRID(1), kWave, mdes_stream_lds_bytes(kChunkPx, 4, kRB), stream>>>(
-                    bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<float *>(out));
+                    bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us, scale, static_cast<float *>(out));
             LAUNCH_CHECK("k_mdes_stream");
             return EVREP_OK;
         }
     }
+    if (int rc3 = ensure_pixel_stream(plan, events, offsets, workspace, stream)) return rc3;
     UnitCfg uc = unit_cfg(plan, (size_t)C * (out_dtype == EVREP_F64 ? 8 : 4));
     if ((plan->flags & EVREP_PLAN_X_SPAN2) && plan->nchunk >= 2) { uc.span = 2; uc.stage = 128; unit_cfg_geometry(uc, plan); }
     const int span = uc.span;
@@ -77,7 +78,7 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
         /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it; the float32 one   \
            hands hot units to its hot launch whole (Split, IN_HOT): a stage of kHotSplitStage records there */                   \
-        const bool hot_launch = plan->reserved == 2 && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                             \
+        const bool hot_launch = ks_pass(plan) && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                                       \
         UnitCfg hc = hot_cfg(uc);                                                                                             \
         if (MdesIsErgo12<DESC>::value) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 7 * 4, 4096, (size_t)uc.partpx * C * sizeof(T));                                                             \
         if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(  \

@@ -196,9 +196,41 @@ def test_many_block_runs(oracle, n, monkeypatch):
         assert_bit_equal(ks.optimized()[b].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 n=%d" % len(ev))
     assert_bit_equal(ks.event_stack().cpu().numpy(), cl.event_stack().cpu().numpy(), "event stack")
     assert_bit_equal(ks.tore(6, frame_mode=1).cpu().numpy(), cl.tore(6, frame_mode=1).cpu().numpy(), "tore")
-    # one event more than 64 blocks: a builder wave has one lane per run -- the column sort runs as a kernel, forced or not
+
+
+@pytest.mark.parametrize("n", [64 * 8192 + 1, 100 * 8192 + 77, 128 * 8192])
+def test_more_than_64_block_runs(oracle, n, monkeypatch):
+    """r06: windows of 65 .. 128 block runs stay on the key-sorted pass -- the stream builders gather two runs per lane; an
+    ordered builder (one lane per run) gets the pixel-sorted stream from the per-key column sort, run in front of its launch."""
+    import torch
+    from event_representation_study_amd import engine as eng
+    H, W = 100, 260
+    wins = [make_events(n, W, H, seed=n % 1000), make_events(700, W, H, seed=4, polarity="01")]
+    monkeypatch.delenv("EVREP_BIN_CLASSIC", raising=False)
+    monkeypatch.delenv("EVREP_BIN_THREE_KERNEL", raising=False)
     monkeypatch.setenv("EVREP_BIN_KEY_SORTED", "1")
-    assert eng.EventBatch.from_numpy([make_events(64 * 8192 + 1, W, H, seed=1)], H, W).plan.reserved == 3
+    ks = eng.EventBatch.from_numpy(wins, H, W)
+    assert ks.plan.reserved == 2 and ks.plan.nblk == (n + 8191) // 8192 > 64
+    monkeypatch.delenv("EVREP_BIN_KEY_SORTED", raising=False)
+    monkeypatch.setenv("EVREP_BIN_CLASSIC", "1")
+    cl = eng.EventBatch.from_numpy(wins, H, W)
+    assert cl.plan.reserved in (0, 1)
+    for b, ev in enumerate(wins):
+        assert_bit_equal(ks.optimized()[b].cpu().numpy(), oracle.ergo12(ev, H, W), "ergo12 (stream) n=%d" % len(ev))
+        assert_bit_equal(ks.voxel(5)[b].cpu().numpy(), oracle.voxel(ev, H, W, 5), "voxel (stream) n=%d" % len(ev))
+    tn = torch.rand(ks.total, dtype=torch.float64, device=ks.device, generator=torch.Generator(device=ks.device).manual_seed(5))
+    for tag, fn in {
+        "event stack (stream)": lambda eb: eb.event_stack(),
+        "tore, shifted frame (stream)": lambda eb: eb.tore(6, frame_mode=1),
+        "tore, negative scale (ordered, behind the column sort)": lambda eb: eb.tore(6, frame_mode=2, scale=-1.0),
+        "accumulators (stream)": lambda eb: eb.polstats(tn, [1, 2, 0, 0], [0, 1, 2, 4], tau=0.4),
+        "ergo12 float32 (stream)": lambda eb: eb.optimized(dtype=torch.float32),
+        "mdes, other triples (ordered, behind the column sort)": lambda eb: eb.mdes([0, 4, 6, 2], [0, 1, 5, 6], [2, 3, 0, 1]),
+    }.items():
+        assert_bit_equal(fn(ks).cpu().numpy(), fn(cl).cpu().numpy(), "%s n=%d" % (tag, n))
+    np.testing.assert_allclose(ks.time_surface().cpu().numpy(), cl.time_surface().cpu().numpy(), rtol=1e-13, atol=0)
+    np.testing.assert_array_equal(ks.status(), cl.status())
+    np.testing.assert_array_equal(ks.bbox(), cl.bbox())
 
 
 def test_status_bbox_and_failed_channels(monkeypatch):
