@@ -19,3 +19,8 @@ cp profiles/traffic.json $P/traffic.json
 grep -v amdgpu.ids $O/gwd_tile_phases.txt > $P/gwd_tile_phases.txt || true
 for f in phase_times phase_times_dense phase_times_gen1; do grep -v amdgpu.ids $O/$f.txt > $P/$f.txt || true; done
 for f in ks_phases tmpfs_write_floor hot_overflow; do [ -f $O/$f.txt ] && grep -v amdgpu.ids $O/$f.txt > $P/$f.txt || true; done
+# r06: ordered-builder A/B sweep and the clustered PMC passes (tools/pmc_clustered.sh writes gpurun_out/pmc_clustered/<stream>/)
+[ -f $O/sweep_ordered_builders.jsonl ] && cp $O/sweep_ordered_builders.jsonl $P/ || true
+if [ -d gpurun_out/pmc_clustered ]; then
+  for d in gpurun_out/pmc_clustered/*/; do n=$(basename $d); mkdir -p $P/pmc_clustered/$n; cp $d/sq.csv $d/fetch.csv $d/write.csv $d/summary.txt $P/pmc_clustered/$n/ 2>/dev/null || true; done
+fi

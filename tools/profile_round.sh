@@ -14,7 +14,7 @@ timeout 900 python bench.py --out-dtype f32 --no-cpu-baseline --no-gwd --no-gw-e
 timeout 900 python bench.py --pacing 0 --no-cpu-baseline --no-gwd --no-gw-extension --no-live-traffic --no-sweep --no-precompute > $O/bench_unpaced.json 2>> $O/bench.err
 timeout 300 python tools/experiments/pacing.py ergo64 8 0 600 650 680 690 700 720 750 > $O/pacing.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic --no-sweep --no-precompute > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic --no-sweep --no-precompute --no-pipelined-value > $O/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o pmc_fetch -- python $R/tools/pmc_workload.py > $O/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o pmc_write -- python $R/tools/pmc_workload.py > $O/write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/sq -o pmc_sq -- python $R/tools/pmc_workload.py > $O/sq.log 2>&1
@@ -28,6 +28,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gw_kt -o 
 cd $R
 timeout 900 python tools/bench_sweep.py > $O/sweep.jsonl 2> $O/sweep.err
 timeout 900 python tools/bench_sweep.py gen1@circle gen1@edges c2@circle c2@edges c3@circle c3@edges > $O/sweep_clustered.jsonl 2>> $O/sweep.err
+# r06: the ordered builders beside the streams (A/B by plan flags), and counters on clustered streams
+EVREP_X_VOXEL_ORDERED=1 EVREP_X_TORE_ORDERED=1 EVREP_X_POLSTATS_ORDERED=1 EVREP_X_ESTACK_ORDERED=1 EVREP_X_MDES_ORDERED=1 EVREP_X_TS_ORDERED=1 timeout 900 python tools/bench_sweep.py gen1 c2-dense gen1@circle gen1@edges c3@circle > $O/sweep_ordered_builders.jsonl 2>> $O/sweep.err
+bash tools/pmc_clustered.sh gen1 gen1@circle gen1@edges c3@circle c2-dense > $O/pmc_clustered.log 2>&1
 bash tools/experiments/wave_lifetimes.sh > $O/wave_lifetimes.txt 2>&1
 timeout 900 python tools/per_sample_latency.py > $O/per_sample.jsonl 2>&1
 timeout 900 python tools/gwd_matrix.py > $O/gwd_matrix.log 2>&1
