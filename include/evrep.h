@@ -76,7 +76,9 @@ typedef struct evrep_plan {
 } evrep_plan;
 
 /* evrep_plan_init_ex flags: which binning passes the plan may choose from (A/B timing and the cross-pass parity
- * tests; every pass produces the same tensors bit for bit), and two tuning knobs. */
+ * tests; every pass produces the same tensors bit for bit -- but for the time surface, whose stream builder (after the
+ * key-sorted pass, dense windows) takes one exponential per event where the ordered builder takes one per slice: the two
+ * forms agree to 1e-13 relative), and tuning / A/B knobs. */
 #define EVREP_PLAN_NO_KEY_PASS 1u       /* keep passes 2 and 3 (k_block_keysort) out of the choice */
 #define EVREP_PLAN_THREE_KERNEL 2u      /* the round-1 three-kernel pass (0) only */
 #define EVREP_PLAN_FORCE_KEY_SORTED 4u  /* pass 2 also for windows denser than it is chosen for */
