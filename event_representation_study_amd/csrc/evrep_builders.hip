@@ -3798,6 +3798,17 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
     const int nb = R.nb;
     const uint32_t nrec = nb > 0 ? R.nrec : 0u;
     const bool wide = nb > kWave;   // wave-uniform
+    {
+        // a BURST unit -- more records than uc.stage and than three times its window's average -- goes to the hot launch, untouched:
+        // several waves per unit there (k_voxel_hot).  A uniformly dense window (every unit near the average: one or two election
+        // rounds per batch) streams whatever its units hold.
+        const uint32_t avg = (uint32_t)((uint64_t)n_win / (uint64_t)(H * nchunk));   // records per unit, on average
+        if (nrec > (uint32_t)uc.stage && nrec > 3u * avg) {   // wave-uniform
+            if (!defer_items(bv, uid, (uint32_t)kHotWhole, 1u) && lane == 0)
+                atomicOr(&bv.stats_rw[(size_t)b * bv.nblk].status, EVREP_ST_HOT_OVERFLOW);
+            return;
+        }
+    }
     double *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * bins;
     double t0 = 0.0, den = 1.0;
     if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
@@ -3998,6 +4009,258 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
     }
     tile_store(acc, ncell, dst);
 }
+
+// --------------------------------------------------------------------------------------------
+// A2 (r06): BURST units of the voxel grid -- several waves per unit.
+// A unit of a clustered window whose records come in bursts on a few pixels (a moving blob) costs the stream as many election rounds
+// as its hottest pixel holds records of each batch -- 540 rounds of ~0.2 us of a lone wave for ONE Gen1 circle unit of 2 100 records,
+// the launch's tail -- while the chain that has to be sequential is short: the terms of ONE cell (pixel, bin), 60 of them.  The main
+// wave hands a unit of more than uc.stage records and more than three times its window's average over untouched (item kHotWhole); a
+// workgroup of kVhWaves waves takes it, pass by pass, in chunks of kVhChunk records (array order):
+//   count   every wave sweeps its contiguous share of the chunk: the record's cell of this pass (its digest: the float64 division),
+//           LDS atomicAdd on its OWN row of cell counters;
+//   scan    cell starts and per-(wave, cell) cursors: an earlier wave's terms of a cell lie in front of a later wave's;
+//   place   the same sweep again: ranks inside a batch by a ballot match over the cell index, the record's 8-byte TERM (w * p) to its
+//           place of the chunk's stage -- stable: every cell's terms stay in array order;
+//   fold    one thread per cell adds the cell's terms onto the cell, four LDS reads in flight: the chain is one float64 add per term.
+// Pass 1's terms go on top of pass 0's of the WHOLE unit, so the passes are the outer loop.  The tile leaves as one burst.
+// LDS: cells [npixa * bins] f64 | cnt [kVhWaves][ncella] | seg [ncella + 1] | rt [2][128] | touched [npixa] | tmp | stage [kVhChunk] f64
+#ifndef EVREP_VH_WAVES
+#define EVREP_VH_WAVES 8
+#endif
+constexpr int kVhWaves = EVREP_VH_WAVES, kVhThreads = kVhWaves * kWave, kVhChunk = 4096, kVhGrid = 256, kVhMaxBins = 8;
+static_assert(kVhGrid % kHotLists == 0, "every sublist is worked off by kVhGrid / kHotLists workgroups");
+__host__ __device__ inline size_t voxel_hot_lds_bytes(int bins, int npixa) {
+    const size_t ncella = (size_t)npixa * bins;
+    return align16(ncella * 8) + (size_t)kVhWaves * ncella * 4 + align16((ncella + 1) * 4) + 256 * 4 + align16((size_t)npixa) + 64 +
+           (size_t)kVhChunk * 8;
+}
+#ifdef EVREP_TU_BUILDERS   // (compiled by the one translation unit that launches it)
+static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__restrict__ ev, BinView bv, const int64_t *__restrict__ off,
+                                                              int H, int W, int nchunk, UnitCfg uc, int bins, int mode, double scale,
+                                                              const int64_t *__restrict__ t_range, const double *__restrict__ tnorm,
+                                                              double *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t l = blockIdx.x % kHotLists, capl = hot_sublist_cap(bv.hot_cap);
+    const uint32_t nraw = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.hot[l * 16]);
+    if (nraw == 0u) return;
+    const uint32_t nitems = min(nraw, capl);
+    const uint32_t *items = bv.hot + kHotHdrWords + (size_t)l * capl;
+    const int npixa = (uc.span + uc.merge) * kChunkPx;
+    const int ncella = npixa * bins;
+    double *acc = reinterpret_cast<double *>(smem);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + align16((size_t)ncella * 8));                        // [kVhWaves][ncella]
+    uint32_t *seg = cnt + kVhWaves * ncella;                                                                  // [ncella + 1]
+    uint32_t *rt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(seg) + align16((size_t)(ncella + 1) * 4));   // [2][128]
+    unsigned char *touched = reinterpret_cast<unsigned char *>(rt + 256);
+    uint32_t *tmp = reinterpret_cast<uint32_t *>(touched + align16((size_t)npixa));                          // [16]
+    double *stage = reinterpret_cast<double *>(tmp + 16);
+    for (uint32_t it = blockIdx.x / kHotLists; it < nitems; it += gridDim.x / kHotLists) {
+        const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
+        if (item >= 0 && item % kHotCodes == kHotWhole) {
+            const int uid = item / kHotCodes;
+            int chunk, nch;
+            const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+            const int b = g.b;
+            const int64_t beg = off[b];
+            const int64_t n_win = off[b + 1] - beg;
+            int tz0 = 0, tz1 = 0;
+            if (n_win > 0) { tz0 = ev[beg].z; tz1 = ev[beg + n_win - 1].z; }
+            const int NK = H * nchunk, klo = g.row * nchunk + chunk;
+            const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, klo + nch);   // (every wave reads the unit's run tables itself)
+            const int nb = R.nb;
+            const uint32_t nrec = nb > 0 ? R.nrec : 0u;
+            const int ncell = g.npix * bins;
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(acc);
+                for (int v = tid; v * 2 < ncell; v += kVhThreads) z[v] = make_uint4(0u, 0u, 0u, 0u);
+                for (int v = tid; v < npixa; v += kVhThreads) touched[v] = 0;
+            }
+            const uint32_t src0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0 - R.pre0;
+            const uint32_t src1 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1 - R.pre1;
+            if (wv == 0 && nb > kBsChainBlocks) {
+                rt[lane] = R.pre0; rt[128 + lane] = src0;
+                if (nb > kWave) { rt[kWave + lane] = R.pre1; rt[128 + kWave + lane] = src1; }
+            }
+            double *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * bins;
+            double t0 = 0.0, den = 1.0;
+            if (n_win > 0) { t0 = (double)tz0; den = (double)tz1 - t0; }
+            if (t_range) { t0 = (double)t_range[2 * b]; den = (double)(t_range[2 * b + 1] - t_range[2 * b]); }
+            const double *tw = tnorm ? tnorm + beg : nullptr;
+            const int4 *evw = ev + beg;
+            const int c0 = g.c0;
+            const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+            const double lowlim = mode == 2 ? -1.0 : -0.0;
+            auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
+                if (nb <= kBsChainBlocks) {
+                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
+                    uint32_t prev = sx;
+                    for (int k = 1; k < nb; ++k) {
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)R.pre0, k);
+                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src0, k);
+                        sx += (j >= pk) ? sk - prev : 0u;
+                        prev = sk;
+                    }
+                    return sx + j;
+                }
+                uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+                for (int step = 0; step < 7; ++step) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool go = hi - lo > 1 && rt[mid] <= j;
+                    if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+                }
+                return rt[128 + lo] + j;
+            };
+            // a record's cell and term of `pass` (k_voxel's digest + the body of its reduce); false: no contribution
+            auto term = [&](int pass, const Rec8 &q, uint32_t &px, uint32_t &cell, double &wp) -> bool {
+                px = ((q.y & 511u) - (uint32_t)c0) & 511u;
+                const uint32_t p2 = (q.y >> 9) & 3u;
+                int p = (int)p2 - 1;
+                if (p2 == 3u) p = evw[q.y >> 11].w;
+                double bpos;
+                if (tw) bpos = (double)(bins - 1) * tw[q.y >> 11];
+                else {
+                    const int t = (int)q.x;
+                    if (mode == 2) { const int64_t num = (int64_t)(bins - 1) * ((int64_t)t - (int64_t)t0); bpos = (double)num / (den == 0.0 ? 1.0 : den); }
+                    else if (mode == 0) { const double tn = ((double)t - t0) / den; bpos = (double)(bins - 1) * tn; }
+                    else { const double num = (double)bins * ((double)t - t0); bpos = num / den; }
+                }
+                double pd = (double)p;
+                if (mode == 1 && p == 0) pd = -1.0;
+                if (!((bpos > lowlim && bpos < 1.0e9) || bpos == 0.0)) return false;
+                const int bi = (int)bpos;
+                const int blim = bi + pass;
+                if (blim >= bins) return false;
+                double wgt;
+                if (mode == 2) wgt = 1.0;
+                else if (mode == 0) wgt = 1.0 - fabs((double)blim - bpos);
+                else { const double dts = bpos - (double)bi; wgt = pass ? dts : 1.0 - dts; }
+                wp = wgt * pd;
+                cell = px * (uint32_t)bins + (uint32_t)blim;
+                return true;
+            };
+            const int nbits = 32 - __builtin_clz((unsigned)ncella - 1u);
+            const int npass = mode == 2 ? 1 : 2;
+            const uint32_t nchunks = (nrec + (uint32_t)kVhChunk - 1u) / (uint32_t)kVhChunk;
+            uint32_t *mycnt = cnt + wv * ncella;
+            volatile uint32_t *vcnt = mycnt;
+            __syncthreads();
+            for (int pass = 0; pass < npass; ++pass) {
+                for (uint32_t ch = 0; ch < nchunks; ++ch) {
+                    const uint32_t lo = ch * (uint32_t)kVhChunk, hi = min(nrec, lo + (uint32_t)kVhChunk);
+                    const uint32_t piece = (((hi - lo + (uint32_t)kVhWaves - 1u) / (uint32_t)kVhWaves) + 63u) & ~63u;
+                    const uint32_t mlo = min(hi, lo + (uint32_t)wv * piece), mhi = min(hi, mlo + piece);
+                    for (int v = tid; v < kVhWaves * ncella; v += kVhThreads) cnt[v] = 0u;
+                    __syncthreads();
+                    constexpr int G = 4;
+                    for (uint32_t j0 = mlo; j0 < mhi; j0 += (uint32_t)(G * kWave)) {
+                        Rec8 q[G];
+#pragma unroll
+                        for (int sl = 0; sl < G; ++sl) {
+                            const uint32_t j = j0 + (uint32_t)(sl * kWave + lane);
+                            q[sl] = make_uint2(0u, 0u);
+                            if (j < mhi) q[sl] = s8[src_of(j)];
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < G; ++sl) {
+                            if (j0 + (uint32_t)(sl * kWave + lane) < mhi) {
+                                uint32_t px, cell; double wp;
+                                const bool ok = term(pass, q[sl], px, cell, wp);
+                                if (pass == 0) touched[px] = 1;
+                                if (ok) atomicAdd(&mycnt[cell], 1u);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    {   // cell starts of the chunk; cursors of every (wave, cell): `cpt` consecutive cells per thread
+                        const int cpt = (ncella + kVhThreads - 1) / kVhThreads;
+                        const int k0 = tid * cpt;
+                        uint32_t local = 0;
+                        for (int k = 0; k < cpt; ++k)
+                            if (k0 + k < ncella) for (int w2 = 0; w2 < kVhWaves; ++w2) local += cnt[w2 * ncella + k0 + k];
+                        uint32_t total;
+                        uint32_t run = block_exclusive_scan<kVhWaves>(local, tmp, &total);
+                        for (int k = 0; k < cpt; ++k) {
+                            if (k0 + k < ncella) {
+                                seg[k0 + k] = run;
+                                for (int w2 = 0; w2 < kVhWaves; ++w2) { const uint32_t c = cnt[w2 * ncella + k0 + k]; cnt[w2 * ncella + k0 + k] = run; run += c; }
+                            }
+                        }
+                        if (tid == 0) seg[ncella] = total;
+                    }
+                    __syncthreads();
+                    for (uint32_t j0 = mlo; j0 < mhi; j0 += (uint32_t)(G * kWave)) {
+                        Rec8 q[G];
+#pragma unroll
+                        for (int sl = 0; sl < G; ++sl) {
+                            const uint32_t j = j0 + (uint32_t)(sl * kWave + lane);
+                            q[sl] = make_uint2(0u, 0u);
+                            if (j < mhi) q[sl] = s8[src_of(j)];
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < G; ++sl) {
+                            if (j0 + (uint32_t)(sl * kWave) >= mhi) break;   // uniform
+                            const bool have = j0 + (uint32_t)(sl * kWave + lane) < mhi;
+                            uint32_t px = 0u, cell = 0u; double wp = 0.0;
+                            const bool valid = have && term(pass, q[sl], px, cell, wp);
+                            if (!__any(valid)) continue;
+                            if (!valid) cell = 0u;
+                            uint32_t rk; bool last;
+                            wave_match(cell, nbits, valid, lane, rk, last);
+                            uint32_t pos = 0;
+                            if (valid) { pos = vcnt[cell] + rk; stage[pos] = wp; }
+                            __builtin_amdgcn_wave_barrier();
+                            if (valid && last) vcnt[cell] = pos + 1;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    __syncthreads();
+                    // fold: a thread per cell, the cell's terms in array order, four reads in flight
+                    for (int cell = tid; cell < ncell; cell += kVhThreads) {
+                        const uint32_t st = seg[cell], en = seg[cell + 1];
+                        if (en > st) {
+                            double run = acc[cell];
+                            uint32_t j = st;
+                            for (; j + 4u <= en; j += 4u) {
+                                const double a0 = stage[j], a1 = stage[j + 1], a2 = stage[j + 2], a3 = stage[j + 3];
+                                run = run + a0; run = run + a1; run = run + a2; run = run + a3;
+                            }
+                            for (; j < en; ++j) run = run + stage[j];
+                            acc[cell] = run;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (scale != 1.0) {   // the pixels that hold records are scaled, bin by bin (k_voxel's reduce); empty ones stay +0
+                const uint32_t inv = (65536u + (uint32_t)bins - 1u) / (uint32_t)bins;
+                for (int v = tid; v < ncell; v += kVhThreads) {
+                    const uint32_t px = ((uint32_t)v * inv) >> 16;
+                    if (touched[px]) acc[v] = acc[v] * scale;
+                }
+                __syncthreads();
+            }
+            {
+                const int nvec = ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) ? ncell / 2 : 0;
+                const float4 *s4 = reinterpret_cast<const float4 *>(acc);
+                float4 *d4 = reinterpret_cast<float4 *>(dst);
+                for (int v = tid; v < nvec; v += kVhThreads) d4[v] = s4[v];
+                for (int e = nvec * 2 + tid; e < ncell; e += kVhThreads) dst[e] = acc[e];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t ticket = atomicAdd(&bv.hot[(kHotLists + l) * 16], 1u);
+        if (ticket + 1u == gridDim.x / kHotLists) {   // the sublist's last workgroup: every other one has read its items
+            bv.hot[(kHotLists + l) * 16] = 0u;
+            bv.hot[l * 16] = 0u;
+        }
+    }
+}
+#endif
 
 // --------------------------------------------------------------------------------------------
 // F4: n_imagenet's per-polarity accumulators (n_imagenet/real_cnn_model/data/imagenet.py:169-511,841-871)

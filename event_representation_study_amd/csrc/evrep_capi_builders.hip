@@ -219,12 +219,29 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
         // after the key-sorted pass: the streaming form (k_voxel_stream) -- one launch, every unit, no hot list
         UnitCfg us = unit_cfg(plan, (size_t)bins * 8);
         us.span = 1; us.merge = 0; us.hold = 0;
+        // (the stream has no record stage: the field carries the burst threshold) a unit of more records than this AND of more than three
+        // times its window's average is handed to k_voxel_hot (grids of up to kVhMaxBins bins: its per-wave cell counters must fit LDS)
+        const bool hot = bins <= kVhMaxBins;
+        us.stage = hot ? 768 : 0x7fffffff;
+        if (const char *e = getenv("EVREP_VS_HOTMIN")) us.stage = atoi(e);        // EXPERIMENT (r06 tuning; removed once settled)
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
         k_voxel_stream<kRB><<<SPAN_GRID(1), kWave, voxel_stream_lds_bytes(bins, kChunkPx, kRB), stream>>>(
             reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us,
             bins, mode, scale, t_range, tnorm, out);
+        if (hot) {
+            const size_t lds = voxel_hot_lds_bytes(bins, kChunkPx);
+            if (lds > 64 * 1024) {   // per (function, device) opt-in, renewed per launch (see k_block_keysort)
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_voxel_hot), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return EVREP_EHIP;
+                }
+            }
+            k_voxel_hot<<<kVhGrid, kVhThreads, lds, stream>>>(
+                reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us,
+                bins, mode, scale, t_range, tnorm, out);
+        }
         LAUNCH_CHECK("k_voxel_stream");
         return EVREP_OK;
     }
