@@ -1779,7 +1779,7 @@ struct StreamRuns {
     }
 };
 __device__ inline StreamRuns stream_runs(const BinView &bv, int b, int64_t n_win, int NK, int klo, int khi) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);   // (lane-relative: k_voxel_hot's workgroups hold several waves, each reads the tables itself)
     StreamRuns r;
     r.a0 = 0; r.a1 = 0; r.len0 = 0; r.len1 = 0; r.pre0 = 0; r.pre1 = 0; r.nrec = 0;
     uint32_t k0v = 0, k1v = 0;
@@ -4026,7 +4026,7 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
 // Pass 1's terms go on top of pass 0's of the WHOLE unit, so the passes are the outer loop.  The tile leaves as one burst.
 // LDS: cells [npixa * bins] f64 | cnt [kVhWaves][ncella] | seg [ncella + 1] | rt [2][128] | touched [npixa] | tmp | stage [kVhChunk] f64
 #ifndef EVREP_VH_WAVES
-#define EVREP_VH_WAVES 8
+#define EVREP_VH_WAVES 16
 #endif
 constexpr int kVhWaves = EVREP_VH_WAVES, kVhThreads = kVhWaves * kWave, kVhChunk = 4096, kVhGrid = 256, kVhMaxBins = 8;
 static_assert(kVhGrid % kHotLists == 0, "every sublist is worked off by kVhGrid / kHotLists workgroups");
@@ -4060,6 +4060,14 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
         const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
         if (item >= 0 && item % kHotCodes == kHotWhole) {
             const int uid = item / kHotCodes;
+#ifdef EVREP_TIMING   // experiment builds: 10 ns ticks since the item started, cumulative per phase: 0 tables, 1 count, 2 scan, 3 place, 4 fold, 5 total, 6 records
+            const long long tm0 = (long long)wall_clock64();
+            long long tph[5] = {0, 0, 0, 0, 0}, tlast = tm0;
+            unsigned long long *dbg = bv.dbg ? bv.dbg + 8 * (size_t)uid : nullptr;
+#define VH_PH(i_) do { const long long t_ = (long long)wall_clock64(); tph[i_] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define VH_PH(i_) do {} while (0)
+#endif
             int chunk, nch;
             const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
             const int b = g.b;
@@ -4147,6 +4155,7 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
             uint32_t *mycnt = cnt + wv * ncella;
             volatile uint32_t *vcnt = mycnt;
             __syncthreads();
+            VH_PH(0);
             for (int pass = 0; pass < npass; ++pass) {
                 for (uint32_t ch = 0; ch < nchunks; ++ch) {
                     const uint32_t lo = ch * (uint32_t)kVhChunk, hi = min(nrec, lo + (uint32_t)kVhChunk);
@@ -4174,6 +4183,7 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
                         }
                     }
                     __syncthreads();
+                    VH_PH(1);
                     {   // cell starts of the chunk; cursors of every (wave, cell): `cpt` consecutive cells per thread
                         const int cpt = (ncella + kVhThreads - 1) / kVhThreads;
                         const int k0 = tid * cpt;
@@ -4191,6 +4201,7 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
                         if (tid == 0) seg[ncella] = total;
                     }
                     __syncthreads();
+                    VH_PH(2);
                     for (uint32_t j0 = mlo; j0 < mhi; j0 += (uint32_t)(G * kWave)) {
                         Rec8 q[G];
 #pragma unroll
@@ -4217,6 +4228,7 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
                         }
                     }
                     __syncthreads();
+                    VH_PH(3);
                     // fold: a thread per cell, the cell's terms in array order, four reads in flight
                     for (int cell = tid; cell < ncell; cell += kVhThreads) {
                         const uint32_t st = seg[cell], en = seg[cell + 1];
@@ -4232,6 +4244,7 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
                         }
                     }
                     __syncthreads();
+                    VH_PH(4);
                 }
             }
             if (scale != 1.0) {   // the pixels that hold records are scaled, bin by bin (k_voxel's reduce); empty ones stay +0
@@ -4249,6 +4262,12 @@ static __global__ __launch_bounds__(kVhThreads) void k_voxel_hot(const int4 *__r
                 for (int v = tid; v < nvec; v += kVhThreads) d4[v] = s4[v];
                 for (int e = nvec * 2 + tid; e < ncell; e += kVhThreads) dst[e] = acc[e];
             }
+#ifdef EVREP_TIMING
+            if (tid == 0 && dbg) {
+                for (int q_ = 0; q_ < 5; ++q_) dbg[q_] = (unsigned long long)tph[q_];
+                dbg[5] = (unsigned long long)((long long)wall_clock64() - tm0); dbg[6] = (unsigned long long)nrec * 100ull;
+            }
+#endif
         }
         __syncthreads();
     }

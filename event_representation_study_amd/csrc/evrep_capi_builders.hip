@@ -222,8 +222,10 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
         // (the stream has no record stage: the field carries the burst threshold) a unit of more records than this AND of more than three
         // times its window's average is handed to k_voxel_hot (grids of up to kVhMaxBins bins: its per-wave cell counters must fit LDS)
         const bool hot = bins <= kVhMaxBins;
+        // (measured, r06, build in us, stream only / threshold 768 with 16 waves per unit: Gen1 circle 148 / 126, 640x480 circle 132 / 118,
+        //  1 Mpx circle 233 / 155; the edge streams, whose largest units hold ~1 000 records at 4-5 per batch and pixel, 80 / 93 and 93 / 91:
+        //  a unit of that size is cheaper inside the main launch's tail than in a launch behind it)
         us.stage = hot ? 768 : 0x7fffffff;
-        if (const char *e = getenv("EVREP_VS_HOTMIN")) us.stage = atoi(e);        // EXPERIMENT (r06 tuning; removed once settled)
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
         constexpr int kRB = 4;

@@ -1,4 +1,4 @@
-for cfg in "1000000" "128" "256" "512" "1024"; do
+for cfg in "768" "1024"; do
   set -- $cfg
   echo "== hotmin $1"
   EVREP_VS_HOTMIN=$1 python tools/bench_sweep.py gen1 gen1@circle gen1@edges c2 c2@circle c3@circle c3@edges c2-dense b=voxel5_f64 2>/dev/null | python -c "
