@@ -224,7 +224,8 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
         const bool hot = bins <= kVhMaxBins;
         // (measured, r06, build in us, stream only / threshold 768 with 16 waves per unit: Gen1 circle 148 / 126, 640x480 circle 132 / 118,
         //  1 Mpx circle 233 / 155; the edge streams, whose largest units hold ~1 000 records at 4-5 per batch and pixel, 80 / 93 and 93 / 91:
-        //  a unit of that size is cheaper inside the main launch's tail than in a launch behind it)
+        //  a unit of that size is cheaper inside the main launch's tail than in a launch behind it; a threshold of 1 536 loses on the circles --
+        //  640x480 155 us: the units of 768-1 536 records then make the main launch's tail AND the hot launch still runs behind it)
         us.stage = hot ? 768 : 0x7fffffff;
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
