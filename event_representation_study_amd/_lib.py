@@ -86,7 +86,7 @@ SYMBOLS = {
 PLAN_NO_KEY_PASS, PLAN_THREE_KERNEL, PLAN_FORCE_KEY_SORTED, PLAN_BIG_BLOCKS, PLAN_NO_FUSED_SCATTER = 1, 2, 4, 8, 16
 _ENV_FLAGS = (("EVREP_BIN_CLASSIC", PLAN_NO_KEY_PASS), ("EVREP_BIN_THREE_KERNEL", PLAN_THREE_KERNEL),
               ("EVREP_BIN_KEY_SORTED", PLAN_FORCE_KEY_SORTED), ("EVREP_KS_BIG_BLOCKS", PLAN_BIG_BLOCKS),
-              ("EVREP_NO_FUSED_SCATTER", PLAN_NO_FUSED_SCATTER), ("EVREP_X_SPAN2", 64), ("EVREP_X_STAGE128", 128), ("EVREP_X_TAIL_MERGE", 256), ("EVREP_X_STAGE64", 512), ("EVREP_X_HANDOVER2", 1024), ("EVREP_X_HANDOVER_DENSE", 2048), ("EVREP_X_NO_SWEEP_MAIN", 4096), ("EVREP_X_NO_MONSTER_HANDOVER", 8192), ("EVREP_X_VOXEL_ORDERED", 16384), ("EVREP_X_TORE_ORDERED", 32768), ("EVREP_X_POLSTATS_ORDERED", 65536), ("EVREP_X_ESTACK_ORDERED", 131072), ("EVREP_X_MDES_ORDERED", 262144), ("EVREP_X_MDES_STREAM", 524288), ("EVREP_X_TS_STREAM", 1048576), ("EVREP_X_TS_ORDERED", 2097152))
+              ("EVREP_NO_FUSED_SCATTER", PLAN_NO_FUSED_SCATTER), ("EVREP_X_SPAN2", 64), ("EVREP_X_STAGE128", 128), ("EVREP_X_TAIL_MERGE", 256), ("EVREP_X_STAGE64", 512), ("EVREP_X_HANDOVER2", 1024), ("EVREP_X_HANDOVER_DENSE", 2048), ("EVREP_X_NO_SWEEP_MAIN", 4096), ("EVREP_X_NO_MONSTER_HANDOVER", 8192), ("EVREP_X_VOXEL_ORDERED", 16384), ("EVREP_X_TORE_ORDERED", 32768), ("EVREP_X_POLSTATS_ORDERED", 65536), ("EVREP_X_ESTACK_ORDERED", 131072), ("EVREP_X_MDES_ORDERED", 262144), ("EVREP_X_MDES_STREAM", 524288), ("EVREP_X_TS_STREAM", 1048576), ("EVREP_X_TS_ORDERED", 2097152), ("EVREP_X_MDES_NO_COOP", 4194304))
 
 
 def plan_flags_from_env():

@@ -560,6 +560,8 @@ struct UnitSplit { static constexpr bool enabled = true; static constexpr bool i
                    Merge merge;   // merge(mine, unit): a time slice's words of one pixel into the unit's words in global memory (atomics; sub-waves)
                    Pre pre;       // pre(record) -> 8 bytes the builder wants of the record from global memory (its caller-side time): gathered for every
                                   // batch of a round before the first f() -- all in flight together -- and handed to f as `aux`
+                   uint32_t coop_min = 0u;   // main launch, IN_HOT (r06): a unit of at least this many records goes to the hot list as ONE item kHotCoop
+                                             // -- for the builder's cooperative launch of several waves per unit -- instead of whole / in time slices (0: never)
 };
 template <bool IN_HOT = false, typename Begin, typename F, typename Done>
 __device__ inline UnitSplit<IN_HOT, Begin, F, Done> unit_split(Begin b, F f, Done d, int words_per_px, uint32_t st_lane = 0u, uint32_t min_rec = 0u) { return UnitSplit<IN_HOT, Begin, F, Done>{b, f, d, words_per_px, st_lane, min_rec, NoMerge(), NoPre()}; }
@@ -773,14 +775,16 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         const uint32_t stw = wave_or(lane < nb ? split.st_lane : 0u);
         // (warm units too -- those that would fit this wave's hot stage: measured, r05b, ordering them here makes the main launch
         //  of a clustered batch 30-40 % longer, which the hot launch they spare does not give back)
-        if (!(stw & kStEscaped) && nrec >= split.min_rec && nrec <= 65535u && dpx == 0) {
+        if (!(stw & kStEscaped) && (nrec >= split.min_rec || (split.coop_min != 0u && nrec >= split.coop_min)) && nrec <= 65535u && dpx == 0) {
             // A unit of >= kHotSubMin records is taken in TIME slices (r05b): S hot waves sweep ~1 000 consecutive records each into
             // their own words, merge them into the unit's words in its spill slot (global atomics: sums, flags, maxima), leave their
             // kept records there, and the last one to finish orders the kept records and emits the unit.  One wave's instruction
             // stream bounds a sweep at ~250 instructions per 64 records: a 20 000-record unit of a 1 Mpx circle window took one
             // hot wave 100 us, the whole launch's tail.  This wave clears the slot's header and words (visible at the launch boundary).
             bool ok;
-            if (Split::sliceable && nrec >= kHotSubMin) {
+            if (split.coop_min != 0u && nrec >= split.coop_min) {
+                ok = defer_items(bv, uid, (uint32_t)kHotCoop, 1u);
+            } else if (Split::sliceable && nrec >= kHotSubMin) {
                 uint4 *z = reinterpret_cast<uint4 *>(bv.spill + cs);
                 const uint32_t nz = (kHotSubHdrBytes + 4u * split_gwpp(split.words_per_px) * (uint32_t)npixu + 15u) / 16u;
                 for (uint32_t i = (uint32_t)lane; i < nz; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -2007,6 +2011,7 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 // A record of escaped polarity (p outside {-1, 0, 1}: sum p^2 may leave the integers float64 holds exactly) sends its unit to the
 // ordered paths.
 constexpr int kErgoSplitWords = 7;
+constexpr uint32_t kErgoCoopMin = 4096u;   // records from which the ordered float32 builder's hot units go to k_mdes_coop
 // the ERGO-12 channels of rank window `wnd`, as bits
 constexpr uint32_t ergo_chans_of(int wnd) {
     uint32_t m = 0;
@@ -2225,10 +2230,10 @@ __device__ inline void mdes_unit(const BinView &bv, const int64_t *__restrict__ 
         auto never = []() -> bool { return false; };
         auto nof = [](uint32_t, const Rec8 &, uint2 &, const uint2 &) -> bool { return false; };
         // lane k: the status word of the window's block k (meta_prefetch: q2.x), merged by unit_records only when a unit is hot
-        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(),
-                                                  unit_split<true>(never, nof, never, kErgoSplitWords,
-                                                                   (uint32_t)mraw.q2.x | ((uc.xflags & 6) ? 0u : kStEscaped),
-                                                                   (uc.xflags & 2) ? 0u : kHotSubMin));
+        auto sp = unit_split<true>(never, nof, never, kErgoSplitWords, (uint32_t)mraw.q2.x | ((uc.xflags & 14) ? 0u : kStEscaped),
+                                   (uc.xflags & 2) ? 0u : kHotSubMin);
+        sp.coop_min = (uc.xflags & 8) ? kErgoCoopMin : 0u;   // r06: a cooperative launch of sixteen waves per unit takes the big ones (k_mdes_coop)
+        u = unit_front<OutT, HOT, false, NoVisit>(bv, off, H, W, nchunk, uc, w, g, uid, part, NoVisit(), sp);
         // (two-chunk units -- sparse windows, 640x480 / 1280x720 at 50 000 - 200 000 events -- keep the ordered ways: measured, r05b,
         //  their hot units are few and huge -- 4 000 to 20 000 records, one wave's instruction stream each, 30 to 100 us of sweep --
         //  and the hot launch's tail costs 5-8 % more than it saves; at the reference's Gen1 shape the hand-over takes the
@@ -2456,6 +2461,7 @@ __global__ __launch_bounds__(kWave, HOT ? ((MdesIsErgo12<D>::value && sizeof(Out
                                                OutT *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     run_units<HOT>(bv, [&](int uid, int part) {
+        if (HOT && part == kHotCoop) return;   // (k_mdes_coop's item)
         const int C = D::C(P);
         WaveLds<OutT, HOT> w(smem, C, (uc.span + uc.merge) * kChunkPx, uc.stage, uc.partpx);
         w.arm(uc.hold);
@@ -2701,6 +2707,298 @@ __global__ __launch_bounds__(kWave, EVREP_MS_WAVES) void k_mdes_stream(BinView b
     OutT *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * C;
     tile_store(tile, g.npix * C, dst);
 }
+
+// --------------------------------------------------------------------------------------------
+// A5 (r06): the big hot units of the ORDERED float32 ERGO-12 builder (sparse windows) -- SIXTEEN waves per unit.
+// Until r05 such a unit was swept in time slices by up to sixteen independent hot waves that merged their words through the unit's
+// spill slot with global atomics, and the wave that took the last ticket ordered the kept records of ch6 / ch1 -- a third of the unit,
+// 6 600 records of a 1 Mpx circle monster -- through global memory and walked them: 95-100 us of ONE wave, the launch's tail.  Here
+// the main wave hands a unit of >= kErgoCoopMin records over as ONE item (kHotCoop) and a workgroup of kMcWaves waves takes it, in
+// chunks of kMcChunk records (array order): every wave sweeps its contiguous share -- the order-free channels by LDS atomics on the
+// unit's SHARED state (k_mdes_stream's twenty words per pixel), the kept records counted per (wave, cell = pixel x {ch6, ch1}); a scan
+// makes cell starts and per-(wave, cell) cursors; the same sweep again places the kept records' normalised timestamps (the float64
+// division, one record per lane) stably in the chunk's stage; a thread per cell adds them onto the pixel's sums in array order; at the
+// end a thread per pixel forms the twelve values (mdes_unit's finish) and stores them.  Windows with escaped polarity values never
+// come here (their units stay with the main launch's ordered paths).
+// LDS: state [npixa * 20] u32 | cnt [kMcWaves][2 npixa] | seg [2 npixa + 1] | rt [2][128] | window scalars | tmp | stage [kMcChunk] f64
+constexpr int kMcWaves = 16, kMcThreads = kMcWaves * kWave, kMcChunk = 4096, kMcGrid = 256;
+static_assert(kMcGrid % kHotLists == 0, "every sublist is worked off by kMcGrid / kHotLists workgroups");
+__host__ __device__ inline size_t mdes_coop_lds_bytes(int npixa) {
+    return align16((size_t)npixa * kErgoStreamWords * 4) + (size_t)kMcWaves * 2 * npixa * 4 + align16((size_t)(2 * npixa + 1) * 4) + 256 * 4 + 128 + 64 +
+           (size_t)kMcChunk * 8;
+}
+#ifdef EVREP_TU_MDES   // (compiled by the one translation unit that launches it)
+static __global__ __launch_bounds__(kMcThreads) void k_mdes_coop(BinView bv, const int64_t *__restrict__ off, int H, int W, int nchunk, UnitCfg uc,
+                                                             double scale, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    using T = Ergo12Table;
+    constexpr int C = 12, NWD = kErgoStreamWords;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t l = blockIdx.x % kHotLists, capl = hot_sublist_cap(bv.hot_cap);
+    const uint32_t nraw = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv.hot[l * 16]);
+    if (nraw == 0u) return;
+    const uint32_t nitems = min(nraw, capl);
+    const uint32_t *items = bv.hot + kHotHdrWords + (size_t)l * capl;
+    const int npixa = (uc.span + uc.merge) * kChunkPx, ncella = 2 * npixa;
+    uint32_t *words = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * NWD * 4));                        // [kMcWaves][ncella]
+    uint32_t *seg = cnt + kMcWaves * ncella;                                                                       // [ncella + 1]
+    uint32_t *rt = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(seg) + align16((size_t)(ncella + 1) * 4));   // [2][128]
+    struct WinScalars { double interval; unsigned long long pmask; int32_t tmin, hi1, hi2, hi3, lo4, lo5, lo6; };
+    WinScalars *ws = reinterpret_cast<WinScalars *>(rt + 256);                                                    // (128 bytes reserved)
+    uint32_t *tmp = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ws) + 128);                     // [16]
+    double *stage = reinterpret_cast<double *>(tmp + 16);
+    // (the one-wave hot launch behind this one clears the list: it takes the exit tickets)
+    for (uint32_t it = blockIdx.x / kHotLists; it < nitems; it += gridDim.x / kHotLists) {
+        const int item = __builtin_amdgcn_readfirstlane((int)items[it]);
+        if (item >= 0 && item % kHotCodes == kHotCoop) {
+            const int uid = item / kHotCodes;
+            int chunk, nch;
+            const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
+            const int b = g.b;
+            const int64_t beg = off[b];
+            const int64_t n_win = off[b + 1] - beg;
+            const int NK = H * nchunk, klo = g.row * nchunk + chunk;
+            const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, klo + nch);   // (every wave reads the unit's run tables itself)
+            const int nb = R.nb;
+            const uint32_t nrec = nb > 0 ? R.nrec : 0u;
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(words);
+                const int nvec = (g.npix * NWD + 3) / 4;
+                for (int v = tid; v < nvec; v += kMcThreads) z[v] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            const uint32_t src0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0 - R.pre0;
+            const uint32_t src1 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1 - R.pre1;
+            if (wv == 0) {   // threadIdx.x == lane here: the window's statistics and the per-channel classes, once per item
+                if (nb > kBsChainBlocks) {
+                    rt[lane] = R.pre0; rt[128 + lane] = src0;
+                    if (nb > kWave) { rt[kWave + lane] = R.pre1; rt[128 + kWave + lane] = src1; }
+                }
+                const WindowMeta m = window_meta(bv, off, b);
+                const MdesWindows mw = mdes_windows(n_win);
+                uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int wi = T::kWin[c], f = T::kFunc[c];
+                    uint32_t cls = 7u;
+                    int field = 0;
+                    if (f == EVREP_F_TIMESTAMP_POS || f == EVREP_F_COUNT_POS) { cls = 4u; field = 1; }
+                    if (f == EVREP_F_TIMESTAMP_NEG || f == EVREP_F_COUNT_NEG) {
+                        const bool has_neg = (m.neg_flags >> wi) & 1u;   // operations.py:59-61,78-80
+                        cls = has_neg ? 1u : 2u;
+                        field = has_neg ? 2 : 3;
+                    }
+                    if (n_win <= 0 || ((m.oob_flags >> (7 * field + wi)) & 1u)) cls = 0u;
+                    a0 |= (cls & 1u) << c; a1 |= ((cls >> 1) & 1u) << c; a2 |= ((cls >> 2) & 1u) << c;
+                }
+                if (lane == 0) {
+                    ws->interval = (double)((int64_t)m.tmax - (int64_t)m.tmin);
+                    ws->pmask = (unsigned long long)a0 | ((unsigned long long)a1 << 16) | ((unsigned long long)a2 << 32);
+                    ws->tmin = m.tmin; ws->hi1 = mw.hi[1]; ws->hi2 = mw.hi[2]; ws->hi3 = mw.hi[3]; ws->lo4 = mw.lo[4]; ws->lo5 = mw.lo[5]; ws->lo6 = mw.lo[6];
+                }
+            }
+            __syncthreads();
+            const double interval = ws->interval;
+            const unsigned long long pmask = ws->pmask;
+            const int32_t tmin = ws->tmin, hi1 = ws->hi1, hi2 = ws->hi2, hi3 = ws->hi3, lo4 = ws->lo4, lo5 = ws->lo5, lo6 = ws->lo6;
+            const int c0 = g.c0;
+            const Rec8 *__restrict__ s8 = reinterpret_cast<const Rec8 *>(bv.sorted);
+            auto src_of = [&](uint32_t j) -> uint32_t {    // the address of record j of the unit in the block runs
+                if (nb <= kBsChainBlocks) {
+                    uint32_t sx = (uint32_t)__builtin_amdgcn_readlane((int)src0, 0);
+                    uint32_t prev = sx;
+                    for (int k = 1; k < nb; ++k) {
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)R.pre0, k);
+                        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)src0, k);
+                        sx += (j >= pk) ? sk - prev : 0u;
+                        prev = sk;
+                    }
+                    return sx + j;
+                }
+                uint32_t lo = 0, hi = (uint32_t)nb;
+#pragma unroll
+                for (int step = 0; step < 7; ++step) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool go = hi - lo > 1 && rt[mid] <= j;
+                    if (hi - lo > 1) { if (go) lo = mid; else hi = mid; }
+                }
+                return rt[128 + lo] + j;
+            };
+            // a record's channels (mdes_unit's sweep); p in {-1, 0, 1}: escaped windows never come here
+            auto hits_of = [&](const Rec8 &q) -> uint32_t {
+                const int rank = (int)(q.y >> 11);
+                const uint32_t p2 = (q.y >> 9) & 3u;
+                uint32_t chans = ergo_chans_of(0);
+                chans |= rank < hi1 ? ergo_chans_of(1) : (rank < hi2 ? ergo_chans_of(2) : (rank < hi3 ? ergo_chans_of(3) : 0u));
+                chans |= rank >= lo4 ? ergo_chans_of(4) : 0u;
+                chans |= rank >= lo5 ? ergo_chans_of(5) : 0u;
+                chans |= rank >= lo6 ? ergo_chans_of(6) : 0u;
+                return p2 == 3u ? 0u : (chans & (uint32_t)(pmask >> (16u * p2)));
+            };
+            const int nbits = 32 - __builtin_clz((unsigned)ncella - 1u);
+            const uint32_t nchunks = (nrec + (uint32_t)kMcChunk - 1u) / (uint32_t)kMcChunk;
+            uint32_t *mycnt = cnt + wv * ncella;
+            volatile uint32_t *vcnt = mycnt;
+            for (uint32_t ch = 0; ch < nchunks; ++ch) {
+                const uint32_t lo = ch * (uint32_t)kMcChunk, hi = min(nrec, lo + (uint32_t)kMcChunk);
+                const uint32_t piece = (((hi - lo + (uint32_t)kMcWaves - 1u) / (uint32_t)kMcWaves) + 63u) & ~63u;
+                const uint32_t mlo = min(hi, lo + (uint32_t)wv * piece), mhi = min(hi, mlo + piece);
+                for (int v = tid; v < kMcWaves * ncella; v += kMcThreads) cnt[v] = 0u;
+                __syncthreads();
+                constexpr int G = 4;
+                for (uint32_t j0 = mlo; j0 < mhi; j0 += (uint32_t)(G * kWave)) {
+                    Rec8 q[G];
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        const uint32_t j = j0 + (uint32_t)(sl * kWave + lane);
+                        q[sl] = make_uint2(0u, 0u);
+                        if (j < mhi) q[sl] = s8[src_of(j)];
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        if (j0 + (uint32_t)(sl * kWave + lane) < mhi) {
+                            const Rec8 r = q[sl];
+                            const uint32_t px = ((r.y & 511u) - (uint32_t)c0) & 511u;
+                            const int p = (int)((r.y >> 9) & 3u) - 1;
+                            const uint32_t tt = (uint32_t)((int64_t)(int32_t)r.x - (int64_t)tmin);
+                            const uint32_t hits = hits_of(r);
+                            uint32_t *wd = words + px * (uint32_t)NWD;
+                            auto hit = [&](int c) -> bool { return (hits >> c) & 1u; };
+                            if (hit(0)) atomicAdd(wd + (p > 0 ? 0 : (p < 0 ? 1 : 2)), 1u);
+                            if (hit(3) && p != 0) atomicAdd(wd + (p > 0 ? 4 : 5), 1u);
+                            if (hit(5)) atomicAdd(wd + 3, 1u);
+                            const uint32_t bits = hits & ((1u << 2) | (1u << 4) | (1u << 7) | (1u << 11) | (1u << 8) | (1u << 9) | (1u << 10));
+                            atomicOr(wd + 6, bits | 0x80000000u);
+                            if (hit(8)) atomicMax(wd + 7, tt);
+                            if (hit(9)) atomicMax(wd + 8, tt);
+                            if (hit(10)) atomicMax(wd + 9, tt);
+                            if (hit(6)) atomicAdd(&mycnt[2u * px], 1u);
+                            else if (hit(1)) atomicAdd(&mycnt[2u * px + 1u], 1u);
+                        }
+                    }
+                }
+                __syncthreads();
+                {   // cell starts of the chunk; cursors of every (wave, cell)
+                    const int cpt = (ncella + kMcThreads - 1) / kMcThreads;
+                    const int k0 = tid * cpt;
+                    uint32_t local = 0;
+                    for (int k = 0; k < cpt; ++k)
+                        if (k0 + k < ncella) for (int w2 = 0; w2 < kMcWaves; ++w2) local += cnt[w2 * ncella + k0 + k];
+                    uint32_t total;
+                    uint32_t run = block_exclusive_scan<kMcWaves>(local, tmp, &total);
+                    for (int k = 0; k < cpt; ++k) {
+                        if (k0 + k < ncella) {
+                            seg[k0 + k] = run;
+                            for (int w2 = 0; w2 < kMcWaves; ++w2) { const uint32_t c = cnt[w2 * ncella + k0 + k]; cnt[w2 * ncella + k0 + k] = run; run += c; }
+                        }
+                    }
+                    if (tid == 0) seg[ncella] = total;
+                }
+                __syncthreads();
+                for (uint32_t j0 = mlo; j0 < mhi; j0 += (uint32_t)(G * kWave)) {
+                    Rec8 q[G];
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        const uint32_t j = j0 + (uint32_t)(sl * kWave + lane);
+                        q[sl] = make_uint2(0u, 0u);
+                        if (j < mhi) q[sl] = s8[src_of(j)];
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < G; ++sl) {
+                        if (j0 + (uint32_t)(sl * kWave) >= mhi) break;   // uniform
+                        const bool have = j0 + (uint32_t)(sl * kWave + lane) < mhi;
+                        const Rec8 r = q[sl];
+                        const uint32_t hits = have ? hits_of(r) : 0u;
+                        const bool h6 = (hits >> 6) & 1u, h1 = (hits >> 1) & 1u;
+                        const bool valid = h6 || h1;
+                        if (!__any(valid)) continue;
+                        const uint32_t px = ((r.y & 511u) - (uint32_t)c0) & 511u;
+                        const uint32_t cell = valid ? 2u * px + (h6 ? 0u : 1u) : 0u;
+                        const uint32_t tt = (uint32_t)((int64_t)(int32_t)r.x - (int64_t)tmin);
+                        const double ts = (double)tt / interval;   // the digest: one division per kept record and lane (mixed_density_event_stack.py:112-114)
+                        uint32_t rk; bool last;
+                        wave_match(cell, nbits, valid, lane, rk, last);
+                        uint32_t pos = 0;
+                        if (valid) { pos = vcnt[cell] + rk; stage[pos] = ts; }
+                        __builtin_amdgcn_wave_barrier();
+                        if (valid && last) vcnt[cell] = pos + 1;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();
+                // fold: a thread per cell, the cell's terms in array order onto the pixel's sums
+                for (int cell = tid; cell < 2 * g.npix; cell += kMcThreads) {
+                    const uint32_t st = seg[cell], en = seg[cell + 1];
+                    if (en > st) {
+                        uint32_t *wd = words + (uint32_t)(cell >> 1) * (uint32_t)NWD;
+                        double *dd = reinterpret_cast<double *>(wd);
+                        if (!(cell & 1)) {
+                            double run = dd[6];
+                            for (uint32_t j = st; j < en; ++j) run = run + stage[j];
+                            dd[6] = run;
+                            wd[10] += en - st;
+                        } else {
+                            double run = dd[7], sq = dd[8];
+                            for (uint32_t j = st; j < en; ++j) { const double v = stage[j]; run = run + v; const double vv = v * v; sq = sq + vv; }
+                            dd[7] = run; dd[8] = sq;
+                            wd[11] += en - st;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // a thread per pixel: the twelve values (k_mdes_stream's emit = mdes_unit's finish), straight to the tensor
+            float *dst = out + (((size_t)b * H + g.row) * (size_t)W + g.c0) * C;
+            const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+            for (int px = tid; px < g.npix; px += kMcThreads) {
+                const uint32_t *wd = words + (uint32_t)px * (uint32_t)NWD;
+                const double *dd = reinterpret_cast<const double *>(wd);
+                const uint32_t fl = wd[6];
+                double r[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) r[c] = 0.0;
+                if (fl >> 31) {
+                    const int np0 = (int)wd[0], nn0 = (int)wd[1], nz0 = (int)wd[2];
+                    const int n0 = np0 + nn0 + nz0;
+                    const double s0 = (double)(np0 - nn0), q0 = (double)(np0 + nn0);
+                    {
+                        const double d = (double)(n0 < 1 ? 1 : n0);
+                        const double mean = n0 > 1 ? s0 / d : s0, mean2 = n0 > 1 ? q0 / d : q0;
+                        const double mm = mean * mean;
+                        r[0] = mean2 - mm;
+                    }
+                    {
+                        const int n1 = (int)wd[11];
+                        const double d = (double)(n1 < 1 ? 1 : n1);
+                        const double mean = n1 > 1 ? dd[7] / d : dd[7], mean2 = n1 > 1 ? dd[8] / d : dd[8];
+                        const double mm = mean * mean;
+                        r[1] = mean2 - mm;
+                    }
+                    r[2] = (fl >> 2) & 1u ? 1.0 : 0.0;
+                    r[3] = (double)((int)wd[4] - (int)wd[5]);
+                    r[4] = (fl >> 4) & 1u ? 1.0 : 0.0;
+                    r[5] = (double)(int)wd[3];
+                    { const int n6 = (int)wd[10]; r[6] = n6 > 1 ? dd[6] / (double)n6 : dd[6]; }
+                    r[7] = (fl >> 7) & 1u ? 1.0 : 0.0;
+                    r[8] = (fl >> 8) & 1u ? (double)wd[7] / interval : 0.0;
+                    r[9] = (fl >> 9) & 1u ? (double)wd[8] / interval : 0.0;
+                    r[10] = (fl >> 10) & 1u ? (double)wd[9] / interval : 0.0;
+                    r[11] = (fl >> 11) & 1u ? 1.0 : 0.0;
+                    if (scale != 1.0) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) r[c] = r[c] * scale;
+                    }
+                }
+                float vals[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) vals[c] = (float)r[c];
+                store_pixel<float, C>(dst + (size_t)px * C, vals, C, vec);
+            }
+        }
+        __syncthreads();
+    }
+}
+#endif
 
 // "SBT" stacking (mixed_density_event_stack.py:76-107): eight windows cut by the normalised time t_s = (t - tmin) / (tmax -
 // tmin) -- w0 all, w1..w3 i/3 <= t_s <= (i+1)/3 (both ends inclusive), w4..w7 t_s <= 1/2, 1/4, 1/8, 1/16.  On ascending

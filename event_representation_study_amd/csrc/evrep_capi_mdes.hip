@@ -73,14 +73,22 @@ int evrep_mdes_ex(const evrep_plan *plan, const int32_t *events, const int64_t *
 #define MDES_LAUNCH(T, DESC)                                                                                          \
     do {                                                                                                              \
         const size_t lds_ = chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, uc.stage, uc.partpx);                       \
+        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it; the float32 one   \
+           hands hot units to its hot launch whole (Split, IN_HOT): a stage of kHotSplitStage records there -- and, r06, units of \
+           >= kErgoCoopMin records to a cooperative launch of sixteen waves per unit (k_mdes_coop; UnitCfg::xflags bit 8) */       \
+        const bool hot_launch = ks_pass(plan) && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                                       \
+        const bool coop = hot_launch && MdesIsErgo12<DESC>::value && sizeof(T) == 4 && !(plan->flags & EVREP_PLAN_X_MDES_NO_COOP);      \
+        if (coop) uc.xflags |= 8;                                                                                                       \
         if (pace_auto) uc.hold = auto_hold(plan, reinterpret_cast<const void *>(&k_mdes<T, DESC>), lds_, span, (size_t)C * sizeof(T), uc.merge); \
         k_mdes<T, DESC><<<SPAN_GRID(span), kWave, lds_, stream>>>(bin_view(plan, events, workspace), offsets, P, plan->H, plan->W,   \
                                                                   plan->nchunk, uc, scale, static_cast<T *>(out));           \
-        /* the float64 ERGO-12 instance defers nothing (its split path, mdes_unit): no hot launch behind it; the float32 one   \
-           hands hot units to its hot launch whole (Split, IN_HOT): a stage of kHotSplitStage records there */                   \
-        const bool hot_launch = ks_pass(plan) && !(MdesIsErgo12<DESC>::value && sizeof(T) == 8);                                       \
         UnitCfg hc = hot_cfg(uc);                                                                                             \
         if (MdesIsErgo12<DESC>::value) hc.stage = hot_sweep_stage((size_t)(span + uc.merge) * kChunkPx * 7 * 4, 4096, (size_t)uc.partpx * C * sizeof(T));                                                             \
+        if (coop) {                                                                                                                     \
+            const size_t cl = mdes_coop_lds_bytes((span + uc.merge) * kChunkPx);                                                        \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mdes_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) { (void)hipGetLastError(); return EVREP_EHIP; } \
+            k_mdes_coop<<<kMcGrid, kMcThreads, cl, stream>>>(bin_view(plan, events, workspace), offsets, plan->H, plan->W, plan->nchunk, uc, scale, reinterpret_cast<float *>(out)); \
+        }                                                                                                                               \
         if (hot_launch) k_mdes<T, DESC, true><<<kHotGrid, kWave, chunk_lds_bytes(C, sizeof(T), (span + uc.merge) * kChunkPx, hc.stage, uc.partpx), stream>>>(  \
             bin_view(plan, events, workspace), offsets, P, plan->H, plan->W, plan->nchunk, hc, scale, static_cast<T *>(out)); \
     } while (0)

@@ -27,6 +27,7 @@ constexpr int kHotParts = 8;                  // parts per unit at most (TORE's 
 constexpr int kHotCodes = 64;                 // item = unit id * kHotCodes + piece code
 constexpr int kHotLists = 64;
 constexpr int kHotWhole = kHotCodes - 1;      // piece code: the WHOLE unit, taken by the hot wave's split sweep (unit_records, Split::in_hot)
+constexpr int kHotCoop = kHotCodes - 2;       // piece code (r06): the WHOLE unit, for the cooperative launch of several waves per unit (k_mdes_coop); the one-wave hot launch skips it
 constexpr int kHotSub0 = 40, kHotSubMax = 16; // piece codes kHotSub0 + s: the s-th TIME slice of a hot unit of >= kHotSubMin records (unit_records, sub-waves)
 #ifdef EVREP_TIMING
 constexpr uint32_t kHotSubMin = 0x7fffffffu, kHotSubRecs = 1024u;   // (the experiment build keeps its phase marks where sliced units order their kept records)

@@ -88,6 +88,7 @@ typedef struct evrep_plan {
 #define EVREP_PLAN_X_TAIL_MERGE 256u    /* experiment: a row's last unit also takes a short tail chunk (NOTES.md r04: slower) */
 #define EVREP_PLAN_X_POLSTATS_ORDERED 65536u /* A/B: the n_imagenet accumulators by k_polstats also where r06 streams them (k_polstats_stream) */
 #define EVREP_PLAN_X_ESTACK_ORDERED 131072u /* A/B: EventStack by k_event_stack also where r06 streams it (k_event_stack_stream) */
+#define EVREP_PLAN_X_MDES_NO_COOP 4194304u /* A/B: the ordered float32 ERGO-12's big hot units by time slices of one-wave workgroups (r05) instead of k_mdes_coop */
 #define EVREP_PLAN_X_TS_STREAM 1048576u   /* tests / A/B: the time surface by k_time_surface_stream at every density */
 #define EVREP_PLAN_X_TS_ORDERED 2097152u  /* A/B: the time surface by k_time_surface also where r06 streams it */
 #define EVREP_PLAN_X_MDES_STREAM 524288u  /* tests / A/B: ERGO-12 by k_mdes_stream at every density (default: where it is measured faster) */
