@@ -110,3 +110,33 @@ def test_stream_builders_on_unsorted_windows(monkeypatch, oracle):
         assert_bit_equal(a, b, "tore bbox stream vs ordered on unsorted windows")
     for b, ev in enumerate(wins):
         assert_bit_equal(got["ergo64"][b], oracle.ergo12(ev, H, W), "ergo12 stream vs oracle, unsorted window %d" % b)
+
+
+def test_ordered_float32_ergo12_monsters_by_sixteen_waves(monkeypatch, oracle):
+    """k_mdes_coop (r06): on a SPARSE window (the ordered float32 builder) a unit of >= 4096 records is one hot item for a workgroup of
+    sixteen waves; EVREP_X_MDES_NO_COOP brings r05's time slices back.  Both against the oracle, bit for bit; the voxel grid's burst
+    units (k_voxel_hot) ride along."""
+    from event_representation_study_amd import engine as eng
+    H, W = 480, 640
+    rng = np.random.default_rng(31)
+    wins = []
+    for s, (n_hot, span) in enumerate(((9000, 200), (5000, 40))):
+        ev = make_events(60000, W, H, seed=90 + s)
+        idx = np.sort(rng.choice(60000, n_hot, replace=False))
+        ev[idx, 1] = 100 + s
+        ev[idx, 0] = rng.integers(130, 130 + span, size=n_hot)
+        wins.append(ev)
+    res = {}
+    for flag in (False, True):
+        if flag:
+            monkeypatch.setenv("EVREP_X_MDES_NO_COOP", "1")
+        else:
+            monkeypatch.delenv("EVREP_X_MDES_NO_COOP", raising=False)
+        eb = eng.EventBatch.from_numpy(wins, H, W)
+        assert eb.plan.reserved == 2
+        res[flag] = (eb.optimized(dtype=torch.float32).cpu().numpy(), eb.voxel(5).cpu().numpy())
+        eb.check_built("ergo12 float32")
+    assert_bit_equal(res[False][0], res[True][0], "ergo12 float32: sixteen waves vs time slices")
+    for b, ev in enumerate(wins):
+        assert_bit_equal(res[False][0][b], oracle.ergo12(ev, H, W).astype(np.float32), "ergo12 float32 monster window %d" % b)
+        assert_bit_equal(res[False][1][b], oracle.voxel(ev, H, W, 5), "voxel burst window %d" % b)
