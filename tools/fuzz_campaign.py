@@ -53,6 +53,11 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 300:
     au = eng.EventBatch.from_numpy(wins, H, W)
     a, c, d = builders(ks), builders(cl), builders(au)
     for k in a:
+        if k == "ts":   # r06: the stream takes one exponential per event, the ordered builder one per slice beyond its stage: an ulp or two
+            for other, what in ((c, "classic"), (d, "auto(%d)" % au.plan.reserved)):
+                assert np.allclose(a[k], other[k], rtol=1e-13, atol=0, equal_nan=True) and np.array_equal(a[k] == 0, other[k] == 0), \
+                    (seed, k, "key-sorted vs " + what, W, H, [len(w) for w in wins])
+            continue
         assert np.array_equal(a[k], c[k], equal_nan=True), (seed, k, "key-sorted vs classic", W, H, [len(w) for w in wins])
         assert np.array_equal(a[k], d[k], equal_nan=True), (seed, k, "key-sorted vs auto(%d)" % au.plan.reserved, W, H)
     for b, ev in enumerate(wins):
