@@ -4070,6 +4070,9 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+#ifdef EVREP_TIMING   // experiment builds (tools/experiments/wave_timeline.py): slot 7 = the wave's start (10 ns ticks, absolute), 5 = its lifetime, 6 = its records
+    const long long vs_t0 = (long long)wall_clock64();
+#endif
     int chunk, nch;
     const ChunkGeom g = unit_geom(H, W, nchunk, uc, chunk, nch, uid);
     const int b = g.b;
@@ -4306,6 +4309,9 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
         wave_phase();
     }
     tile_store(acc, ncell, dst);
+#ifdef EVREP_TIMING
+    if (lane == 0 && bv.dbg) { bv.dbg[(size_t)uid * 8 + 7] = (unsigned long long)vs_t0; bv.dbg[(size_t)uid * 8 + 5] = (unsigned long long)((long long)wall_clock64() - vs_t0); bv.dbg[(size_t)uid * 8 + 6] = nrec; }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------

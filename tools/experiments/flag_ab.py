@@ -30,10 +30,11 @@ for tag in tags:
     fns = {"optimized_f32": lambda eb, o: eb.optimized(dtype=torch.float32, out=o), "optimized_f64": lambda eb, o: eb.optimized(out=o),
            "voxel5_f64": lambda eb, o: eb.voxel(5, out=o), "tore_full_frame_f32": lambda eb, o: eb.tore(6, frame_mode=2, out=o),
            "time_surface_f64": lambda eb, o: eb.time_surface(out=o), "event_stack_f32": lambda eb, o: eb.event_stack(out=o),
-           "nimagenet_acc_all_f32": lambda eb, o: eb.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2], out=o)}
+           "nimagenet_acc_all_f32": lambda eb, o: eb.polstats(tn, [1, 2, 1, 2, 1, 2], [0, 0, 1, 1, 2, 2], out=o),
+           "bin": lambda eb, o: eb.rebin()}   # (the binning pass itself)
     shape = {"optimized_f32": (12, torch.float32), "optimized_f64": (12, torch.float64), "voxel5_f64": (5, torch.float64),
              "tore_full_frame_f32": (12, torch.float32), "time_surface_f64": (12, torch.float64), "event_stack_f32": (12, torch.float32),
-             "nimagenet_acc_all_f32": (6, torch.float32)}[builder]
+             "nimagenet_acc_all_f32": (6, torch.float32), "bin": (1, torch.float32)}[builder]
     out = torch.empty((B, H, W, shape[0]), dtype=shape[1], device="cuda:0")
     for eb in ebs:
         eb.bin()
