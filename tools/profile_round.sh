@@ -32,6 +32,7 @@ timeout 900 python tools/bench_sweep.py gen1@circle gen1@edges c2@circle c2@edge
 EVREP_X_VOXEL_ORDERED=1 EVREP_X_TORE_ORDERED=1 EVREP_X_POLSTATS_ORDERED=1 EVREP_X_ESTACK_ORDERED=1 EVREP_X_MDES_ORDERED=1 EVREP_X_TS_ORDERED=1 timeout 900 python tools/bench_sweep.py gen1 c2-dense gen1@circle gen1@edges c3@circle > $O/sweep_ordered_builders.jsonl 2>> $O/sweep.err
 bash tools/pmc_clustered.sh gen1 gen1@circle gen1@edges c3@circle c2-dense > $O/pmc_clustered.log 2>&1
 bash tools/experiments/wave_lifetimes.sh > $O/wave_lifetimes.txt 2>&1
+for cfg in "304,240,50000,32 uniform" "304,240,50000,32 circle" "304,240,50000,32 edges" "1280,720,200000,8 circle"; do set -- $cfg; EVREP_LIB_PATH=tools/variants/libevrep_timing.so SHAPE=$1 DIST=$2 timeout 100 python tools/experiments/wave_timeline.py 2>&1 | grep -v amdgpu; done > $O/wave_timeline.txt
 timeout 900 python tools/per_sample_latency.py > $O/per_sample.jsonl 2>&1
 timeout 900 python tools/gwd_matrix.py > $O/gwd_matrix.log 2>&1
 timeout 900 python tools/gwd_matrix.py --windows 24 > $O/gwd_matrix24.log 2>&1
