@@ -244,6 +244,22 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
     }
 }
 
+// A stream builder sweeps a unit of more than 64 * RB records RUN BY RUN (a batch = up to 64 consecutive records of one block run: a
+// handful of scalar instructions per batch) when its runs hold this many records on average, else 64 consecutive records of the
+// UNIT per batch (every lane finds its record's run itself: full batches)
+// (measured, r06: `tools/experiments/lib_ab.sh`).  The order-free streams -- a batch is a few LDS atomics -- want the cheap addresses
+// (never run by run: EventStack / TORE / accumulators on circle streams +15-50 %); the builders whose batches run ELECTION rounds for
+// their ordered float64 sums want full batches -- the voxel grid above all (two passes, every record elected): 12 -> 48 records per
+// run takes 1 Mpx edges from 92 to 73 us, 1 Mpx circle 155 -> 132, Gen1 circle / edges 125 / 90 -> 120 / 87.
+#ifndef EVREP_STREAM_BYRUN
+#define EVREP_STREAM_BYRUN 12
+#endif
+#ifndef EVREP_VOXEL_BYRUN
+#define EVREP_VOXEL_BYRUN 48
+#endif
+#ifndef EVREP_MDES_STREAM_BYRUN
+#define EVREP_MDES_STREAM_BYRUN 48
+#endif
 // Linear work-unit id of this workgroup among `total` units (see the XCD note in the file header).
 __device__ inline int chunk_unit(int total) {
     const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
@@ -1814,7 +1830,7 @@ __device__ inline StreamRuns stream_runs(const BinView &bv, int b, int64_t n_win
 }
 template <int RB, typename Pre, typename F>
 __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
-                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f) {
+                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f, uint32_t byrun_min = EVREP_STREAM_BYRUN) {
     static_assert(RB >= 4, "head[] doubles as the 2 x 128-word run table of the LDS search");
     const int lane = threadIdx.x;
     const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, khi);
@@ -1859,7 +1875,7 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         return nrec;
     }
     constexpr int G = 4;
-    const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+    const bool by_run = nrec >= byrun_min * (uint32_t)nb;   // wave-uniform
     const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
     const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
     uint32_t *rt = head;   // [2][128]: the runs' first records of the unit (pre) and their addresses (src)
@@ -2612,7 +2628,7 @@ __global__ __launch_bounds__(kWave, EVREP_MS_WAVES) void k_mdes_stream(BinView b
                     wave_phase();
                 }
             }
-        });
+        }, (uint32_t)EVREP_MDES_STREAM_BYRUN);
     wave_phase();
     // A lane per NON-EMPTY pixel: the twelve values from the pixel's state (mdes_unit's finish, channel by channel).  The non-empty
     // pixels of the unit are listed first (sparse windows: a sixth of the pixels), every round's values wait in registers until all
@@ -4219,7 +4235,7 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
             // a larger unit: swept once per pass, four batches in flight; run by run when the runs are long enough to fill
             // batches, else 64 consecutive records of the unit with the run found per record (unit_records)
             constexpr int G = 4;
-            const bool by_run = nrec >= 12u * (uint32_t)nb;   // wave-uniform
+            const bool by_run = nrec >= (uint32_t)EVREP_VOXEL_BYRUN * (uint32_t)nb;   // wave-uniform
             const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
             const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
             uint32_t *runs2 = head;   // [2][128]
