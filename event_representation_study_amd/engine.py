@@ -264,7 +264,9 @@ class EventBatch:
         bb = self.bbox()
         views = []
         for b in range(self.B):
-            hb, wb = int(bb[b, 3] - bb[b, 1] + 1), int(bb[b, 2] - bb[b, 0] + 1)
+            hb, wb = int(bb[b, 3]) - int(bb[b, 1]) + 1, int(bb[b, 2]) - int(bb[b, 0]) + 1
+            if hb <= 0 or wb <= 0:                      # an empty window has no bounding box: an empty frame
+                hb = wb = 0
             flat = out[b].reshape(-1)
             views.append(flat[: hb * wb * 2 * k].view(hb, wb, 2 * k))
         return views

@@ -33,6 +33,18 @@ def _windows(kind, W, H):
         return [ev, make_events(4000, W, H, seed=9)]
     if kind == "dense":
         return [make_events(40000, W, H, seed=11), make_events(40001, W, H, seed=12, polarity="01")]
+    if kind == "sweeps":
+        # units of more than 256 records, both ways a stream sweeps them.  15 block runs of 4 096 events with ~40 records of a unit
+        # each: 64 consecutive records of the UNIT per batch for the voxel grid / ERGO-12 (every lane finds its record's run by the
+        # readlane chain), run by run for the order-free streams
+        return [make_events(60000, W, H, seed=21), make_events(0, W, H, seed=1)]
+    if kind == "sweeps19":
+        # 19 runs of 8 192 events (the run of a record by an LDS search) with ~41 records of a unit each, and a unit that holds
+        # 3 000 more in bursts (run by run for everyone)
+        b = make_events(150000, W, H, seed=22, polarity="01")
+        idx = np.sort(rng.choice(150000, 3000, replace=False))
+        b[idx, 0], b[idx, 1] = 130 + (idx % 7), H // 2
+        return [b]
     raise ValueError(kind)
 
 
@@ -63,10 +75,10 @@ def _build_all(eng, wins, H, W, monkeypatch, ordered):
     return res
 
 
-@pytest.mark.parametrize("kind", ["uniform", "clustered", "escaped", "dense"])
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "escaped", "dense", "sweeps", "sweeps19"])
 def test_stream_builders_equal_ordered_builders_and_oracle(kind, monkeypatch, oracle):
     from event_representation_study_amd import engine as eng
-    H, W = (60, 200) if kind != "dense" else (48, 160)
+    H, W = {"dense": (48, 160), "sweeps": (48, 160), "sweeps19": (48, 480)}.get(kind, (60, 200))
     wins = _windows(kind, W, H)
     got = _build_all(eng, wins, H, W, monkeypatch, ordered=False)
     ref = _build_all(eng, wins, H, W, monkeypatch, ordered=True)
