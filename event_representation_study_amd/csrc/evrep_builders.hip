@@ -254,6 +254,9 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
 #ifndef EVREP_STREAM_BYRUN
 #define EVREP_STREAM_BYRUN 12
 #endif
+#ifndef EVREP_ORDERED_BYRUN   // (the ordered builders' sweeps of a unit beyond the record stage: unit_records)
+#define EVREP_ORDERED_BYRUN 48
+#endif
 #ifndef EVREP_VOXEL_BYRUN
 #define EVREP_VOXEL_BYRUN 48
 #endif
@@ -831,7 +834,7 @@ __device__ inline UnitRecs unit_records(const BinView &bv, const int64_t *__rest
         jlo = min(nrec, (uint32_t)(part - kHotSub0) * qs);
         jhi = min(nrec, jlo + qs);
     }
-    const bool by_run = !hot_sub && nrec >= 12u * (uint32_t)nb;   // wave-uniform
+    const bool by_run = !hot_sub && nrec >= (uint32_t)EVREP_ORDERED_BYRUN * (uint32_t)nb;   // wave-uniform
     const uint32_t run0 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + a;   // lane k: the unit's first record in run k
     uint32_t *runs2 = cnt + npixu;   // (behind the pixel counters: a main launch places a warm unit over the record stage)
     if (!by_run && nb > kBsChainBlocks) { runs2[lane] = pre; runs2[64 + lane] = src; }
