@@ -226,10 +226,16 @@ static int voxel_launch(const evrep_plan *plan, const int32_t *events, const int
         //  1 Mpx circle 233 / 155; the edge streams, whose largest units hold ~1 000 records at 4-5 per batch and pixel, 80 / 93 and 93 / 91:
         //  a unit of that size is cheaper inside the main launch's tail than in a launch behind it; a threshold of 1 536 loses on the circles --
         //  640x480 155 us: the units of 768-1 536 records then make the main launch's tail AND the hot launch still runs behind it)
-        us.stage = hot ? 768 : 0x7fffffff;
+#ifndef EVREP_VOXEL_HOT_MIN
+#define EVREP_VOXEL_HOT_MIN 768
+#endif
+#ifndef EVREP_VOXEL_RB
+#define EVREP_VOXEL_RB 4
+#endif
+        us.stage = hot ? EVREP_VOXEL_HOT_MIN : 0x7fffffff;
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
-        constexpr int kRB = 4;
+        constexpr int kRB = EVREP_VOXEL_RB;
         k_voxel_stream<kRB><<<SPAN_GRID(1), kWave, voxel_stream_lds_bytes(bins, kChunkPx, kRB), stream>>>(
             reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us,
             bins, mode, scale, t_range, tnorm, out);
