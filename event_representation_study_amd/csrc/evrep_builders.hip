@@ -254,6 +254,9 @@ __device__ inline void tile_store(const OutT *tile, int count, OutT *__restrict_
 #ifndef EVREP_STREAM_BYRUN
 #define EVREP_STREAM_BYRUN 12
 #endif
+#ifndef EVREP_STREAM_G   // batches of a big unit a stream wave keeps in flight
+#define EVREP_STREAM_G 4
+#endif
 #ifndef EVREP_ORDERED_BYRUN   // (the ordered builders' sweeps of a unit beyond the record stage: unit_records)
 #define EVREP_ORDERED_BYRUN 48
 #endif
@@ -1877,7 +1880,7 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
             if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
         return nrec;
     }
-    constexpr int G = 4;
+    constexpr int G = EVREP_STREAM_G;
     const bool by_run = nrec >= byrun_min * (uint32_t)nb;   // wave-uniform
     const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
     const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
@@ -2030,7 +2033,12 @@ __device__ inline bool is_count_func(int f) { return f == EVREP_F_COUNT || f == 
 // A record of escaped polarity (p outside {-1, 0, 1}: sum p^2 may leave the integers float64 holds exactly) sends its unit to the
 // ordered paths.
 constexpr int kErgoSplitWords = 7;
-constexpr uint32_t kErgoCoopMin = 4096u;   // records from which the ordered float32 builder's hot units go to k_mdes_coop
+// (measured, r06, library variants alternated -- tools/experiments/lib_ab.sh; float32 ERGO-12 build in us at 4096 / 2048 / 1536 / 1024:
+//  1 Mpx circle 193 / 168 / 162 / 162, 640x480 circle 137 / 136 / 148 / 147, 1 Mpx edges 108 / 109 / 111 / 118; every other row within 1 %)
+#ifndef EVREP_ERGO_COOP_MIN
+#define EVREP_ERGO_COOP_MIN 2048
+#endif
+constexpr uint32_t kErgoCoopMin = EVREP_ERGO_COOP_MIN;   // records from which the ordered float32 builder's hot units go to k_mdes_coop
 // the ERGO-12 channels of rank window `wnd`, as bits
 constexpr uint32_t ergo_chans_of(int wnd) {
     uint32_t m = 0;
@@ -4237,7 +4245,7 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
         } else {
             // a larger unit: swept once per pass, four batches in flight; run by run when the runs are long enough to fill
             // batches, else 64 consecutive records of the unit with the run found per record (unit_records)
-            constexpr int G = 4;
+            constexpr int G = EVREP_STREAM_G;
             const bool by_run = nrec >= (uint32_t)EVREP_VOXEL_BYRUN * (uint32_t)nb;   // wave-uniform
             const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
             const uint32_t run01 = (uint32_t)beg + ((uint32_t)(kWave + lane) << bv.chunk_shift) + R.a1;
