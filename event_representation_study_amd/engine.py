@@ -7,6 +7,7 @@ representations from the binned stream -- all on the caller's HIP stream, no hos
 The per-sample functions that mirror the reference's Python names
 (``representations/*.py``) are thin wrappers over this class with B = 1.
 """
+import contextlib
 import ctypes
 import weakref
 
@@ -20,6 +21,9 @@ from ._lib import Plan, check
 def _require_gpu():
     if not torch.cuda.is_available():
         raise _lib.EvrepError("no HIP device visible: the builders run on an MI355X only (no CPU fallback)")
+
+
+_NO_GUARD = contextlib.nullcontext()
 
 
 def _stream_ptr():
@@ -65,6 +69,16 @@ class EventBatch:
         nbytes = int(self.lib.evrep_workspace_bytes(ctypes.byref(self.plan)))
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._binned = False
+        # The per-sample wrappers (representations/_common.py) keep one pooled batch per (host thread, device, stream) and only use
+        # it there: they pin the stream pointer and skip the device guard (torch.cuda.current_stream() + torch.cuda.device() cost
+        # ~8 us per call of the ~100 us a sample takes).  None: look both up per call, as every other user must.
+        self._pinned_stream = None
+
+    def _sp(self):
+        return self._pinned_stream if self._pinned_stream is not None else _stream_ptr()
+
+    def _dev(self):
+        return _NO_GUARD if self._pinned_stream is not None else torch.cuda.device(self.device)
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -88,8 +102,8 @@ class EventBatch:
     def bin(self):
         """Run the (y,x) binning pass (idempotent)."""
         if not self._binned:
-            with torch.cuda.device(self.device):
-                check(self.lib.evrep_bin_events(*self._args(), _stream_ptr()), "evrep_bin_events")
+            with self._dev():
+                check(self.lib.evrep_bin_events(*self._args(), self._sp()), "evrep_bin_events")
             self._binned = True
         return self
 
@@ -101,9 +115,9 @@ class EventBatch:
     def status(self):
         self.bin()
         st = np.zeros(self.B, dtype=np.uint32)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_read_status(ctypes.byref(self.plan), _ptr(self.workspace),
-                                             st.ctypes.data_as(ctypes.c_void_p), _stream_ptr()), "evrep_read_status")
+                                             st.ctypes.data_as(ctypes.c_void_p), self._sp()), "evrep_read_status")
         return st
 
     def check_built(self, what="builder"):
@@ -120,9 +134,9 @@ class EventBatch:
     def bbox(self):
         self.bin()
         bb = np.zeros((self.B, 4), dtype=np.int32)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_read_bbox(ctypes.byref(self.plan), _ptr(self.workspace),
-                                           bb.ctypes.data_as(ctypes.c_void_p), _stream_ptr()), "evrep_read_bbox")
+                                           bb.ctypes.data_as(ctypes.c_void_p), self._sp()), "evrep_read_bbox")
         return bb
 
     # ------------------------------------------------------------------ builders
@@ -147,9 +161,9 @@ class EventBatch:
         call: a pooled batch is refilled with other events between calls."""
         bounds = torch.empty((self.B, 8, 2), dtype=torch.int32, device=self.device)
         flags = torch.empty((self.B, 2), dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_mdes_sbt_windows(_ptr(self.events), _ptr(self.offsets), self.B, self.H, self.W,
-                                                  _ptr(bounds), _ptr(flags), _stream_ptr()), "evrep_mdes_sbt_windows")
+                                                  _ptr(bounds), _ptr(flags), self._sp()), "evrep_mdes_sbt_windows")
         return bounds, flags
 
     def mdes(self, windows, funcs, aggs, scale=1.0, dtype=torch.float64, out=None, stacking="SBN"):
@@ -167,11 +181,11 @@ class EventBatch:
             out = self._out(out, C, dtype)
             null = ctypes.c_void_p(None)
             bounds, flags = self.sbt_windows() if stacking == "SBT" else (None, None)
-            with torch.cuda.device(self.device):
+            with self._dev():
                 check(self.lib.evrep_mdes_ex(*self._args(), C, _lib.int32_array(w), _lib.int32_array(f),
                                              _lib.int32_array(a), float(scale), self._dt(dtype), _ptr(out),
                                              _ptr(bounds) if bounds is not None else null,
-                                             _ptr(flags) if flags is not None else null, _stream_ptr()), "evrep_mdes_ex")
+                                             _ptr(flags) if flags is not None else null, self._sp()), "evrep_mdes_ex")
             return out
         parts = [self.mdes(w[i:i + 16], f[i:i + 16], a[i:i + 16], scale, dtype, stacking=stacking) for i in range(0, C, 16)]
         res = torch.cat(parts, dim=3)
@@ -184,8 +198,8 @@ class EventBatch:
         """get_optimized_representation (ERGO-12) for every window -> (B, H, W, 12)."""
         self.bin()
         out = self._out(out, 12, dtype)
-        with torch.cuda.device(self.device):
-            check(self.lib.evrep_optimized(*self._args(), float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
+        with self._dev():
+            check(self.lib.evrep_optimized(*self._args(), float(scale), self._dt(dtype), _ptr(out), self._sp()),
                   "evrep_optimized")
         return out
 
@@ -195,9 +209,9 @@ class EventBatch:
         already holds the final int8 polarity value (EventStack.pre_stack forms it on the host)."""
         self.bin()
         out = self._out(out, stack_size, torch.float32)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_event_stack(*self._args(), int(stack_size), int(premap), float(scale),
-                                             _ptr(out), _stream_ptr()), "evrep_event_stack")
+                                             _ptr(out), self._sp()), "evrep_event_stack")
         return out
 
     def _i32_dev(self, values, per_window):
@@ -228,9 +242,9 @@ class EventBatch:
             if indices is None:
                 raise ValueError("times_f64 needs explicit indices")
             fptr = _ptr(times_f64)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_time_surface_ftime(*self._args(), int(slices), iptr, fptr, float(tau), int(premap),
-                                              float(scale), self._dt(dtype), _ptr(out), _stream_ptr()),
+                                              float(scale), self._dt(dtype), _ptr(out), self._sp()),
                   "evrep_time_surface")
         return out
 
@@ -256,9 +270,9 @@ class EventBatch:
                 if keep_f.numel() != self.B:
                     raise ValueError("sample_times_f64 must hold one time per window")
                 sfptr = _ptr(keep_f)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_tore_ftime(*self._args(), int(k), int(frame_mode), tptr, fptr, sfptr, float(scale), _ptr(out),
-                                            _stream_ptr()), "evrep_tore_ftime")
+                                            self._sp()), "evrep_tore_ftime")
         if frame_mode != 0:
             return out
         bb = self.bbox()
@@ -283,9 +297,9 @@ class EventBatch:
                 raise ValueError("t_range must hold (t0, t1) for each of the %d windows" % self.B)
             tr = tr.to(self.device)
             rptr = _ptr(tr)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_voxel_range(*self._args(), int(bins), int(mode), float(scale), rptr, _ptr(out),
-                                             _stream_ptr()), "evrep_voxel_range")
+                                             self._sp()), "evrep_voxel_range")
         return out
 
     def voxel_tnorm(self, tnorm, bins=5, scale=1.0, out=None):
@@ -295,8 +309,8 @@ class EventBatch:
         if tnorm.dtype != torch.float64 or tnorm.device != self.device or tnorm.numel() != self.total or not tnorm.is_contiguous():
             raise ValueError("tnorm must be a contiguous float64 tensor with one entry per event on %s" % self.device)
         out = self._out(out, bins, torch.float64)
-        with torch.cuda.device(self.device):
-            check(self.lib.evrep_voxel_tnorm(*self._args(), _ptr(tnorm), int(bins), float(scale), _ptr(out), _stream_ptr()),
+        with self._dev():
+            check(self.lib.evrep_voxel_tnorm(*self._args(), _ptr(tnorm), int(bins), float(scale), _ptr(out), self._sp()),
                   "evrep_voxel_tnorm")
         return out
 
@@ -313,8 +327,8 @@ class EventBatch:
             if keep.numel() != 2 * self.B:
                 raise ValueError("t_range must hold (t0, t1) for each of the %d windows" % self.B)
             rptr = _ptr(keep)
-        with torch.cuda.device(self.device):
-            check(self.lib.evrep_voxel_subpixel(*self._args(), _ptr(xy), int(bins), rptr, _ptr(out), _stream_ptr()),
+        with self._dev():
+            check(self.lib.evrep_voxel_subpixel(*self._args(), _ptr(xy), int(bins), rptr, _ptr(out), self._sp()),
                   "evrep_voxel_subpixel")
         return out
 
@@ -330,9 +344,9 @@ class EventBatch:
                 or not tnorm.is_contiguous():
             raise ValueError("tnorm must be a contiguous float64 tensor with one entry per event on %s" % self.device)
         out = self._out(out, len(pol), torch.float32)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_polstats(*self._args(), _ptr(tnorm), len(pol), pol.ctypes.data_as(ctypes.c_void_p),
-                                          stat.ctypes.data_as(ctypes.c_void_p), float(tau), _ptr(out), _stream_ptr()),
+                                          stat.ctypes.data_as(ctypes.c_void_p), float(tau), _ptr(out), self._sp()),
                   "evrep_polstats")
         return out
 
@@ -346,10 +360,10 @@ class EventBatch:
         if segments.dtype != torch.float64 or segments.dim() != 2 or segments.shape[1] != 3 or buckets.dtype != torch.int32:
             raise ValueError("segments must be float64 (nseg, 3), buckets int32")
         out = self._out(out, 2 * int(C), torch.float32)
-        with torch.cuda.device(self.device):
+        with self._dev():
             check(self.lib.evrep_est_voxel(*self._args(), _ptr(tnorm), int(C), _ptr(segments), int(segments.shape[0]),
                                            _ptr(buckets), int(buckets.numel()), float(lo), float(hi), _ptr(out),
-                                           _stream_ptr()), "evrep_est_voxel")
+                                           self._sp()), "evrep_est_voxel")
         return out
 
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..engine import EventBatch, _ptr, _require_gpu, _stream_ptr
+from ..engine import EventBatch, _ptr, _require_gpu
 from ..synthetic import from_structured, narrow_to_int32
 
 RESULT_POOL_DEPTH = int(os.environ.get("EVREP_RESULT_POOL", os.environ.get("EVREP_RESULT_RING", "8")))
@@ -64,7 +64,18 @@ class _SampleContext:
         self.batch = EventBatch(self.ev_dev, torch.tensor([0, self.cap], dtype=torch.int64), height, width,
                                 max_events_per_window=self.cap, plan_flags=plan_flags, pacing=pacing)
         self.batch.offsets = self.buf_dev[0].view(torch.int64)          # the device offsets live in front of the events
+        # host-side views made once (a torch index / slice / clone costs 2-5 us each; a sample has ~100 us in all)
+        self.ev_np = self.ev_pinned.numpy()
+        self.off_np = self.off_pinned.numpy()
+        self.off_host = torch.zeros(2, dtype=torch.int64)               # the batch's offsets_host, rewritten per sample
+        self.off_host_np = self.off_host.numpy()
+        self.batch.offsets_host = self.off_host
+        # this context is only ever used on the stream it was made for (the stream is part of its key), with that stream's
+        # device current: the pooled batch skips the per-call stream look-up and device guard
+        self.stream = torch.cuda.current_stream(device)
+        self.batch._pinned_stream = ctypes.c_void_p(self.stream.cuda_stream)
         self.meta_pinned = torch.zeros(16, dtype=torch.int32, pin_memory=True)      # one 64-byte WindowMeta
+        self.meta_np = self.meta_pinned.numpy()
         self.outs = {}          # (C, dtype) -> (1, H, W, C) device tensor
         self.pools = {}         # (shape, dtype) -> [_ResultSlot]
         self.staging = {}       # (shape, dtype) -> pinned tensor never handed out (results beyond the pool's depth)
@@ -94,15 +105,15 @@ class _SampleContext:
 
 
 def _context(height, width, n):
-    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream()
+    dev = stream.device
     cap = 4096
     while cap < n:
         cap *= 2
     flags, pacing = _lib.plan_flags_from_env(), _lib.pacing_from_env()
     # per process (a HIP context does not survive fork()), per host thread and per stream: two threads or two streams never
     # share a staging buffer, an output tensor or a workspace
-    key = (os.getpid(), threading.get_ident(), str(dev), int(torch.cuda.current_stream(dev).cuda_stream), int(height),
-           int(width), cap, flags, pacing)
+    key = (os.getpid(), threading.get_ident(), dev.index, int(stream.cuda_stream), int(height), int(width), cap, flags, pacing)
     with _CONTEXTS_LOCK:
         ctx = _CONTEXTS.pop(key, None)
         if ctx is not None:
@@ -175,9 +186,9 @@ class SampleBatch:
         b = self.batch
         b.bin()
         null = ctypes.c_void_p(None)
-        with torch.cuda.device(b.device):
+        with b._dev():
             _lib.check(b.lib.evrep_tore_ftime(*b._args(), int(k), int(frame_mode), null, null, null, float(scale), _ptr(out),
-                                              _stream_ptr()), "evrep_tore_ftime")
+                                              b._sp()), "evrep_tore_ftime")
         return out
 
 
@@ -193,12 +204,11 @@ def sample_batch(event_sequence, height, width, truncate=False, rebase_t=False, 
     n = int(ev.shape[0])
     ctx = _context(height, width, n)
     b = ctx.batch
-    stream = torch.cuda.current_stream(b.device)
-    stream.synchronize()          # the previous call's H2D has left the staging buffer (its own finish() synchronised: free)
-    ctx.ev_pinned[:n].numpy()[...] = ev
-    ctx.off_pinned[1] = n
+    ctx.stream.synchronize()      # the previous call's H2D has left the staging buffer (its own finish() synchronised: free)
+    ctx.ev_np[:n] = ev
+    ctx.off_np[1] = n
+    ctx.off_host_np[1] = n
     ctx.buf_dev[:n + 1].copy_(ctx.buf_pinned[:n + 1], non_blocking=True)     # offsets + events: one H2D
-    b.offsets_host = ctx.off_pinned.clone()
     b._binned = False
     return SampleBatch(ctx, n, device_out)
 
@@ -209,17 +219,17 @@ def finish(sb, dev_out, allow_oob=False, what="builder", out=None, tore_k=None, 
     ``device_out`` sample, the CUDA tensor itself; raises what the reference raises."""
     ctx, b = sb.ctx, sb.batch
     b.bin()
-    with torch.cuda.device(b.device):
+    with b._dev():
         _lib.check(b.lib.evrep_copy_window_meta_async(ctypes.byref(b.plan), _ptr(b.workspace), _ptr(ctx.meta_pinned),
-                                                      _stream_ptr()), "evrep_copy_window_meta_async")
+                                                      b._sp()), "evrep_copy_window_meta_async")
     shape = tuple(dev_out.shape[1:])
     slot = host = None
     if not sb.device_out:
         slot = ctx.result_slot(shape, dev_out.dtype) if out is None else None
         host = slot.tensor if slot is not None else ctx.staging_buffer(shape, dev_out.dtype)
         host.copy_(dev_out[0], non_blocking=True)
-    torch.cuda.current_stream(b.device).synchronize()
-    meta = ctx.meta_pinned.numpy()
+    ctx.stream.synchronize()
+    meta = ctx.meta_np
     _raise_for_status_word(int(meta[8]) & 0xffffffff, b, allow_oob, what, allow_unsorted)
     if sb.device_out:
         res = dev_out[0]

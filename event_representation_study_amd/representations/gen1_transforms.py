@@ -46,8 +46,9 @@ def _event_stack(events, transform, height, width, num_events, device_out=False)
     t = np.asarray(events["t"])
     past = (t.astype(np.int64) <= t[-1] if t.dtype.kind == "f" else t <= t[-1]) if len(t) else None   # pre_stack compares t.astype(int64) (event_stack.py:36-38)
     sb = sample_batch(events if past is None or past.all() else events[past], height, width, device_out=device_out)
-    events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34)
-    return finish(sb, sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE)), what="EventStack", allow_unsorted=True)
+    dev = sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE))
+    events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34) -- while the GPU works (the events were staged above)
+    return finish(sb, dev, what="EventStack", allow_unsorted=True)
 
 
 def _histogram(events, transform, height, width, num_events, device_out=False):
@@ -72,10 +73,11 @@ def _tore(events, transform, height, width, num_events, device_out=False):
 def _time_surface(events, transform, height, width, num_events, device_out=False):
     sb = sample_batch(events, height, width, device_out=device_out)
     t = np.asarray(events["t"])       # (read before the side effect below; the events themselves are on their way already)
-    events["p"] = ((events["p"] + 1) / 2).astype(np.int8)     # (:70-72)
     # the six cuts searchsorted(t_norm, 1..6) are taken on the device from the same float64 formula
+    dev = sb.time_surface(TS_SLICES, float(TS_TAU), premap=1, scale=float(SCALE))
+    events["p"] = ((events["p"] + 1) / 2).astype(np.int8)     # (:70-72) -- while the GPU works
     try:
-        return finish(sb, sb.time_surface(TS_SLICES, float(TS_TAU), premap=1, scale=float(SCALE)), what="ToTimesurface")
+        return finish(sb, dev, what="ToTimesurface")
     except UnsortedWindow:
         # timestamps not ascending (r04): the reference's scan runs in array order whatever they are (time_surface.py:66-74),
         # and so do the kernels; the cuts are what the DISPATCHER's own numpy call yields on such an array (:79-81) -- taken

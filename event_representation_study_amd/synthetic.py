@@ -89,14 +89,10 @@ def from_structured(rec, truncate=False, rebase_t=False):
     n = rec.shape[0]
     if rec.dtype == EVENT_DTYPE and rec.ndim == 1 and rec.flags.c_contiguous:
         # the adapters' own layout (four packed '<i4' fields, gen1_2yolo.py:567-571): a view, no per-field conversion
-        ev = rec.view(np.int32).reshape(n, 4)
-        if rebase_t and n:
-            t0 = int(ev[:, 2].min())
-            if t0 != 0:
-                t = ev[:, 2].astype(np.int64) - t0
-                ev = ev.copy()
-                ev[:, 2] = int64_to_int32(t, "t")
-        return ev
+        # (rebase_t: nothing to do -- the timestamps ARE int32, and the one builder that asks for it, MixedDensityEventStack, only
+        #  reads (t - t.min()) / (t.max() - t.min()), which its kernels form from 64-bit differences themselves; the strided min
+        #  over the window was 9 us of a 100 us sample)
+        return rec.view(np.int32).reshape(n, 4)
     ev = np.empty((n, 4), dtype=np.int32)
     for k, name in enumerate(("x", "y", "t", "p")):
         v = field_to_int64(rec[name], name, truncate)
