@@ -44,8 +44,10 @@ def _event_stack(events, transform, height, width, num_events, device_out=False)
     # event_stack.py:125).  On ascending timestamps the past half is the whole window; otherwise it is the events with
     # t <= t[-1], in array order (r04: unsorted windows are built in array order, as the reference does)
     t = np.asarray(events["t"])
+    sb = sample_batch(events, height, width, device_out=device_out)    # the whole window is on its way while the host looks for a future half
     past = (t.astype(np.int64) <= t[-1] if t.dtype.kind == "f" else t <= t[-1]) if len(t) else None   # pre_stack compares t.astype(int64) (event_stack.py:36-38)
-    sb = sample_batch(events if past is None or past.all() else events[past], height, width, device_out=device_out)
+    if past is not None and not past.all():
+        sb = sample_batch(events[past], height, width, device_out=device_out)   # (unsorted timestamps only: staged again without it)
     dev = sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE))
     events["p"] = (events["p"] + 1) // 2                      # side effect the reference has (:34) -- while the GPU works (the events were staged above)
     return finish(sb, dev, what="EventStack", allow_unsorted=True)

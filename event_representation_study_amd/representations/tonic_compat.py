@@ -42,7 +42,8 @@ class ToImage:
         # counts of p == 0 ("count_neg" falls back to p == 0 when no -1 is present) and of p == 1
         import torch
         rep = sb.mdes([0, 0], ["count_neg", "count_pos"], ["sum", "sum"], dtype=torch.float32)
-        frames = rep[0].permute(2, 0, 1).to(torch.int16).contiguous()[None]     # counts are exact in float32
+        frames = torch.empty((1, 2, H, W), dtype=torch.int16, device=rep.device)
+        frames[0].copy_(rep[0].permute(2, 0, 1))                                # one kernel: transpose + cast (counts are exact in float32)
         return finish(sb, frames, what="ToImage")
 
     def __call__(self, events):
