@@ -45,7 +45,9 @@ def _event_stack(events, transform, height, width, num_events, device_out=False)
     # t <= t[-1], in array order (r04: unsorted windows are built in array order, as the reference does)
     t = np.asarray(events["t"])
     sb = sample_batch(events, height, width, device_out=device_out)    # the whole window is on its way while the host looks for a future half
-    past = (t.astype(np.int64) <= t[-1] if t.dtype.kind == "f" else t <= t[-1]) if len(t) else None   # pre_stack compares t.astype(int64) (event_stack.py:36-38)
+    past = None
+    if len(t) and (t.dtype.kind == "f" or t.max() > t[-1]):      # (integer timestamps: one reduction says whether a future half exists at all)
+        past = t.astype(np.int64) <= t[-1] if t.dtype.kind == "f" else t <= t[-1]   # pre_stack compares t.astype(int64) (event_stack.py:36-38)
     if past is not None and not past.all():
         sb = sample_batch(events[past], height, width, device_out=device_out)   # (unsorted timestamps only: staged again without it)
     dev = sb.event_stack(STACK_LEVELS, premap=True, scale=float(SCALE))
