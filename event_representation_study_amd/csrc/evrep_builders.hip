@@ -310,6 +310,7 @@ struct BinView {
     BlockStats *stats_rw;       // key-sorted: a main wave that cannot defer a unit (every sublist full) reports it in the window's status
 #ifdef EVREP_TIMING
     unsigned long long *dbg;
+    unsigned long long *dbg_wave;   // a stream kernel points it at its wave's slots 0-3: stream_unit_records leaves a big unit's sweep times there
 #endif
 };
 
@@ -1914,7 +1915,13 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
     int rk_ = 0;
     uint32_t ro_ = 0;
     bool more = true;
+#ifdef EVREP_TIMING   // (experiment builds: where a big unit's sweep spends its time -- issue / wait for the records / process)
+    long long ta_ = 0, acc_i = 0, acc_w = 0, acc_p = 0, nbat = 0;
+#endif
     while (more) {
+#ifdef EVREP_TIMING
+        ta_ = (long long)wall_clock64();
+#endif
         Rec8 q[G];
         uint32_t bcnt[G];
 #pragma unroll
@@ -1947,6 +1954,11 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         } else {
             more = ro_ < nrec;
         }
+#ifdef EVREP_TIMING
+        const long long tb_ = (long long)wall_clock64();
+        __builtin_amdgcn_s_waitcnt(0);
+        const long long tc_ = (long long)wall_clock64();
+#endif
         uint2 aux[G];
 #pragma unroll
         for (int sl = 0; sl < G; ++sl) {
@@ -1957,8 +1969,17 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         for (int sl = 0; sl < G; ++sl) {
             if (bcnt[sl] == 0u) break;   // uniform
             f((uint32_t)lane < bcnt[sl], q[sl], aux[sl]);
+#ifdef EVREP_TIMING
+            ++nbat;
+#endif
         }
+#ifdef EVREP_TIMING
+        { const long long td_ = (long long)wall_clock64(); acc_i += tb_ - ta_; acc_w += tc_ - tb_; acc_p += td_ - tc_; }
+#endif
     }
+#ifdef EVREP_TIMING
+    if (bv.dbg_wave && lane == 0) { bv.dbg_wave[0] = (unsigned long long)acc_i; bv.dbg_wave[1] = (unsigned long long)acc_w; bv.dbg_wave[2] = (unsigned long long)acc_p; bv.dbg_wave[3] = (unsigned long long)nbat; }
+#endif
     return nrec;
 }
 
@@ -3858,6 +3879,11 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
     const int lane = threadIdx.x;
     const int C = 2 * K;
     const int uid = chunk_unit((int)(gridDim.x * gridDim.y * gridDim.z));
+#ifdef EVREP_TIMING   // (tools/experiments/wave_timeline.py BUILDER=tore: slot 7 = the wave's start, 5 = its lifetime, 6 = its records,
+    const long long ts_t0 = (long long)wall_clock64();   //  0-3 = a big unit's sweep: issue / wait / process ticks, batches)
+    uint32_t ts_nrec = 0u;
+    bv.dbg_wave = bv.dbg ? bv.dbg + (size_t)uid * 8 : nullptr;
+#endif
     const int nunit = uc.nunit;
     const uint32_t urow = fastdiv((uint32_t)uid, uc.nunit_m, uc.nunit_sh);
     const int b = (int)fastdiv(urow, uc.h_m, uc.h_sh), orow = (int)urow - b * H, oc0 = (uid - (int)urow * nunit) * uc.span * kChunkPx;
@@ -3947,11 +3973,18 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
         }
     };
     wave_phase();
-    if (has)
+    if (has) {
+#ifdef EVREP_TIMING
+        ts_nrec =
+#endif
         stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, klo, khi, head, srcs, StreamNoPre(),
                                 [&](bool have, const Rec8 &q, const uint2 &) { push(have, q); });
+    }
     wave_phase();
     tile_store(reinterpret_cast<const float *>(tile), npix * C, dst);
+#ifdef EVREP_TIMING
+    if (lane == 0 && bv.dbg) { bv.dbg[(size_t)uid * 8 + 7] = (unsigned long long)ts_t0; bv.dbg[(size_t)uid * 8 + 5] = (unsigned long long)((long long)wall_clock64() - ts_t0); bv.dbg[(size_t)uid * 8 + 6] = ts_nrec; }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------

@@ -37,6 +37,7 @@ static inline BinView bin_view(const evrep_plan *plan, const int32_t *events, vo
     // the spill stream of the warm / hot units), in sorted1 under the classic passes
     bv.dbg = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + plan->off_sorted1 +
                                                     (bv.fused ? up256((size_t)plan->total_events * 8) : 0));
+    bv.dbg_wave = nullptr;
 #endif
     return bv;
 }
