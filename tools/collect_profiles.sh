@@ -10,7 +10,7 @@ grep "^{" $O/kt.log > $P/bench_under_rocprof.json
 cp $O/fetch/pmc_fetch_counter_collection.csv $O/write/pmc_write_counter_collection.csv $O/sq/pmc_sq_counter_collection.csv $P/
 cp $O/b_sq/pmc_builders_sq_counter_collection.csv $O/b_fetch/pmc_builders_fetch_counter_collection.csv $O/b_write/pmc_builders_write_counter_collection.csv $P/
 cp $O/gwd_sq/pmc_gwd_counter_collection.csv $O/gw_sq/pmc_gw_counter_collection.csv $O/gw_kt/gw_kernel_stats.csv $O/gwd_kt/gwd_kernel_stats.csv $P/
-cp $O/sweep.jsonl $P/sweep.jsonl; cp $O/sweep_clustered.jsonl $P/sweep_clustered.jsonl; grep -v amdgpu.ids $O/wave_lifetimes.txt > $P/wave_lifetimes.txt; cp $O/wave_timeline.txt $P/wave_timeline.txt; grep "^{" $O/per_sample.jsonl > $P/per_sample_latency.jsonl
+cp $O/sweep.jsonl $P/sweep.jsonl; cp $O/sweep_clustered.jsonl $P/sweep_clustered.jsonl; grep -v amdgpu.ids $O/wave_lifetimes.txt > $P/wave_lifetimes.txt; cp $O/wave_timeline.txt $P/wave_timeline.txt; [ -f $O/wave_timeline_tore.txt ] && cat $O/wave_timeline_tore.txt >> $P/wave_timeline.txt; grep "^{" $O/per_sample.jsonl > $P/per_sample_latency.jsonl
 grep "^{" $O/gwd_matrix.log | tail -1 > $P/gwd_matrix.json || true
 grep "^{" $O/gwd_matrix24.log | tail -1 > $P/gwd_matrix_24windows.json || true
 cp $O/est_bench.json $O/gw_bench_f64.json $O/gw_bench_f32.json $O/precompute.json $P/
