@@ -1837,7 +1837,11 @@ __device__ inline StreamRuns stream_runs(const BinView &bv, int b, int64_t n_win
 }
 template <int RB, typename Pre, typename F>
 __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t beg, int64_t n_win, int NK, int klo, int khi,
-                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f, uint32_t byrun_min = EVREP_STREAM_BYRUN) {
+                                               uint32_t *head, uint32_t *srcs, Pre pre_f, F f, uint32_t byrun_min = EVREP_STREAM_BYRUN,
+                                               bool reverse = false, int *is_big = nullptr) {
+    // reverse (wave-uniform; order-free builders only): the batches from the unit's LAST records to its first -- a pixel's records are
+    // time-ordered inside a run and the runs are time slices, so every pixel's records then arrive latest first.  is_big: set
+    // before the first batch of a unit of more than 64 * RB records (the caller's batch function may treat those differently)
     static_assert(RB >= 4, "head[] doubles as the 2 x 128-word run table of the LDS search");
     const int lane = threadIdx.x;
     const StreamRuns R = stream_runs(bv, b, n_win, NK, klo, khi);
@@ -1876,11 +1880,18 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
             aux[i] = make_uint2(0u, 0u);
             if ((uint32_t)(64 * i + lane) < nrec) aux[i] = pre_f(q[i]);
         }
+        if (reverse) {
+#pragma unroll
+            for (int i = RB - 1; i >= 0; --i)
+                if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
+            return nrec;
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             if ((uint32_t)(64 * i) < nrec) f((uint32_t)(64 * i + lane) < nrec, q[i], aux[i]);
         return nrec;
     }
+
     constexpr int G = EVREP_STREAM_G;
     const bool by_run = nrec >= byrun_min * (uint32_t)nb;   // wave-uniform
     const uint32_t run00 = (uint32_t)beg + ((uint32_t)lane << bv.chunk_shift) + R.a0;
@@ -1890,6 +1901,7 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         rt[lane] = R.pre0; rt[128 + lane] = src0;
         if (wide) { rt[kWave + lane] = R.pre1; rt[128 + kWave + lane] = src1; }
     }
+    if (is_big) *is_big = (!by_run && nb > kBsChainBlocks) ? 2 : 1;   // 1: `head` is free during the sweep (the caller may use it), 2: it holds the run table
     wave_phase();
     auto src_of = [&](uint32_t j) -> uint32_t {
         if (nb <= kBsChainBlocks) {
@@ -1915,6 +1927,16 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
     int rk_ = 0;
     uint32_t ro_ = 0;
     bool more = true;
+    uint32_t run_len = 0u, run_base = 0u;   // of run rk_ (in visiting order)
+    auto load_run = [&]() {
+        run_len = 0u;
+        if (rk_ < nb) {
+            const int r = reverse ? nb - 1 - rk_ : rk_;
+            run_len = R.pick(R.len0, R.len1, r);
+            run_base = R.pick(run00, run01, r);
+        }
+    };
+    if (by_run) load_run();
 #ifdef EVREP_TIMING   // (experiment builds: where a big unit's sweep spends its time -- issue / wait for the records / process)
     long long ta_ = 0, acc_i = 0, acc_w = 0, acc_p = 0, nbat = 0;
 #endif
@@ -1928,18 +1950,18 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
         for (int sl = 0; sl < G; ++sl) {
             bcnt[sl] = 0u;
             uint32_t addr = 0u;
+            // (reverse: the cursor counts the runs from the last one and the records from a run's / the unit's END)
             if (by_run) {
-                uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
-                while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
+                while (rk_ < nb && ro_ >= run_len) { ++rk_; ro_ = 0; load_run(); }   // (the current run's length and base are kept in scalars)
                 if (rk_ < nb) {
-                    addr = R.pick(run00, run01, rk_) + ro_ + (uint32_t)lane;
-                    bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                    bcnt[sl] = min(run_len - ro_, (uint32_t)kWave);
+                    addr = run_base + (reverse ? run_len - ro_ - bcnt[sl] : ro_) + (uint32_t)lane;
                     ro_ += kWave;
                 }
             } else {
-                const uint32_t j0 = ro_;
-                if (j0 < nrec) {
-                    bcnt[sl] = min(nrec - j0, (uint32_t)kWave);
+                if (ro_ < nrec) {
+                    bcnt[sl] = min(nrec - ro_, (uint32_t)kWave);
+                    const uint32_t j0 = reverse ? nrec - ro_ - bcnt[sl] : ro_;
                     if ((uint32_t)lane < bcnt[sl]) addr = src_of(j0 + (uint32_t)lane);
                     ro_ += kWave;
                 }
@@ -1948,8 +1970,7 @@ __device__ inline uint32_t stream_unit_records(const BinView &bv, int b, int64_t
             if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
         }
         if (by_run) {
-            uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
-            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
+            while (rk_ < nb && ro_ >= run_len) { ++rk_; ro_ = 0; load_run(); }
             more = rk_ < nb;
         } else {
             more = ro_ < nrec;
@@ -3864,7 +3885,7 @@ __global__ __launch_bounds__(kWave, 6) void k_event_stack_stream(BinView bv, con
 // sensor keys its output columns cover, a record's output pixel is its column minus the frame's offset.
 // Windows whose timestamps are not ascending keep the reference's array-order semantics (np.partition on the k-vector, see
 // k_tore's reduce): there one record per (pixel, polarity) and round inserts into its FIFO -- an election as in k_voxel_stream.
-// LDS: tile [npixa * 2 K] u32 | tag [2 * npixa] | head [64 * RB] | srcs [64] / run table [128]
+// LDS: tile [npixa * 2 K] u32 | tag [2 * npixa] | head [64 * RB] (a big unit's queue: 128 x 8 bytes, RB >= 4) | srcs [64] / run table [128]
 __host__ __device__ inline size_t tore_stream_lds_bytes(int K, int npixa, int rb) {
     return align16((size_t)npixa * 2 * K * 4) + (size_t)2 * npixa * 4 + (size_t)(64 * rb) * 4 + 128 * 4;
 }
@@ -3908,6 +3929,8 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
     uint32_t *tag = reinterpret_cast<uint32_t *>(smem + align16((size_t)npixa * C * 4));
     uint32_t *head = tag + 2 * npixa;
     uint32_t *srcs = head + 64 * RB;
+    static_assert(RB >= 4, "a big unit's queue (128 x 8 bytes) takes the place of head");
+    uint2 *queue = reinterpret_cast<uint2 *>(head);   // [128]: the records of a big unit that still have a FIFO to enter (below); `head` is idle then
     const double log_min = log(151.0);
     const float bgv = fmaxf((float)((double)logf(500e6f + 1.0f) - log_min), 0.0f) * scale;
     const uint32_t bgb = __float_as_uint(bgv);
@@ -3916,7 +3939,8 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
         uint4 *t4 = reinterpret_cast<uint4 *>(tile);
         const int nvec = (npix * C + 3) / 4;
         for (int v = lane; v < nvec; v += kWave) t4[v] = make_uint4(bgb, bgb, bgb, bgb);
-        if (unsorted) { uint4 *g4 = reinterpret_cast<uint4 *>(tag); for (int v = lane; v * 4 < 2 * npixa; v += kWave) g4[v] = make_uint4(~0u, ~0u, ~0u, ~0u); }
+        // tag: the election words of an unsorted window (all ones) / the FIFOs' record COUNTERS of a big unit of a sorted one (zero)
+        { const uint32_t tv = unsorted ? ~0u : 0u; uint4 *g4 = reinterpret_cast<uint4 *>(tag); for (int v = lane; v * 4 < 2 * npixa; v += kWave) g4[v] = make_uint4(tv, tv, tv, tv); }
     }
     float *dst = out + (size_t)b * H * W * C + ((size_t)orow * Wf + oc0) * C;
     int c0 = 0, klo = 0, khi = 0;
@@ -3929,13 +3953,17 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
     const int4 *evw = ev + beg;
     const int pxoff = sc_lo - c0;   // output pixel = (column inside the gathered chunks) - pxoff
     // one batch: a record's finished value down its FIFO
-    auto push = [&](bool have, const Rec8 &q) {
-        const int32_t t = (int32_t)q.x;
-        const int px = (int)(((q.y & 511u) - (uint32_t)c0) & 511u) - pxoff;
+    // (digest: the record's time, output pixel and polarity; insert: the value and the FIFO)
+    auto digest = [&](bool have, const Rec8 &q, int32_t &t, int &px, int &p) -> bool {
+        t = (int32_t)q.x;
+        px = (int)(((q.y & 511u) - (uint32_t)c0) & 511u) - pxoff;
         const bool ok = have && t < T && px >= 0 && px < npix;   // events at the sample time are dropped (tore.py:17)
         const uint32_t p2 = (q.y >> 9) & 3u;
-        int p = (int)p2 - 1;
+        p = (int)p2 - 1;
         if (ok && p2 == 3u) p = evw[q.y >> 11].w;
+        return ok;
+    };
+    auto insert = [&](bool ok, int32_t t, int px, int p) {
         float v = (float)(double)((int64_t)T - (int64_t)t);
         v = fminf(v, 500e6f);
         v = fmaxf((float)((double)logf(v + 1.0f) - log_min), 0.0f) * scale;
@@ -3972,14 +4000,52 @@ __global__ __launch_bounds__(kWave, EVREP_TST_WAVES) void k_tore_stream(const in
             }
         }
     };
+    // A unit of more than 64 * RB records of a window with ascending timestamps (r06b): its batches arrive LAST records first, so the
+    // first K records a FIFO meets are its K latest -- a counter per FIFO (the tag words), and only the records that meet a FIFO
+    // still below K are QUEUED; the values (int64 / float64 conversions, logf) and the K-deep cascade of dependent returning LDS
+    // atomics (~200 cycles each for a lone wave: 0.5 us per batch) run on full batches of queued records.  A 4 500-record unit of a
+    // 1 Mpx circle window holds at most 256 x K = 1 536 records that matter: 80 cascades -> ~25.  (The counter over-admits inside a
+    // batch -- every lane of a FIFO below K goes -- and the cascade keeps the K smallest values whatever it is fed: exact.)
+    int big = 0;
+    uint32_t qn = 0u;   // queued records (wave-uniform)
+    auto drain = [&](uint32_t n) {   // the first n (<= 64) queued records
+        const uint2 e = queue[lane];
+        const bool ok = (uint32_t)lane < n;
+        insert(ok, (int32_t)e.x, (int)(e.y & 0xffffu), (int)(e.y >> 16) - 1);
+    };
+    auto batch = [&](bool have, const Rec8 &q) {
+        int32_t t; int px, p;
+        const bool ok = digest(have, q, t, px, p);
+        if (big != 1 || unsorted) { insert(ok, t, px, p); return; }   // (big == 2: the sweep keeps its run table in `head`, no queue)
+        uint32_t *cn = tag + 2u * (uint32_t)(ok ? px : 0) + (p > 0 ? 0u : 1u);
+        const bool live = ok && *cn < (uint32_t)K;
+        const unsigned long long lm = __ballot(live);
+        if (lm == 0ull) return;                                    // (wave-uniform) nothing of this batch matters any more
+        if (live) {
+            atomicAdd(cn, 1u);
+            queue[qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)t, (uint32_t)px | ((uint32_t)(p > 0 ? 2 : 0) << 16));
+        }
+        qn += (uint32_t)__popcll(lm);
+        wave_phase();
+        if (qn >= (uint32_t)kWave) {
+            drain((uint32_t)kWave);
+            const uint2 mv = queue[kWave + lane];                  // the rest moves to the front
+            wave_phase();
+            if ((uint32_t)(kWave + lane) < qn) queue[lane] = mv;
+            qn -= (uint32_t)kWave;
+            wave_phase();
+        }
+    };
     wave_phase();
     if (has) {
 #ifdef EVREP_TIMING
         ts_nrec =
 #endif
         stream_unit_records<RB>(bv, b, beg, n_win, H * nchunk, klo, khi, head, srcs, StreamNoPre(),
-                                [&](bool have, const Rec8 &q, const uint2 &) { push(have, q); });
+                                [&](bool have, const Rec8 &q, const uint2 &) { batch(have, q); }, (uint32_t)EVREP_STREAM_BYRUN, !unsorted, &big);
     }
+    wave_phase();
+    if (qn) drain(qn);
     wave_phase();
     tile_store(reinterpret_cast<const float *>(tile), npix * C, dst);
 #ifdef EVREP_TIMING
@@ -4313,6 +4379,12 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                 int rk_ = 0;
                 uint32_t ro_ = 0;
                 bool more = true;
+                uint32_t run_len = 0u, run_base = 0u;   // of run rk_
+                auto load_run = [&]() {
+                    run_len = 0u;
+                    if (rk_ < nb) { run_len = R.pick(R.len0, R.len1, rk_); run_base = R.pick(run00, run01, rk_); }
+                };
+                if (by_run) load_run();
                 while (more) {
                     Rec8 q[G];
                     uint32_t bcnt[G];
@@ -4321,11 +4393,10 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                         bcnt[sl] = 0u;
                         uint32_t addr = 0u;
                         if (by_run) {
-                            uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
-                            while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
+                            while (rk_ < nb && ro_ >= run_len) { ++rk_; ro_ = 0; load_run(); }   // (the current run's length and base are kept in scalars)
                             if (rk_ < nb) {
-                                addr = R.pick(run00, run01, rk_) + ro_ + (uint32_t)lane;
-                                bcnt[sl] = min(lk - ro_, (uint32_t)kWave);
+                                addr = run_base + ro_ + (uint32_t)lane;
+                                bcnt[sl] = min(run_len - ro_, (uint32_t)kWave);
                                 ro_ += kWave;
                             }
                         } else {
@@ -4340,8 +4411,7 @@ __global__ __launch_bounds__(kWave, EVREP_VS_WAVES) void k_voxel_stream(const in
                         if ((uint32_t)lane < bcnt[sl]) q[sl] = s8[addr];
                     }
                     if (by_run) {
-                        uint32_t lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u;
-                        while (rk_ < nb && ro_ >= lk) { ++rk_; ro_ = 0; lk = rk_ < nb ? R.pick(R.len0, R.len1, rk_) : 0u; }
+                        while (rk_ < nb && ro_ >= run_len) { ++rk_; ro_ = 0; load_run(); }
                         more = rk_ < nb;
                     } else {
                         more = ro_ < nrec;
