@@ -4,6 +4,17 @@
 #include <cstdlib>
 #include "evrep_capi_builders.h"
 
+// LDS padding of a stream launch on SPARSE windows (<= 30 records per unit on average).  EventStack's and TORE's streams are bound by
+// their HBM stores there, and two workgroups fewer per CU leave them FASTER -- the store-pacing effect of DESIGN.md 3.2, found again
+// when a TORE experiment added 1 KB of LDS.  Library variants alternated (tools/experiments/lib_ab.sh; pad 0 / 1 / 2 / 4 KB, us):
+// EventStack 640x480 x 50 000 events 85.9 / 81.9 / 83.5 / 80.1, 1 Mpx 64.0 / 59.1 / 62.6 / 63.3, 1 Mpx edges 64.8 / 62.8 / 62.3 / 61.4;
+// TORE 77.9 / 77.7 / 84.3 / 90.4, 60.8 / 58.8 / 62.5 / 68.4, 640x480 edges 84.3 / 74.3 / 80.0 / 86.5.  The voxel grid and the
+// accumulators (latency-bound: they want every wave they can get) lose 8-30 % with any padding: none.
+static inline size_t stream_pad(const evrep_plan *plan, size_t bytes) {
+    const double per_chunk = (double)plan->max_events_per_window / ((double)plan->H * plan->nchunk);
+    return per_chunk <= 30.0 ? bytes : 0;
+}
+
 extern "C" {
 
 int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64_t *offsets, void *workspace,
@@ -19,7 +30,7 @@ int evrep_event_stack(const evrep_plan *plan, const int32_t *events, const int64
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
-#define ESS_LAUNCH(CM) k_event_stack_stream<CM, kRB><<<SPAN_GRID(1), kWave, event_stack_stream_lds_bytes(stack_size, kChunkPx, kRB), stream>>>( \
+#define ESS_LAUNCH(CM) k_event_stack_stream<CM, kRB><<<SPAN_GRID(1), kWave, event_stack_stream_lds_bytes(stack_size, kChunkPx, kRB) + stream_pad(plan, 1024), stream>>>( \
             bin_view(plan, events, workspace, true), offsets, plan->H, plan->W, plan->nchunk, us, stack_size, premap, scale, out)
         if (stack_size <= 8) ESS_LAUNCH(8); else if (stack_size <= 12) ESS_LAUNCH(12); else ESS_LAUNCH(16);
 #undef ESS_LAUNCH
@@ -147,7 +158,7 @@ int evrep_tore_ftime(const evrep_plan *plan, const int32_t *events, const int64_
         unit_cfg_geometry(us, plan);
         const UnitCfg &uc = us;
         constexpr int kRB = 4;
-        k_tore_stream<kRB><<<SPAN_GRID(1), kWave, tore_stream_lds_bytes(k, kChunkPx, kRB), stream>>>(
+        k_tore_stream<kRB><<<SPAN_GRID(1), kWave, tore_stream_lds_bytes(k, kChunkPx, kRB) + stream_pad(plan, 1024), stream>>>(
             reinterpret_cast<const int4 *>(events), bin_view(plan, events, workspace, true), offsets, sample_times, plan->H, plan->W,
             plan->nchunk, us, k, frame_mode, scale, out);
         LAUNCH_CHECK("k_tore_stream");
